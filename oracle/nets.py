@@ -1,0 +1,127 @@
+"""Oracle networks: functional PyTorch-CPU fp32 restatements.  TEST INFRASTRUCTURE ONLY.
+
+Every function takes ``w``: a mapping ``state_dict key -> tensor/ndarray`` in the reference's
+key names (see ``sharkshark-4k_amd/weights.py``) and an NCHW float32 tensor.
+"""
+from __future__ import annotations
+
+from typing import Mapping
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _t(v) -> torch.Tensor:
+    if isinstance(v, torch.Tensor):
+        return v.detach().to(torch.float32)
+    return torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+
+
+def _conv(x, w, name, stride=1, padding=1):
+    return F.conv2d(x, _t(w[name + ".weight"]), _t(w[name + ".bias"]), stride=stride, padding=padding)
+
+
+# ---------------------------------------------------------------------------------------
+def fsrcnn(x: torch.Tensor, w: Mapping, factor: int) -> torch.Tensor:
+    """FSRCNN forward on single-channel planes ``(P,1,H,W) -> (P,1,H*f,W*f)``.
+
+    Follows reference ``src/upscale/model/fsrcnn/model.py``: layers :17,:23,:29-36,:41,:46,
+    forward :55-62 (conv5x5 p2 + PReLU, 1x1 shrink + PReLU, 4x(conv3x3 p1 + PReLU), 1x1 expand +
+    PReLU, ConvTranspose 9x9 stride f, padding 4, output_padding f-1).
+    """
+    y = F.prelu(_conv(x, w, "feature_extraction.0", padding=2), _t(w["feature_extraction.1.weight"]))
+    y = F.prelu(_conv(y, w, "shrink.0", padding=0), _t(w["shrink.1.weight"]))
+    for i in range(4):
+        y = F.prelu(_conv(y, w, f"map.{2*i}", padding=1), _t(w[f"map.{2*i+1}.weight"]))
+    y = F.prelu(_conv(y, w, "expand.0", padding=0), _t(w["expand.1.weight"]))
+    return F.conv_transpose2d(y, _t(w["deconv.weight"]), _t(w["deconv.bias"]), stride=factor,
+                              padding=4, output_padding=factor - 1)
+
+
+# ---------------------------------------------------------------------------------------
+def srvgg(x: torch.Tensor, w: Mapping, num_conv: int, upscale: int) -> torch.Tensor:
+    """SRVGGNetCompact forward, reference ``src/upscale/model/realesrgan/factory.py:71-82``:
+    conv3x3+PReLU, num_conv x (conv3x3+PReLU), conv3x3 -> PixelShuffle(upscale) + nearest(x)."""
+    y = x
+    for i in range(num_conv + 1):
+        y = F.prelu(_conv(y, w, f"body.{2*i}"), _t(w[f"body.{2*i+1}.weight"]))
+    y = _conv(y, w, f"body.{2*num_conv+2}")
+    y = F.pixel_shuffle(y, upscale)
+    return y + F.interpolate(x, scale_factor=float(upscale), mode="nearest")
+
+
+# ---------------------------------------------------------------------------------------
+def _rdb(x, w, p):
+    lr = lambda t: F.leaky_relu(t, 0.2)
+    x1 = lr(_conv(x, w, p + ".conv1"))
+    x2 = lr(_conv(torch.cat((x, x1), 1), w, p + ".conv2"))
+    x3 = lr(_conv(torch.cat((x, x1, x2), 1), w, p + ".conv3"))
+    x4 = lr(_conv(torch.cat((x, x1, x2, x3), 1), w, p + ".conv4"))
+    x5 = _conv(torch.cat((x, x1, x2, x3, x4), 1), w, p + ".conv5")
+    return x5 * 0.2 + x
+
+
+def rrdbnet(x: torch.Tensor, w: Mapping, scale: int, num_block: int) -> torch.Tensor:
+    """RRDBNet forward.  **[external, parity unpinned]**: restates the published BasicSR
+    ``basicsr/archs/rrdbnet_arch.py`` (the class the reference imports at
+    ``realesrgan/factory.py:6`` and instantiates at :113-125); see SURVEY.md §8(a) row a10."""
+    if scale == 2:
+        feat = F.pixel_unshuffle(x, 2)
+    elif scale == 1:
+        feat = F.pixel_unshuffle(x, 4)
+    else:
+        feat = x
+    feat = _conv(feat, w, "conv_first")
+    body = feat
+    for b in range(num_block):
+        t = body
+        for r in (1, 2, 3):
+            t = _rdb(t, w, f"body.{b}.rdb{r}")
+        body = t * 0.2 + body
+    feat = feat + _conv(body, w, "conv_body")
+    lr = lambda t: F.leaky_relu(t, 0.2)
+    feat = lr(_conv(F.interpolate(feat, scale_factor=2, mode="nearest"), w, "conv_up1"))
+    feat = lr(_conv(F.interpolate(feat, scale_factor=2, mode="nearest"), w, "conv_up2"))
+    return _conv(lr(_conv(feat, w, "conv_hr")), w, "conv_last")
+
+
+# ---------------------------------------------------------------------------------------
+def _bibuffer_conv_f1(x, w, name):
+    """A ``BiBufferConv`` fed exactly one frame (reference ``bsvd/model.py:22-53,59-138``):
+    left buffer and right neighbour are zeros, so the ShiftConv input is
+    ``cat(zeros(fold), zeros(fold), center[:, 2*fold:])`` with ``fold = C // 8``."""
+    fold = x.shape[1] // 8
+    xm = x.clone()
+    xm[:, : 2 * fold] = 0
+    return _conv(xm, w, name + ".op.conv")
+
+
+def _memcv(x, w, name):
+    x = F.relu6(_bibuffer_conv_f1(x, w, name + ".c1"))
+    return F.relu6(_bibuffer_conv_f1(x, w, name + ".c2"))
+
+
+def _denblock(x, w, p):
+    """One ``DenBlock`` (reference ``bsvd/model.py:353-442``) on a single frame."""
+    skip1 = x[:, 0:3]
+    x0 = F.relu6(_conv(F.relu6(_conv(x, w, p + ".inc.convblock.0")), w, p + ".inc.convblock.3"))
+    x1 = _memcv(F.relu6(_conv(x0, w, p + ".downc0.convblock.0", stride=2)), w, p + ".downc0.memconv")
+    x2 = _memcv(F.relu6(_conv(x1, w, p + ".downc1.convblock.0", stride=2)), w, p + ".downc1.memconv")
+    x2 = F.pixel_shuffle(_conv(_memcv(x2, w, p + ".upc2.memconv"), w, p + ".upc2.convblock.0"), 2)
+    x1 = F.pixel_shuffle(_conv(_memcv(x2 + x1, w, p + ".upc1.memconv"), w, p + ".upc1.convblock.0"), 2)
+    y = _conv(F.relu6(_conv(x1 + x0, w, p + ".outc.convblock.0")), w, p + ".outc.convblock.3")
+    y = y.clone()
+    y[:, :3] = skip1 - y[:, :3]
+    return y
+
+
+def bsvd_f1(x: torch.Tensor, w: Mapping) -> torch.Tensor:
+    """BSVD exactly as the service drives it: ``(N,1,4,H,W) -> (N,1,3,H,W)`` with F = 1 frame
+    per call (reference ``fsrcnn_upscaler.py:277``; ``bsvd/model.py:515-580``).  With one frame
+    the streaming pipeline degenerates to a stateless two-DenBlock feed-forward net."""
+    n, f, c, h, ww = x.shape
+    assert f == 1
+    y = _denblock(x.reshape(n, c, h, ww), w, "temp1")
+    y = _denblock(y, w, "temp2")
+    return y.reshape(n, 1, y.shape[1], h, ww)
