@@ -1,0 +1,163 @@
+/*
+ * ss4k.h — C ABI of libss4k_hip.so: the MI355X (gfx950) replacement for the arithmetic on
+ * sharkshark-4k's per-frame upscale path (reference: src/upscale/, Python only).
+ *
+ * The reference has no C interface; every entry point below cites the Python call it replaces
+ * (paths relative to the reference repo).  Conventions:
+ *   - return 0 on success, a negative SS4K_E* code on failure; ss4k_last_error() gives the text
+ *     (thread-local).  Nothing throws across this boundary.
+ *   - *_dev pointers are device (HIP) pointers BORROWED from the caller (PyTorch owns the I/O
+ *     tensors); the library owns weights and workspaces.
+ *   - work is enqueued on the caller's stream (hipStream_t passed as void*; NULL = default
+ *     stream) with no hidden synchronisation, like the reference's eager torch calls.
+ *   - one ss4k_ctx per device; a ctx and its children are not thread-safe (the reference's
+ *     worker is a single-threaded process loop, base_service.py:33-60).
+ *   - there is no CPU fallback: without a HIP device ss4k_ctx_create fails.
+ */
+#ifndef SS4K_H
+#define SS4K_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS4K_ABI_VERSION 1
+
+enum { SS4K_OK = 0, SS4K_EINVAL = -22, SS4K_ENOMEM = -12, SS4K_EHIP = -5, SS4K_ENODEV = -19 };
+
+typedef struct ss4k_ctx ss4k_ctx;
+typedef struct ss4k_model ss4k_model;
+typedef struct ss4k_upscaler ss4k_upscaler;
+
+/* network families on the path */
+enum ss4k_model_kind {
+  SS4K_FSRCNN = 1,  /* model/fsrcnn/model.py:6-62 */
+  SS4K_RRDBNET = 2, /* basicsr RRDBNet, instantiated realesrgan/factory.py:113-125 */
+  SS4K_SRVGG = 3,   /* SRVGGNetCompact, realesrgan/factory.py:18-82 */
+  SS4K_BSVD = 4     /* BSVD driven with F = 1, bsvd/model.py:467-588, fsrcnn_upscaler.py:277 */
+};
+
+/* arithmetic/storage type of activations and weights inside the network.
+ * F32: fp32 storage, exact-fp32 MFMA (parity gate, rtol 1e-3 / atol 1e-4 vs PyTorch CPU).
+ * F16: fp16 storage, fp32 accumulate (what RealESRGANer(half=True) + TensorRT fp16 does,
+ *      realesrgan/factory.py:168,206-230). */
+enum ss4k_dtype { SS4K_F32 = 0, SS4K_F16 = 1 };
+
+typedef struct ss4k_model_desc {
+  int32_t kind;        /* ss4k_model_kind */
+  int32_t dtype;       /* ss4k_dtype */
+  int32_t scale;       /* FSRCNN: deconv stride 2|4; RRDBNet: 1|2|4; SRVGG: 2|4; BSVD: 1 */
+  int32_t num_feat;    /* RRDBNet/SRVGG trunk width (64); multiple of 16 */
+  int32_t num_block;   /* RRDBNet: #RRDB (23|6); SRVGG: num_conv (32|16) */
+  int32_t num_grow_ch; /* RRDBNet growth (32) */
+  int32_t bsvd_chns[3];/* BSVD U-Net widths (32,64,128) */
+  int32_t bsvd_mid_ch; /* 32 */
+  int32_t bsvd_interm_ch; /* 30 */
+  int32_t reserved[5];
+} ss4k_model_desc;
+
+int ss4k_abi_version(void);
+const char* ss4k_last_error(void);
+
+/* one per HIP device; replaces `.to(device)` / torch's implicit CUDA context. */
+int ss4k_ctx_create(int hip_device, ss4k_ctx** out);
+void ss4k_ctx_destroy(ss4k_ctx* ctx);
+int ss4k_ctx_device(const ss4k_ctx* ctx);
+
+/* Number of fp32 scalars ss4k_model_create expects: the model's state_dict tensors flattened and
+ * concatenated in state_dict order (OIHW conv weights, then bias, PReLU slopes; ConvTranspose
+ * weight as (C_in, C_out, kH, kW)).  Host-only, no GPU needed.  Returns 0 for a bad desc. */
+size_t ss4k_model_param_count(const ss4k_model_desc* desc);
+
+/* Replaces build_model(...) (fsrcnn/factory.py:5, realesrgan/factory.py:108, bsvd/factory.py:21):
+ * repacks the state_dict blob into MFMA-fragment order and uploads it.  host_weights may be
+ * freed on return. */
+int ss4k_model_create(ss4k_ctx* ctx, const ss4k_model_desc* desc, const float* host_weights,
+                      size_t n_floats, ss4k_model** out);
+void ss4k_model_destroy(ss4k_model* m);
+
+/* Output geometry of ss4k_model_forward for an (n, c, h, w) input. */
+int ss4k_model_out_shape(const ss4k_model* m, int n, int h, int w, int* out_c, int* out_h, int* out_w);
+/* Input channel count the model expects (FSRCNN 1, RRDBNet/SRVGG 3, BSVD 4). */
+int ss4k_model_in_channels(const ss4k_model* m);
+
+/* Replaces `self.model(x)` (fsrcnn_upscaler.py:181,293-297) and `self.denoise_model(x)`
+ * (:277): x is contiguous NCHW fp32 in [0,1] on the device; result contiguous NCHW fp32.
+ * BSVD: in (n,4,h,w) = the reference's (n,1,4,h,w); out (n,3,h,w).  FSRCNN: (planes,1,h,w). */
+int ss4k_model_forward(ss4k_model* m, const float* in_nchw_dev, float* out_nchw_dev, int n, int h,
+                       int w, void* hip_stream);
+
+/* ---- the service's frame-in/frame-out hot path ------------------------------------------- */
+typedef struct ss4k_upscale_cfg {
+  int32_t lr_h, lr_w;       /* self.lr_shape (fsrcnn_upscaler.py:93-100) */
+  int32_t out_h, out_w;     /* self.output_shape, 0,0 = None (fsrcnn_upscaler.py:107) */
+  int32_t lr_hr_resize;     /* :92 */
+  int32_t single_mode;      /* :109  (per-frame path upscale_single vs batched upscale_multi) */
+  int32_t sr_is_realesrgan; /* upscaler_model == 'realesrgan' (model gets (1,3,H,W)); else FSRCNN planes */
+  int32_t denoising;        /* :111 */
+  int32_t reserved0;
+  double denoise_rate;      /* :102 (python float = double) */
+  int32_t reserved[6];
+} ss4k_upscale_cfg;
+
+/* Replaces FsrcnnUpscalerService.proc_init (fsrcnn_upscaler.py:118-139): binds the SR model,
+ * the optional BSVD model, and builds the four fixed depthwise kernels (:135-138). */
+int ss4k_upscaler_create(ss4k_ctx* ctx, const ss4k_upscale_cfg* cfg, ss4k_model* sr,
+                         ss4k_model* denoise /* NULL unless cfg->denoising */, ss4k_upscaler** out);
+void ss4k_upscaler_destroy(ss4k_upscaler* up);
+/* forget `lr_prev` state: the next frame is a "first frame" again (noise map 0.05, :269-271) */
+int ss4k_upscaler_reset(ss4k_upscaler* up);
+int ss4k_upscaler_out_shape(const ss4k_upscaler* up, int n, int h, int w, int* out_h, int* out_w);
+
+/* Replaces FsrcnnUpscalerService.upscale(frames) (fsrcnn_upscaler.py:144-326): uint8 NHWC
+ * (n,h,w,3) device frames in, uint8 NHWC (n,out_h,out_w,3) device frames out. */
+int ss4k_upscale_frames(ss4k_upscaler* up, const uint8_t* in_nhwc_dev, int n, int h, int w,
+                        uint8_t* out_nhwc_dev, size_t out_capacity_bytes, void* hip_stream);
+
+/* Parity taps: fp32 NCHW copies of the intermediates of the LAST ss4k_upscale_frames call
+ * (the oracle exposes the same points).  which: 0 = lr (after pre-resize/denoise),
+ * 1 = model output (after sharpen_hr if denoising), 2 = after mean/std match,
+ * 3 = after local colour match (multi mode only), 4 = final float before *255 truncation.
+ * Enable with ss4k_upscaler_enable_taps before the call; shape returned via dims[4] (n,c,h,w). */
+int ss4k_upscaler_enable_taps(ss4k_upscaler* up, int enable);
+int ss4k_upscaler_read_tap(ss4k_upscaler* up, int which, float* out_dev, size_t capacity_floats,
+                           int dims[4], void* hip_stream);
+
+/* ---- granular glue ops (each replaces one torch call on the path; used by the parity tests) */
+/* img.permute(0,3,1,2) / 255.0  (fsrcnn_upscaler.py:170-171) */
+int ss4k_op_u8nhwc_to_f32nchw(ss4k_ctx* ctx, const uint8_t* in_dev, float* out_dev, int n, int h, int w,
+                              int c, void* hip_stream);
+/* F.interpolate(mode='area') == adaptive average pooling (:174-176, :205-210, :239-241) */
+int ss4k_op_area_resize(ss4k_ctx* ctx, const float* in_dev, float* out_dev, int planes, int h, int w,
+                        int oh, int ow, void* hip_stream);
+/* F.interpolate(mode='bicubic'), A=-0.75, align_corners=False (:226-228, :319-321) */
+int ss4k_op_bicubic_resize(ss4k_ctx* ctx, const float* in_dev, float* out_dev, int planes, int h, int w,
+                           int oh, int ow, void* hip_stream);
+/* F.interpolate(mode='bilinear'), align_corners=False (:214-216) */
+int ss4k_op_bilinear_resize(ss4k_ctx* ctx, const float* in_dev, float* out_dev, int planes, int h, int w,
+                            int oh, int ow, void* hip_stream);
+/* depthwise KxK conv with padding_mode='reflect' (blur_ker / sharpen_ker, :20-84); k2d_host = K*K
+ * fp32 taps on the host, K odd <= 17 */
+int ss4k_op_depthwise_reflect(ss4k_ctx* ctx, const float* in_dev, float* out_dev, int planes, int h, int w,
+                              const float* k2d_host, int k, void* hip_stream);
+/* per-plane mean and unbiased std (:192-197): stats_dev[2*p] = mean, [2*p+1] = std */
+int ss4k_op_plane_stats(ss4k_ctx* ctx, const float* in_dev, float* stats_dev, int planes, int hw,
+                        void* hip_stream);
+/* (clamp(x,0,1) * 255).permute(0,2,3,1).to(uint8) — truncation (:232-233) */
+int ss4k_op_f32nchw_to_u8nhwc(ss4k_ctx* ctx, const float* in_dev, uint8_t* out_dev, int n, int c, int h,
+                              int w, void* hip_stream);
+
+/* ---- measurement hooks (bench.py: live per-kernel timing with HIP events on the launch stream) */
+/* When enabled, every launch of the dominant conv kernel is bracketed with hipEvents on the
+ * stream it is launched on; ss4k_prof_read returns (#launches, total ms, algorithmic FLOPs). */
+int ss4k_prof_enable(ss4k_ctx* ctx, int enable);
+int ss4k_prof_reset(ss4k_ctx* ctx);
+int ss4k_prof_read(ss4k_ctx* ctx, int64_t* launches, double* total_ms, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SS4K_H */

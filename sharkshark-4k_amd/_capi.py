@@ -1,0 +1,311 @@
+"""ctypes binding of libss4k_hip.so (C ABI declared in include/ss4k.h).
+
+PyTorch is used only as the owner of device memory and streams: every function here takes
+``torch`` CUDA(HIP) tensors, passes their ``data_ptr()`` and the current stream to the library and
+returns tensors.  There is no CPU fallback: a missing library or a failing call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libss4k_hip.so")
+
+FSRCNN, RRDBNET, SRVGG, BSVD = 1, 2, 3, 4
+F32, F16 = 0, 1
+
+# every symbol include/ss4k.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "ss4k_abi_version", "ss4k_last_error", "ss4k_ctx_create", "ss4k_ctx_destroy", "ss4k_ctx_device",
+    "ss4k_model_param_count", "ss4k_model_create", "ss4k_model_destroy", "ss4k_model_out_shape",
+    "ss4k_model_in_channels", "ss4k_model_forward", "ss4k_upscaler_create", "ss4k_upscaler_destroy",
+    "ss4k_upscaler_reset", "ss4k_upscaler_out_shape", "ss4k_upscale_frames", "ss4k_upscaler_enable_taps",
+    "ss4k_upscaler_read_tap", "ss4k_op_u8nhwc_to_f32nchw", "ss4k_op_area_resize", "ss4k_op_bicubic_resize",
+    "ss4k_op_bilinear_resize", "ss4k_op_depthwise_reflect", "ss4k_op_plane_stats", "ss4k_op_f32nchw_to_u8nhwc",
+    "ss4k_prof_enable", "ss4k_prof_reset", "ss4k_prof_read",
+]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("dtype", C.c_int32), ("scale", C.c_int32), ("num_feat", C.c_int32),
+                ("num_block", C.c_int32), ("num_grow_ch", C.c_int32), ("bsvd_chns", C.c_int32 * 3),
+                ("bsvd_mid_ch", C.c_int32), ("bsvd_interm_ch", C.c_int32), ("reserved", C.c_int32 * 5)]
+
+
+class UpscaleCfg(C.Structure):
+    _fields_ = [("lr_h", C.c_int32), ("lr_w", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32),
+                ("lr_hr_resize", C.c_int32), ("single_mode", C.c_int32), ("sr_is_realesrgan", C.c_int32),
+                ("denoising", C.c_int32), ("reserved0", C.c_int32), ("denoise_rate", C.c_double),
+                ("reserved", C.c_int32 * 6)]
+
+
+class Ss4kError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library; fail loudly if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Ss4kError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB_PATH)
+    vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
+    L.ss4k_last_error.restype = C.c_char_p
+    L.ss4k_ctx_create.argtypes = [i, C.POINTER(vp)]
+    L.ss4k_ctx_destroy.argtypes = [vp]; L.ss4k_ctx_destroy.restype = None
+    L.ss4k_ctx_device.argtypes = [vp]
+    L.ss4k_model_param_count.argtypes = [C.POINTER(ModelDesc)]; L.ss4k_model_param_count.restype = sz
+    L.ss4k_model_create.argtypes = [vp, C.POINTER(ModelDesc), vp, sz, C.POINTER(vp)]
+    L.ss4k_model_destroy.argtypes = [vp]; L.ss4k_model_destroy.restype = None
+    L.ss4k_model_out_shape.argtypes = [vp, i, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    L.ss4k_model_in_channels.argtypes = [vp]
+    L.ss4k_model_forward.argtypes = [vp, vp, vp, i, i, i, vp]
+    L.ss4k_upscaler_create.argtypes = [vp, C.POINTER(UpscaleCfg), vp, vp, C.POINTER(vp)]
+    L.ss4k_upscaler_destroy.argtypes = [vp]; L.ss4k_upscaler_destroy.restype = None
+    L.ss4k_upscaler_reset.argtypes = [vp]
+    L.ss4k_upscaler_out_shape.argtypes = [vp, i, i, i, C.POINTER(i), C.POINTER(i)]
+    L.ss4k_upscale_frames.argtypes = [vp, vp, i, i, i, vp, sz, vp]
+    L.ss4k_upscaler_enable_taps.argtypes = [vp, i]
+    L.ss4k_upscaler_read_tap.argtypes = [vp, i, vp, sz, C.POINTER(i * 4), vp]
+    L.ss4k_op_u8nhwc_to_f32nchw.argtypes = [vp, vp, vp, i, i, i, i, vp]
+    for name in ("ss4k_op_area_resize", "ss4k_op_bicubic_resize", "ss4k_op_bilinear_resize"):
+        getattr(L, name).argtypes = [vp, vp, vp, i, i, i, i, i, vp]
+    L.ss4k_op_depthwise_reflect.argtypes = [vp, vp, vp, i, i, i, vp, i, vp]
+    L.ss4k_op_plane_stats.argtypes = [vp, vp, vp, i, i, vp]
+    L.ss4k_op_f32nchw_to_u8nhwc.argtypes = [vp, vp, vp, i, i, i, i, vp]
+    L.ss4k_prof_enable.argtypes = [vp, i]
+    L.ss4k_prof_reset.argtypes = [vp]
+    L.ss4k_prof_read.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    _lib = L
+    return L
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise Ss4kError(f"libss4k_hip error {rc}: {lib().ss4k_last_error().decode()}")
+
+
+def _stream() -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_index(device) -> int:
+    d = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+class Context:
+    """One per GPU (include/ss4k.h: ss4k_ctx)."""
+
+    def __init__(self, device=0):
+        self.device_index = _dev_index(device)
+        self.device = torch.device("cuda", self.device_index)
+        h = C.c_void_p()
+        _check(lib().ss4k_ctx_create(self.device_index, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ss4k_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- profiling hooks (bench.py roofline leg)
+    def prof_enable(self, on: bool):
+        _check(lib().ss4k_prof_enable(self._h, int(on)))
+
+    def prof_reset(self):
+        _check(lib().ss4k_prof_reset(self._h))
+
+    def prof_read(self) -> Tuple[int, float, float]:
+        n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+        _check(lib().ss4k_prof_read(self._h, C.byref(n), C.byref(ms), C.byref(fl)))
+        return n.value, ms.value, fl.value
+
+    # -- granular ops (tests)
+    def _f32(self, t):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        return t
+
+    def u8nhwc_to_f32nchw(self, x: torch.Tensor) -> torch.Tensor:
+        assert x.is_cuda and x.dtype == torch.uint8 and x.is_contiguous() and x.ndim == 4
+        n, h, w, c = x.shape
+        out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+        _check(lib().ss4k_op_u8nhwc_to_f32nchw(self._h, x.data_ptr(), out.data_ptr(), n, h, w, c, _stream()))
+        return out
+
+    def _resize(self, fn, x, size):
+        self._f32(x)
+        n, c, h, w = x.shape
+        out = torch.empty((n, c, size[0], size[1]), dtype=torch.float32, device=x.device)
+        _check(fn(self._h, x.data_ptr(), out.data_ptr(), n * c, h, w, size[0], size[1], _stream()))
+        return out
+
+    def area_resize(self, x, size):
+        return self._resize(lib().ss4k_op_area_resize, x, size)
+
+    def bicubic_resize(self, x, size):
+        return self._resize(lib().ss4k_op_bicubic_resize, x, size)
+
+    def bilinear_resize(self, x, size):
+        return self._resize(lib().ss4k_op_bilinear_resize, x, size)
+
+    def depthwise_reflect(self, x, k2d: np.ndarray):
+        self._f32(x)
+        n, c, h, w = x.shape
+        k = np.ascontiguousarray(k2d, dtype=np.float32)
+        out = torch.empty_like(x)
+        _check(lib().ss4k_op_depthwise_reflect(self._h, x.data_ptr(), out.data_ptr(), n * c, h, w,
+                                               k.ctypes.data_as(C.c_void_p), k.shape[0], _stream()))
+        torch.cuda.current_stream().synchronize()  # k lives on the host until the copy is done
+        return out
+
+    def plane_stats(self, x):
+        self._f32(x)
+        n, c, h, w = x.shape
+        out = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
+        _check(lib().ss4k_op_plane_stats(self._h, x.data_ptr(), out.data_ptr(), n * c, h * w, _stream()))
+        return out
+
+    def f32nchw_to_u8nhwc(self, x):
+        self._f32(x)
+        n, c, h, w = x.shape
+        out = torch.empty((n, h, w, c), dtype=torch.uint8, device=x.device)
+        _check(lib().ss4k_op_f32nchw_to_u8nhwc(self._h, x.data_ptr(), out.data_ptr(), n, c, h, w, _stream()))
+        return out
+
+
+def make_desc(kind: int, dtype: int = F32, scale: int = 2, num_feat: int = 64, num_block: int = 23,
+              num_grow_ch: int = 32, bsvd_chns: Sequence[int] = (32, 64, 128), bsvd_mid_ch: int = 32,
+              bsvd_interm_ch: int = 30) -> ModelDesc:
+    d = ModelDesc()
+    d.kind, d.dtype, d.scale, d.num_feat, d.num_block, d.num_grow_ch = kind, dtype, scale, num_feat, num_block, num_grow_ch
+    d.bsvd_chns = (C.c_int32 * 3)(*bsvd_chns)
+    d.bsvd_mid_ch, d.bsvd_interm_ch = bsvd_mid_ch, bsvd_interm_ch
+    return d
+
+
+def param_count(desc: ModelDesc) -> int:
+    return int(lib().ss4k_model_param_count(C.byref(desc)))
+
+
+class Model:
+    """A network resident on one GPU; callable like the reference's ``self.model`` (NCHW float in/out)."""
+
+    def __init__(self, ctx: Context, desc: ModelDesc, flat_weights: np.ndarray):
+        self.ctx, self.desc = ctx, desc
+        w = np.ascontiguousarray(flat_weights, dtype=np.float32)
+        h = C.c_void_p()
+        with torch.cuda.device(ctx.device):
+            _check(lib().ss4k_model_create(ctx._h, C.byref(desc), w.ctypes.data_as(C.c_void_p), w.size, C.byref(h)))
+        self._h = h
+        self.in_channels = lib().ss4k_model_in_channels(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ss4k_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def out_shape(self, n, h, w):
+        oc, oh, ow = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().ss4k_model_out_shape(self._h, n, h, w, C.byref(oc), C.byref(oh), C.byref(ow)))
+        return oc.value, oh.value, ow.value
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        squeeze_f = False
+        if x.ndim == 5:  # BSVD's (N, F=1, C, H, W)
+            assert x.shape[1] == 1, "BSVD is driven with one frame per call (fsrcnn_upscaler.py:277)"
+            x = x[:, 0]
+            squeeze_f = True
+        assert x.ndim == 4 and x.shape[1] == self.in_channels, f"expected (N,{self.in_channels},H,W), got {tuple(x.shape)}"
+        x = x.to(device=self.ctx.device, dtype=torch.float32).contiguous()
+        n, _, h, w = x.shape
+        oc, oh, ow = self.out_shape(n, h, w)
+        out = torch.empty((n, oc, oh, ow), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(self.ctx.device):
+            _check(lib().ss4k_model_forward(self._h, x.data_ptr(), out.data_ptr(), n, h, w, _stream()))
+        return out.unsqueeze(1) if squeeze_f else out
+
+    forward = __call__
+
+    def eval(self):
+        return self
+
+
+class Upscaler:
+    """ss4k_upscaler: the frame-in/frame-out path (uint8 NHWC -> uint8 NHWC)."""
+
+    def __init__(self, ctx: Context, sr: Model, lr_shape, output_shape=None, lr_hr_resize=True, single_mode=False,
+                 denoise: Optional[Model] = None, denoise_rate: float = 1.0):
+        self.ctx, self.sr, self.denoise = ctx, sr, denoise
+        cfg = UpscaleCfg()
+        cfg.lr_h, cfg.lr_w = int(lr_shape[0]), int(lr_shape[1])
+        cfg.out_h, cfg.out_w = (0, 0) if output_shape is None else (int(output_shape[0]), int(output_shape[1]))
+        cfg.lr_hr_resize, cfg.single_mode = int(bool(lr_hr_resize)), int(bool(single_mode))
+        cfg.sr_is_realesrgan = int(sr.in_channels == 3)
+        cfg.denoising, cfg.denoise_rate = int(denoise is not None), float(denoise_rate)
+        h = C.c_void_p()
+        _check(lib().ss4k_upscaler_create(ctx._h, C.byref(cfg), sr._h, denoise._h if denoise is not None else None,
+                                          C.byref(h)))
+        self._h, self.cfg = h, cfg
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ss4k_upscaler_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        _check(lib().ss4k_upscaler_reset(self._h))
+
+    def out_shape(self, n, h, w):
+        oh, ow = C.c_int(), C.c_int()
+        _check(lib().ss4k_upscaler_out_shape(self._h, n, h, w, C.byref(oh), C.byref(ow)))
+        return oh.value, ow.value
+
+    def enable_taps(self, on=True):
+        _check(lib().ss4k_upscaler_enable_taps(self._h, int(on)))
+
+    def read_tap(self, which: int) -> torch.Tensor:
+        dims = (C.c_int * 4)()
+        _check(lib().ss4k_upscaler_read_tap(self._h, which, None, 0, C.byref(dims), _stream()))
+        out = torch.empty(tuple(dims), dtype=torch.float32, device=self.ctx.device)
+        _check(lib().ss4k_upscaler_read_tap(self._h, which, out.data_ptr(), out.numel(), C.byref(dims), _stream()))
+        return out
+
+    def __call__(self, frames: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert frames.is_cuda and frames.dtype == torch.uint8 and frames.ndim == 4 and frames.shape[-1] == 3
+        frames = frames.contiguous()
+        n, h, w, _ = frames.shape
+        oh, ow = self.out_shape(n, h, w)
+        if out is None:
+            out = torch.empty((n, oh, ow, 3), dtype=torch.uint8, device=frames.device)
+        with torch.cuda.device(self.ctx.device):
+            _check(lib().ss4k_upscale_frames(self._h, frames.data_ptr(), n, h, w, out.data_ptr(), out.numel(), _stream()))
+        return out

@@ -1,0 +1,68 @@
+"""Build libss4k_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build()."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libss4k_hip.so")
+SOURCES = ["conv_mfma.hip", "glue.hip", "fsrcnn.hip", "pack.cpp", "models.cpp", "api.cpp"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-x", "hip", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-variable"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _needs_build(obj: str, src: str) -> bool:
+    if not os.path.exists(obj):
+        return True
+    newest = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
+    newest = max(newest, os.path.getmtime(src), os.path.getmtime(os.path.join(HERE, "..", "include", "ss4k.h")))
+    return os.path.getmtime(obj) < newest
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = _hipcc()
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
+        if force or _needs_build(obj, src):
+            jobs.append((src, obj))
+
+    def run(job):
+        src, obj = job
+        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(objdir, os.path.splitext(s)[0] + ".o") for s in SOURCES]
+    if jobs or not os.path.exists(LIB):
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", LIB]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,365 @@
+// C ABI (include/ss4k.h): context, models, the frame-in/frame-out upscaler and the granular ops.
+#include "models.h"
+#include <cmath>
+#include <cstdarg>
+#include <memory>
+
+namespace ss4k {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+
+template <typename F>
+static int guard(F&& f) {
+  try { f(); g_err[0] = 0; return SS4K_OK; }
+  catch (const Error& e) { set_error("%s", e.what()); return e.code; }
+  catch (const std::bad_alloc&) { set_error("out of host memory"); return SS4K_ENOMEM; }
+  catch (const std::exception& e) { set_error("%s", e.what()); return SS4K_EINVAL; }
+}
+
+static std::vector<float> gaussian_taps(int k, float sigma) {  // blur_ker, fsrcnn_upscaler.py:20-52
+  std::vector<float> t((size_t)k * k);
+  const float mean = (k - 1) / 2.0f, var = sigma * sigma;
+  float sum = 0.f;
+  for (int y = 0; y < k; ++y)
+    for (int x = 0; x < k; ++x) {
+      const float dx = x - mean, dy = y - mean;
+      const float v = (1.0f / (2.0f * (float)M_PI * var)) * expf(-(dx * dx + dy * dy) / (2 * var));
+      t[(size_t)y * k + x] = v; sum += v;
+    }
+  for (auto& v : t) v /= sum;
+  return t;
+}
+static std::vector<float> sharpen_taps(double strength) {  // sharpen_ker, fsrcnn_upscaler.py:54-84
+  std::vector<float> t(9);
+  const float s = (float)strength, one_m = (float)(1.0 - strength);
+  float sum = 0.f;
+  for (int i = 0; i < 9; ++i) {
+    const float sharp = i == 4 ? 9.f : -1.f, ident = i == 4 ? 1.f : 0.f;
+    t[i] = sharp * s + one_m * ident; sum += t[i];
+  }
+  for (auto& v : t) v /= sum;
+  return t;
+}
+
+struct Upscaler {
+  ss4k_ctx* ctx; ss4k_upscale_cfg cfg; Model* sr; Model* dn;
+  DevBuf k_blur17, k_sharp, k_sharp_hr;
+  DevBuf img, lr, lr4, den, hr, hr2, lb, hb, lbb, hbb, st_hr, st_lr;
+  bool first_frame = true;
+  bool taps_on = false;
+  DevBuf tap[5]; int tap_dims[5][4] = {};
+
+  void save_tap(int which, const float* src, int n, int c, int h, int w, hipStream_t st) {
+    if (!taps_on) return;
+    const size_t bytes = (size_t)n * c * h * w * 4;
+    tap[which].ensure(bytes);
+    SS4K_HIP(hipMemcpyAsync(tap[which].ptr, src, bytes, hipMemcpyDeviceToDevice, st));
+    tap_dims[which][0] = n; tap_dims[which][1] = c; tap_dims[which][2] = h; tap_dims[which][3] = w;
+  }
+  void append_tap(int which, const float* src, int idx, int n, int c, int h, int w, hipStream_t st) {
+    // single mode: frames are processed one by one; taps are stacked to (n,c,h,w)
+    if (!taps_on) return;
+    const size_t per = (size_t)c * h * w * 4;
+    if (idx == 0) tap[which].ensure(per * n);
+    SS4K_HIP(hipMemcpyAsync((char*)tap[which].ptr + per * idx, src, per, hipMemcpyDeviceToDevice, st));
+    tap_dims[which][0] = n; tap_dims[which][1] = c; tap_dims[which][2] = h; tap_dims[which][3] = w;
+  }
+
+  void out_shape(int h, int w, int* oh, int* ow) const {
+    int lh = h, lw = w;
+    if (cfg.single_mode) { lh = cfg.lr_h; lw = cfg.lr_w; }
+    else if ((w > cfg.lr_w || h > cfg.lr_h) && cfg.lr_hr_resize) { lh = cfg.lr_h; lw = cfg.lr_w; }
+    int oc, H, W; sr->out_shape(1, lh, lw, &oc, &H, &W);
+    const bool resize = cfg.out_h > 0 && (cfg.single_mode || cfg.lr_hr_resize);
+    *oh = resize ? cfg.out_h : H; *ow = resize ? cfg.out_w : W;
+  }
+
+  // fsrcnn_upscaler.py:168-233
+  void multi(const uint8_t* in, int n, int h, int w, uint8_t* out, hipStream_t st) {
+    const int P = 3 * n;
+    img.ensure((size_t)P * h * w * 4);
+    op_u8nhwc_to_f32nchw(in, img.as<float>(), n, h, w, 3, st);
+    const float* lrp = img.as<float>(); int lh = h, lw = w;
+    if ((w > cfg.lr_w || h > cfg.lr_h) && cfg.lr_hr_resize) {
+      lh = cfg.lr_h; lw = cfg.lr_w;
+      lr.ensure((size_t)P * lh * lw * 4);
+      op_area(img.as<float>(), lr.as<float>(), P, h, w, lh, lw, st);
+      lrp = lr.as<float>();
+    }
+    int oc, H, W; sr->out_shape(n, lh, lw, &oc, &H, &W);
+    hr.ensure((size_t)P * H * W * 4);
+    float* hrp = hr.as<float>();
+    sr->forward(lrp, hrp, n, lh, lw, st);
+    save_tap(0, lrp, n, 3, lh, lw, st); save_tap(1, hrp, n, 3, H, W, st);
+    st_hr.ensure(P * 8); st_lr.ensure(P * 8);
+    op_plane_stats(ctx, hrp, st_hr.as<float>(), P, H * W, st);
+    op_plane_stats(ctx, lrp, st_lr.as<float>(), P, lh * lw, st);
+    op_normalize(hrp, st_hr.as<float>(), st_lr.as<float>(), P, H * W, st);
+    save_tap(2, hrp, n, 3, H, W, st);
+    const int mh = H / 8, mw = W / 8;
+    if (mh > 8 && H > 64 && W > 64) {  // local colour match, :201-218
+      const size_t sm = (size_t)P * mh * mw * 4;
+      lb.ensure(sm); hb.ensure(sm); lbb.ensure(sm); hbb.ensure(sm);
+      op_area(lrp, lb.as<float>(), P, lh, lw, mh, mw, st);
+      op_area(hrp, hb.as<float>(), P, H, W, mh, mw, st);
+      op_depthwise_reflect(lb.as<float>(), lbb.as<float>(), k_blur17.as<float>(), P, mh, mw, 17, 0, nullptr, 0, 0, st);
+      op_depthwise_reflect(hb.as<float>(), hbb.as<float>(), k_blur17.as<float>(), P, mh, mw, 17, 0, nullptr, 0, 0, st);
+      op_sub(hbb.as<float>(), lbb.as<float>(), hb.as<float>(), (size_t)P * mh * mw, st);
+      op_bilinear(hb.as<float>(), hrp, P, mh, mw, H, W, /*subtract_from_out=*/1, 0, st);
+    }
+    save_tap(3, hrp, n, 3, H, W, st);
+    op_clamp01(hrp, (size_t)P * H * W, st);
+    const float* fin = hrp; int FH = H, FW = W;
+    if (cfg.out_h > 0 && cfg.lr_hr_resize) {  // always bicubic (quirk, :224-231)
+      FH = cfg.out_h; FW = cfg.out_w;
+      hr2.ensure((size_t)P * FH * FW * 4);
+      op_bicubic(hrp, hr2.as<float>(), P, H, W, FH, FW, 1, st);
+      fin = hr2.as<float>();
+    }
+    save_tap(4, fin, n, 3, FH, FW, st);
+    op_f32nchw_to_u8nhwc(fin, out, n, 3, FH, FW, st);
+  }
+
+  // fsrcnn_upscaler.py:235-326, one frame
+  void single(const uint8_t* in, int idx, int n, int h, int w, uint8_t* out, hipStream_t st) {
+    const int lh = cfg.lr_h, lw = cfg.lr_w;
+    img.ensure((size_t)3 * h * w * 4);
+    op_u8nhwc_to_f32nchw(in, img.as<float>(), 1, h, w, 3, st);
+    lr.ensure((size_t)3 * lh * lw * 4);
+    op_area(img.as<float>(), lr.as<float>(), 3, h, w, lh, lw, st);  // unconditional in this path (:239-241)
+    const float* lr_before = lr.as<float>();
+    const float* lr_cur = lr_before;
+    if (cfg.denoising) {
+      const float noise = first_frame ? 0.05f : (float)(0.1 * cfg.denoise_rate);  // :262, :269-271
+      first_frame = false;
+      const size_t plane = (size_t)lh * lw;
+      lr4.ensure(plane * 4 * 4); den.ensure(plane * 3 * 4 * 2);
+      SS4K_HIP(hipMemcpyAsync(lr4.ptr, lr_before, plane * 3 * 4, hipMemcpyDeviceToDevice, st));
+      std::vector<float> dummy;
+      // constant noise-map plane: write via a 1-tap "depthwise" would be overkill; use memset-like fill
+      fill_plane(lr4.as<float>() + plane * 3, plane, noise, st);
+      float* den0 = den.as<float>(); float* den1 = den0 + plane * 3;
+      dn->forward(lr4.as<float>(), den0, 1, lh, lw, st);
+      // clamp(sharpen(den)) * 0.8 + 0.2 * lr   (:279-281)
+      op_depthwise_reflect(den0, den1, k_sharp.as<float>(), 3, lh, lw, 3, 1, lr_before, 0.8f, (float)(1 - 0.8), st);
+      lr_cur = den1;
+    }
+    append_tap(0, lr_cur, idx, n, 3, lh, lw, st);
+    int oc, H, W; sr->out_shape(1, lh, lw, &oc, &H, &W);
+    hr.ensure((size_t)3 * H * W * 4 * 2);
+    float* hrp = hr.as<float>();
+    if (cfg.sr_is_realesrgan) sr->forward(lr_cur, hrp, 1, lh, lw, st);
+    else sr->forward(lr_cur, hrp, 3, lh, lw, st);  // FSRCNN on the three colour planes (:297)
+    if (cfg.denoising) {
+      float* hs = hrp + (size_t)3 * H * W;
+      op_depthwise_reflect(hrp, hs, k_sharp_hr.as<float>(), 3, H, W, 3, 1, nullptr, 0, 0, st);  // :298-299
+      hrp = hs;
+    }
+    append_tap(1, hrp, idx, n, 3, H, W, st);
+    st_hr.ensure(3 * 8); st_lr.ensure(3 * 8);
+    op_plane_stats(ctx, hrp, st_hr.as<float>(), 3, H * W, st);
+    op_plane_stats(ctx, lr_before, st_lr.as<float>(), 3, lh * lw, st);
+    op_normalize(hrp, st_hr.as<float>(), st_lr.as<float>(), 3, H * W, st);
+    append_tap(2, hrp, idx, n, 3, H, W, st);
+    op_clamp01(hrp, (size_t)3 * H * W, st);
+    const float* fin = hrp; int FH = H, FW = W;
+    if (cfg.out_h > 0) {
+      FH = cfg.out_h; FW = cfg.out_w;
+      hr2.ensure((size_t)3 * FH * FW * 4);
+      op_bicubic(hrp, hr2.as<float>(), 3, H, W, FH, FW, 1, st);
+      fin = hr2.as<float>();
+    }
+    append_tap(4, fin, idx, n, 3, FH, FW, st);
+    op_f32nchw_to_u8nhwc(fin, out, 1, 3, FH, FW, st);
+  }
+
+  static void fill_plane(float* p, size_t n, float v, hipStream_t st) {
+    // hipMemsetD32Async writes a 32-bit pattern
+    uint32_t bits; std::memcpy(&bits, &v, 4);
+    SS4K_HIP(hipMemsetD32Async((hipDeviceptr_t)p, (int)bits, n, st));
+  }
+};
+
+}  // namespace ss4k
+
+struct ss4k_upscaler { ss4k::Upscaler u; };
+
+using namespace ss4k;
+
+extern "C" {
+
+int ss4k_abi_version(void) { return SS4K_ABI_VERSION; }
+const char* ss4k_last_error(void) { return g_err; }
+
+int ss4k_ctx_create(int dev, ss4k_ctx** out) {
+  return guard([&] {
+    SS4K_REQUIRE(out, "ss4k_ctx_create: out is NULL");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+      throw Error(SS4K_ENODEV, "no HIP device available (libss4k_hip has no CPU fallback)");
+    SS4K_REQUIRE(dev >= 0 && dev < count, "ss4k_ctx_create: bad device index");
+    SS4K_HIP(hipSetDevice(dev));
+    hipDeviceProp_t prop; SS4K_HIP(hipGetDeviceProperties(&prop, dev));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+      throw Error(SS4K_ENODEV, std::string("libss4k_hip is built for gfx950 only; device is ") + prop.gcnArchName);
+    auto c = std::make_unique<ss4k_ctx>();
+    c->device = dev; c->num_cu = prop.multiProcessorCount;
+    *out = c.release();
+  });
+}
+void ss4k_ctx_destroy(ss4k_ctx* c) {
+  if (!c) return;
+  for (auto& kv : c->scratch) kv.second.release();
+  for (auto& e : c->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (auto& e : c->prof_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  delete c;
+}
+int ss4k_ctx_device(const ss4k_ctx* c) { return c ? c->device : -1; }
+
+size_t ss4k_model_param_count(const ss4k_model_desc* d) { return d ? model_param_count(*d) : 0; }
+
+int ss4k_model_create(ss4k_ctx* ctx, const ss4k_model_desc* d, const float* w, size_t n, ss4k_model** out) {
+  return guard([&] {
+    SS4K_REQUIRE(ctx && d && w && out, "ss4k_model_create: NULL argument");
+    SS4K_HIP(hipSetDevice(ctx->device));
+    auto m = std::make_unique<ss4k_model>();
+    m->m.ctx = ctx; m->m.desc = *d;
+    m->m.build(w, n);
+    *out = m.release();
+  });
+}
+void ss4k_model_destroy(ss4k_model* m) { delete m; }
+int ss4k_model_out_shape(const ss4k_model* m, int n, int h, int w, int* oc, int* oh, int* ow) {
+  return guard([&] { SS4K_REQUIRE(m && oc && oh && ow, "NULL argument"); m->m.out_shape(n, h, w, oc, oh, ow); });
+}
+int ss4k_model_in_channels(const ss4k_model* m) { return m ? m->m.in_channels() : SS4K_EINVAL; }
+int ss4k_model_forward(ss4k_model* m, const float* in, float* out, int n, int h, int w, void* stream) {
+  return guard([&] {
+    SS4K_REQUIRE(m && in && out, "ss4k_model_forward: NULL argument");
+    m->m.forward(in, out, n, h, w, (hipStream_t)stream);
+  });
+}
+
+int ss4k_upscaler_create(ss4k_ctx* ctx, const ss4k_upscale_cfg* cfg, ss4k_model* sr, ss4k_model* dn, ss4k_upscaler** out) {
+  return guard([&] {
+    SS4K_REQUIRE(ctx && cfg && sr && out, "ss4k_upscaler_create: NULL argument");
+    SS4K_REQUIRE(cfg->lr_h > 0 && cfg->lr_w > 0, "lr_shape must be positive");
+    SS4K_REQUIRE(!cfg->denoising || dn, "denoising requested without a BSVD model");
+    SS4K_REQUIRE(!cfg->denoising || cfg->single_mode, "the reference only denoises on the per-frame path (fsrcnn_upscaler.py:109,168-233)");
+    SS4K_REQUIRE(cfg->single_mode || cfg->sr_is_realesrgan, "the batched path requires a 3-channel SR model (fsrcnn_upscaler.py:180-184)");
+    SS4K_REQUIRE((sr->m.in_channels() == 3) == (cfg->sr_is_realesrgan != 0), "sr_is_realesrgan does not match the SR model kind");
+    auto u = std::make_unique<ss4k_upscaler>();
+    u->u.ctx = ctx; u->u.cfg = *cfg; u->u.sr = &sr->m; u->u.dn = dn ? &dn->m : nullptr;
+    auto up = [&](DevBuf& b, const std::vector<float>& v) {
+      b.ensure(v.size() * 4);
+      SS4K_HIP(hipMemcpy(b.ptr, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    };
+    up(u->u.k_blur17, gaussian_taps(17, 8.0f));
+    up(u->u.k_sharp, sharpen_taps(0.00002));
+    up(u->u.k_sharp_hr, sharpen_taps(0.00007));
+    *out = u.release();
+  });
+}
+void ss4k_upscaler_destroy(ss4k_upscaler* up) {
+  if (!up) return;
+  Upscaler& u = up->u;
+  for (DevBuf* b : {&u.k_blur17, &u.k_sharp, &u.k_sharp_hr, &u.img, &u.lr, &u.lr4, &u.den, &u.hr, &u.hr2, &u.lb, &u.hb,
+                    &u.lbb, &u.hbb, &u.st_hr, &u.st_lr})
+    b->release();
+  for (auto& t : u.tap) t.release();
+  delete up;
+}
+int ss4k_upscaler_reset(ss4k_upscaler* up) { if (!up) return SS4K_EINVAL; up->u.first_frame = true; return SS4K_OK; }
+int ss4k_upscaler_out_shape(const ss4k_upscaler* up, int n, int h, int w, int* oh, int* ow) {
+  (void)n;
+  return guard([&] { SS4K_REQUIRE(up && oh && ow, "NULL argument"); up->u.out_shape(h, w, oh, ow); });
+}
+int ss4k_upscale_frames(ss4k_upscaler* up, const uint8_t* in, int n, int h, int w, uint8_t* out, size_t cap, void* stream) {
+  return guard([&] {
+    SS4K_REQUIRE(up && in && out, "ss4k_upscale_frames: NULL argument");
+    SS4K_REQUIRE(n > 0 && h > 0 && w > 0, "ss4k_upscale_frames: empty batch");
+    int oh, ow; up->u.out_shape(h, w, &oh, &ow);
+    const size_t per = (size_t)oh * ow * 3;
+    SS4K_REQUIRE(cap >= per * n, "ss4k_upscale_frames: output buffer too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (up->u.cfg.single_mode) {
+      for (int i = 0; i < n; ++i) up->u.single(in + (size_t)i * h * w * 3, i, n, h, w, out + per * i, st);
+    } else {
+      up->u.multi(in, n, h, w, out, st);
+    }
+  });
+}
+int ss4k_upscaler_enable_taps(ss4k_upscaler* up, int en) { if (!up) return SS4K_EINVAL; up->u.taps_on = en != 0; return SS4K_OK; }
+int ss4k_upscaler_read_tap(ss4k_upscaler* up, int which, float* out, size_t cap, int dims[4], void* stream) {
+  return guard([&] {
+    SS4K_REQUIRE(up && which >= 0 && which < 5 && dims, "bad tap request");
+    const int* d = up->u.tap_dims[which];
+    for (int i = 0; i < 4; ++i) dims[i] = d[i];
+    const size_t nflt = (size_t)d[0] * d[1] * d[2] * d[3];
+    SS4K_REQUIRE(nflt > 0, "tap not recorded (enable taps before ss4k_upscale_frames)");
+    if (out) {
+      SS4K_REQUIRE(cap >= nflt, "tap buffer too small");
+      SS4K_HIP(hipMemcpyAsync(out, up->u.tap[which].ptr, nflt * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+  });
+}
+
+// ---- granular ops ---------------------------------------------------------------------------
+int ss4k_op_u8nhwc_to_f32nchw(ss4k_ctx* c, const uint8_t* in, float* out, int n, int h, int w, int ch, void* s) {
+  return guard([&] { SS4K_REQUIRE(c && in && out, "NULL argument"); op_u8nhwc_to_f32nchw(in, out, n, h, w, ch, (hipStream_t)s); SS4K_HIP(hipGetLastError()); });
+}
+int ss4k_op_area_resize(ss4k_ctx* c, const float* in, float* out, int p, int h, int w, int oh, int ow, void* s) {
+  return guard([&] { SS4K_REQUIRE(c && in && out, "NULL argument"); op_area(in, out, p, h, w, oh, ow, (hipStream_t)s); SS4K_HIP(hipGetLastError()); });
+}
+int ss4k_op_bicubic_resize(ss4k_ctx* c, const float* in, float* out, int p, int h, int w, int oh, int ow, void* s) {
+  return guard([&] { SS4K_REQUIRE(c && in && out, "NULL argument"); op_bicubic(in, out, p, h, w, oh, ow, 0, (hipStream_t)s); SS4K_HIP(hipGetLastError()); });
+}
+int ss4k_op_bilinear_resize(ss4k_ctx* c, const float* in, float* out, int p, int h, int w, int oh, int ow, void* s) {
+  return guard([&] { SS4K_REQUIRE(c && in && out, "NULL argument"); op_bilinear(in, out, p, h, w, oh, ow, 0, 0, (hipStream_t)s); SS4K_HIP(hipGetLastError()); });
+}
+int ss4k_op_depthwise_reflect(ss4k_ctx* c, const float* in, float* out, int p, int h, int w, const float* k2d, int k, void* s) {
+  return guard([&] {
+    SS4K_REQUIRE(c && in && out && k2d, "NULL argument");
+    SS4K_REQUIRE(k >= 1 && k <= 17 && (k & 1), "kernel size must be odd and <= 17");
+    SS4K_REQUIRE(h > k / 2 && w > k / 2, "reflect padding needs pad < size");
+    float* taps = c->buf("dw_taps", 17 * 17 * 4).as<float>();
+    SS4K_HIP(hipMemcpyAsync(taps, k2d, (size_t)k * k * 4, hipMemcpyHostToDevice, (hipStream_t)s));
+    op_depthwise_reflect(in, out, taps, p, h, w, k, 0, nullptr, 0, 0, (hipStream_t)s);
+    SS4K_HIP(hipGetLastError());
+  });
+}
+int ss4k_op_plane_stats(ss4k_ctx* c, const float* in, float* stats, int p, int hw, void* s) {
+  return guard([&] { SS4K_REQUIRE(c && in && stats, "NULL argument"); op_plane_stats(c, in, stats, p, hw, (hipStream_t)s); SS4K_HIP(hipGetLastError()); });
+}
+int ss4k_op_f32nchw_to_u8nhwc(ss4k_ctx* c, const float* in, uint8_t* out, int n, int ch, int h, int w, void* s) {
+  return guard([&] { SS4K_REQUIRE(c && in && out, "NULL argument"); op_f32nchw_to_u8nhwc(in, out, n, ch, h, w, (hipStream_t)s); SS4K_HIP(hipGetLastError()); });
+}
+
+// ---- profiling hooks --------------------------------------------------------------------------
+static void prof_collect(ss4k_ctx* c) {
+  for (auto& e : c->prof_events) {
+    SS4K_HIP(hipEventSynchronize(e.b));
+    float ms = 0; SS4K_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+    c->prof_ms += ms; c->prof_flops += e.flops; c->prof_launches += 1;
+    c->prof_pool.push_back(e);
+  }
+  c->prof_events.clear();
+}
+int ss4k_prof_enable(ss4k_ctx* c, int en) { if (!c) return SS4K_EINVAL; c->prof = en != 0; return SS4K_OK; }
+int ss4k_prof_reset(ss4k_ctx* c) {
+  return guard([&] { SS4K_REQUIRE(c, "NULL ctx"); prof_collect(c); c->prof_ms = 0; c->prof_flops = 0; c->prof_launches = 0; });
+}
+int ss4k_prof_read(ss4k_ctx* c, int64_t* launches, double* ms, double* flops) {
+  return guard([&] {
+    SS4K_REQUIRE(c, "NULL ctx");
+    prof_collect(c);
+    if (launches) *launches = c->prof_launches;
+    if (ms) *ms = c->prof_ms;
+    if (flops) *flops = c->prof_flops;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,126 @@
+// Internal declarations shared by the translation units of libss4k_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "../../include/ss4k.h"
+
+namespace ss4k {
+
+void set_error(const char* fmt, ...);
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define SS4K_HIP(expr)                                                                      \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess)                                                                   \
+      throw ::ss4k::Error(SS4K_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+  } while (0)
+
+#define SS4K_REQUIRE(cond, msg)                                        \
+  do {                                                                 \
+    if (!(cond)) throw ::ss4k::Error(SS4K_EINVAL, std::string(msg));   \
+  } while (0)
+
+// A device allocation owned by the context; grows on demand, never shrinks (no hipMalloc in
+// steady state: shapes repeat frame after frame).
+struct DevBuf {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  void ensure(size_t need) {
+    if (need <= bytes) return;
+    if (ptr) { (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
+    size_t want = (need + 255) & ~size_t(255);
+    SS4K_HIP(hipMalloc(&ptr, want));
+    bytes = want;
+  }
+  void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(ptr); }
+};
+
+struct ProfEvent { hipEvent_t a, b; double flops; };
+
+}  // namespace ss4k
+
+struct ss4k_ctx {
+  int device = 0;
+  int num_cu = 256;
+  // named scratch for the granular ops
+  std::map<std::string, ss4k::DevBuf> scratch;
+  // conv-kernel profiling (bench.py roofline leg)
+  bool prof = false;
+  std::vector<ss4k::ProfEvent> prof_events;
+  std::vector<ss4k::ProfEvent> prof_pool;
+  int64_t prof_launches = 0;
+  double prof_ms = 0, prof_flops = 0;
+  ss4k::DevBuf& buf(const std::string& name, size_t bytes) {
+    auto& b = scratch[name];
+    b.ensure(bytes);
+    return b;
+  }
+};
+
+namespace ss4k {
+
+enum Act { ACT_NONE = 0, ACT_LRELU = 1, ACT_PRELU = 2, ACT_RELU6 = 3 };
+enum Epi {
+  EPI_NHWC = 0,        // out[(n,y,x)*ocs + oco + v]
+  EPI_NHWC_SUB2 = 1,   // stride-2 conv: keep even (y,x) -> out[(n,y/2,x/2)]
+  EPI_NHWC_PS2 = 2,    // PixelShuffle(2): virtual cout = sub*C' + c' -> out[(n,2y+dy,2x+dx)*ocs + oco + c']
+  EPI_NCHW_F32 = 3     // final fp32 planes out[((n*C+c)*H+y)*W+x], c < cout_real
+};
+
+// One 3x3 / pad 1 / stride 1 convolution over NHWC activations as an implicit GEMM.
+struct ConvArgs {
+  const void* in0; int cs0, co0, nch0;  // segment 0: channel stride, channel offset, #channels (padded)
+  const void* in1; int cs1, co1, nch1;  // optional segment 1 (dense concat is free)
+  int N, H, W;                          // conv grid (== output grid before SUB2/PS2)
+  int ups2;                             // input is the nearest-x2 upsampling of an (H/2, W/2) tensor
+  const void* wpk;                      // packed weights [group][chunk][tap][ks][nb][lane][E]
+  const float* bias;                    // [cout_pad] virtual order
+  const float* prelu;                   // [cout_pad] or null
+  int act; float slope;
+  float alpha, gamma;                   // v = (act(acc+bias)*alpha + res1)*gamma + res2
+  const void* res1; int r1cs, r1co;
+  const void* res2; int r2cs, r2co;
+  int bsvd_resid;                       // channels < 3: v = res1 - v (bsvd/model.py:436-442)
+  int epi;
+  void* out; int ocs, oco;
+  int cout_real, cout_pad, cout_alloc;  // real couts, padded to NB*32 multiples, channels the NHWC dst holds
+  int nchunks0, nchunks1;
+  int tiles_x, tiles_y;
+  double flops;                         // algorithmic FLOPs of this layer (profiling only)
+};
+
+// launchers (conv_mfma.hip)
+void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a, int dtype, hipStream_t st);
+int conv_kc(int dtype);  // channels per K-chunk: 32 (f16) / 16 (f32)
+
+// weight packing (pack.cpp) --------------------------------------------------------------
+struct PackSpec {
+  int dtype;
+  int cout_real, cin_total;        // OIHW dims of the source tensor
+  int nch0_real, nch0;             // logical cin [0,nch0_real) live in segment 0 padded to nch0
+  int nch1_real, nch1;             // remaining logical cin in segment 1
+  int cin_first;                   // first logical cin used (BSVD masked convs skip [0, C/4))
+  int ps2;                         // virtual cout order [sub][c'] for PixelShuffle(2)
+};
+struct PackedConv {
+  std::vector<uint8_t> w;          // device-order bytes
+  std::vector<float> bias, prelu;  // [cout_pad]
+  int cout_pad, nb, groups, nchunks0, nchunks1;
+};
+PackedConv pack_conv3x3(const PackSpec& s, const float* w_oihw, const float* bias, const float* prelu);
+int virt_to_real_cout(const PackSpec& s, int v, int cout_pad);
+
+}  // namespace ss4k

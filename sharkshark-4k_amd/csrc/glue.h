@@ -1,0 +1,46 @@
+// Launchers of the glue kernels (glue.hip) and FSRCNN kernels (fsrcnn.hip).
+#pragma once
+#include "common.h"
+
+namespace ss4k {
+
+void op_u8nhwc_to_f32nchw(const uint8_t* in, float* out, int n, int h, int w, int c, hipStream_t st);
+void op_area(const float* in, float* out, int planes, int h, int w, int oh, int ow, hipStream_t st);
+void op_plane_stats(ss4k_ctx* ctx, const float* in, float* stats, int planes, int hw, hipStream_t st);
+void op_normalize(float* x, const float* st_hr, const float* st_lr, int planes, int hw, hipStream_t st);
+void op_depthwise_reflect(const float* in, float* out, const float* taps_dev, int planes, int h, int w, int k,
+                          int clamp01, const float* blend_src, float blend_a, float blend_b, hipStream_t st);
+void op_bilinear(const float* in, float* out, int planes, int h, int w, int oh, int ow, int subtract_from_out,
+                 int clamp01, hipStream_t st);
+void op_bicubic(const float* in, float* out, int planes, int h, int w, int oh, int ow, int clamp01, hipStream_t st);
+void op_sub(const float* a, const float* b, float* out, size_t n, hipStream_t st);
+void op_clamp01(float* x, size_t n, hipStream_t st);
+void op_f32nchw_to_u8nhwc(const float* in, uint8_t* out, int n, int c, int h, int w, hipStream_t st);
+template <typename T>
+void op_pack_input(const float* in, T* out, int n, int c, int h, int w, int r, int cpad, int fill_ch, float fill_val,
+                   hipStream_t st);
+
+template <typename T>
+void op_ps_nchw_addbase(const T* src, int cs, float* out, const float* base, int n, int h, int w, int r, int cq,
+                        hipStream_t st);
+
+// FSRCNN (fsrcnn.hip): whole-network forward on fp32 planes, weights in the device layout
+// produced by fsrcnn_pack_weights.
+struct FsrcnnWeights {
+  // all fp32 on device
+  const float* w_feat;   // [25][56]   tap-major, cout-minor
+  const float* b_feat;   // [56]
+  const float* a_feat;   // [56] PReLU
+  const float* w_shrink; // [56][12]
+  const float* b_shrink; const float* a_shrink;  // [12]
+  const float* w_map[4]; // [9][12][12]  tap, cin, cout
+  const float* b_map[4]; const float* a_map[4];
+  const float* w_expand; // [12][56]
+  const float* b_expand; const float* a_expand;  // [56]
+  const float* w_deconv; // [81][56]  (ky*9+kx), cin
+  float b_deconv;
+};
+void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const float* in, float* out, int planes, int h,
+                    int w, float* ws12a, float* ws12b, float* ws56, hipStream_t st);
+
+}  // namespace ss4k

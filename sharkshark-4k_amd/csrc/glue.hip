@@ -1,0 +1,288 @@
+// HBM-bound glue around the networks: every kernel here replaces one torch call of
+// FsrcnnUpscalerService.upscale_multi / upscale_single (reference src/upscale/fsrcnn_upscaler.py).
+// Image tensors on this side of the networks are fp32 planes (NCHW), exactly the reference's
+// layout, so that each op can be parity-tested against its torch counterpart.
+#include "common.h"
+#include "glue.h"
+
+namespace ss4k {
+
+static inline dim3 grid1d(size_t n, int block = 256) {
+  size_t g = (n + block - 1) / block;
+  if (g > 256 * 8 * 4) g = 256 * 8 * 4;  // grid-stride beyond a few waves per CU
+  return dim3((unsigned)std::max<size_t>(g, 1));
+}
+
+// ------------------------------------------------------------------ u8 NHWC -> f32 NCHW (/255)
+__global__ void k_u8nhwc_to_f32nchw(const uint8_t* __restrict__ in, float* __restrict__ out, int n, int h,
+                                    int w, int c) {
+  const size_t hw = (size_t)h * w, total = (size_t)n * hw;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t img = i / hw, p = i - img * hw;
+    for (int k = 0; k < c; ++k) out[(img * c + k) * hw + p] = (float)in[i * c + k] / 255.0f;
+  }
+}
+void op_u8nhwc_to_f32nchw(const uint8_t* in, float* out, int n, int h, int w, int c, hipStream_t st) {
+  const size_t total = (size_t)n * h * w;
+  hipLaunchKernelGGL(k_u8nhwc_to_f32nchw, grid1d(total), dim3(256), 0, st, in, out, n, h, w, c);
+}
+
+// ------------------------------------------------------------------ area (adaptive average pool)
+struct Affine { const float* stats_hr; const float* stats_lr; int planes_per_img; };
+
+__device__ __forceinline__ int a_start(int i, int in, int out) { return (int)floorf((float)(i * in) / out); }
+__device__ __forceinline__ int a_end(int i, int in, int out) { return (int)ceilf((float)((i + 1) * in) / out); }
+
+__global__ void k_area(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int oh,
+                       int ow) {
+  const size_t total = (size_t)planes * oh * ow;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = i % ow, oy = (i / ow) % oh;
+    const size_t pl = i / ((size_t)ow * oh);
+    const int y0 = a_start(oy, h, oh), y1 = a_end(oy, h, oh), x0 = a_start(ox, w, ow), x1 = a_end(ox, w, ow);
+    const float* src = in + pl * (size_t)h * w;
+    float sum = 0.f;
+    for (int y = y0; y < y1; ++y)
+      for (int x = x0; x < x1; ++x) sum += src[(size_t)y * w + x];
+    out[i] = sum / (float)(y1 - y0) / (float)(x1 - x0);
+  }
+}
+void op_area(const float* in, float* out, int planes, int h, int w, int oh, int ow, hipStream_t st) {
+  if (h == oh && w == ow) {
+    (void)hipMemcpyAsync(out, in, (size_t)planes * h * w * sizeof(float), hipMemcpyDeviceToDevice, st);
+    return;
+  }
+  hipLaunchKernelGGL(k_area, grid1d((size_t)planes * oh * ow), dim3(256), 0, st, in, out, planes, h, w, oh, ow);
+}
+
+// ------------------------------------------------------------------ per-plane mean / unbiased std
+__global__ void k_stats_partial(const float* __restrict__ in, double* __restrict__ acc, int hw) {
+  const int pl = blockIdx.y;
+  const float* src = in + (size_t)pl * hw;
+  double s = 0.0, q = 0.0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)hw; i += (size_t)gridDim.x * blockDim.x) {
+    const double v = src[i];
+    s += v; q += v * v;
+  }
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); q += __shfl_down(q, off, 64); }
+  __shared__ double ss[4], sq[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { ss[wv] = s; sq[wv] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double S = 0, Q = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { S += ss[i]; Q += sq[i]; }
+    atomicAdd(&acc[2 * pl], S);
+    atomicAdd(&acc[2 * pl + 1], Q);
+  }
+}
+__global__ void k_stats_final(const double* __restrict__ acc, float* __restrict__ stats, int planes, int hw) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= planes) return;
+  const double n = (double)hw, S = acc[2 * p], Q = acc[2 * p + 1];
+  const double mean = S / n;
+  double var = (Q - S * S / n) / (n - 1.0);  // Bessel-corrected, torch.std default (fsrcnn_upscaler.py:193)
+  if (var < 0) var = 0;
+  stats[2 * p] = (float)mean;
+  stats[2 * p + 1] = (float)sqrt(var);
+}
+void op_plane_stats(ss4k_ctx* ctx, const float* in, float* stats, int planes, int hw, hipStream_t st) {
+  double* acc = ctx->buf("stats_acc", sizeof(double) * 2 * 4096).as<double>();
+  SS4K_REQUIRE(planes <= 4096, "plane_stats: too many planes");
+  SS4K_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 2 * planes, st));
+  int gx = (hw + 256 * 16 - 1) / (256 * 16);
+  gx = std::max(1, std::min(gx, 512));
+  hipLaunchKernelGGL(k_stats_partial, dim3(gx, planes), dim3(256), 0, st, in, acc, hw);
+  hipLaunchKernelGGL(k_stats_final, dim3((planes + 63) / 64), dim3(64), 0, st, acc, stats, planes, hw);
+}
+
+// hr = (hr - mean_hr) / (std_hr + 1e-8) * std_lr + mean_lr   (fsrcnn_upscaler.py:198-199, :312-313)
+__global__ void k_normalize(float* __restrict__ x, const float* __restrict__ st_hr, const float* __restrict__ st_lr,
+                            int planes, int hw) {
+  const int pl = blockIdx.y;
+  const float mh = st_hr[2 * pl], sh = st_hr[2 * pl + 1] + 1e-8f, ml = st_lr[2 * pl], sl = st_lr[2 * pl + 1];
+  float* p = x + (size_t)pl * hw;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)hw; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = (p[i] - mh) / sh * sl + ml;
+}
+void op_normalize(float* x, const float* st_hr, const float* st_lr, int planes, int hw, hipStream_t st) {
+  int gx = std::max(1, std::min((hw + 255) / 256, 1024));
+  hipLaunchKernelGGL(k_normalize, dim3(gx, planes), dim3(256), 0, st, x, st_hr, st_lr, planes, hw);
+}
+
+// ------------------------------------------------------------------ depthwise KxK, reflect padding
+__device__ __forceinline__ int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
+__global__ void k_depthwise_reflect(const float* __restrict__ in, float* __restrict__ out,
+                                    const float* __restrict__ taps, int planes, int h, int w, int k, int clamp01,
+                                    const float* __restrict__ blend_src, float blend_a, float blend_b) {
+  const size_t total = (size_t)planes * h * w;
+  const int r = k >> 1;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = i % w, y = (i / w) % h;
+    const float* src = in + (i / ((size_t)w * h)) * (size_t)h * w;
+    float acc = 0.f;
+    for (int ky = 0; ky < k; ++ky) {
+      const int yy = reflect(y + ky - r, h);
+      for (int kx = 0; kx < k; ++kx) acc += taps[ky * k + kx] * src[(size_t)yy * w + reflect(x + kx - r, w)];
+    }
+    if (clamp01) acc = fminf(fmaxf(acc, 0.f), 1.f);
+    if (blend_src) acc = acc * blend_a + blend_b * blend_src[i];
+    out[i] = acc;
+  }
+}
+void op_depthwise_reflect(const float* in, float* out, const float* taps_dev, int planes, int h, int w, int k,
+                          int clamp01, const float* blend_src, float blend_a, float blend_b, hipStream_t st) {
+  hipLaunchKernelGGL(k_depthwise_reflect, grid1d((size_t)planes * h * w), dim3(256), 0, st, in, out, taps_dev,
+                     planes, h, w, k, clamp01, blend_src, blend_a, blend_b);
+}
+
+// ------------------------------------------------------------------ bilinear / bicubic (align_corners=False)
+__global__ void k_bilinear(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int oh,
+                           int ow, int subtract_from_out, int clamp01) {
+  const size_t total = (size_t)planes * oh * ow;
+  const float sy = (float)h / oh, sx = (float)w / ow;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = i % ow, oy = (i / ow) % oh;
+    const float* src = in + (i / ((size_t)ow * oh)) * (size_t)h * w;
+    float fy = sy * (oy + 0.5f) - 0.5f; if (fy < 0) fy = 0;
+    float fx = sx * (ox + 0.5f) - 0.5f; if (fx < 0) fx = 0;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float v = hy * (hx * src[(size_t)y0 * w + x0] + lx * src[(size_t)y0 * w + x1]) +
+                    ly * (hx * src[(size_t)y1 * w + x0] + lx * src[(size_t)y1 * w + x1]);
+    float r = subtract_from_out ? out[i] - v : v;
+    if (clamp01) r = fminf(fmaxf(r, 0.f), 1.f);
+    out[i] = r;
+  }
+}
+void op_bilinear(const float* in, float* out, int planes, int h, int w, int oh, int ow, int subtract_from_out,
+                 int clamp01, hipStream_t st) {
+  hipLaunchKernelGGL(k_bilinear, grid1d((size_t)planes * oh * ow), dim3(256), 0, st, in, out, planes, h, w, oh, ow,
+                     subtract_from_out, clamp01);
+}
+
+__device__ __forceinline__ float cc1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cc2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+__device__ __forceinline__ void cubic_coeffs(float t, float* c) {
+  const float A = -0.75f;
+  c[0] = cc2(t + 1.f, A); c[1] = cc1(t, A); c[2] = cc1(1.f - t, A); c[3] = cc2(2.f - t, A);
+}
+__global__ void k_bicubic(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int oh,
+                          int ow, int clamp01) {
+  const size_t total = (size_t)planes * oh * ow;
+  const float sy = (float)h / oh, sx = (float)w / ow;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = i % ow, oy = (i / ow) % oh;
+    const float* src = in + (i / ((size_t)ow * oh)) * (size_t)h * w;
+    const float fy = sy * (oy + 0.5f) - 0.5f, fx = sx * (ox + 0.5f) - 0.5f;
+    const float fly = floorf(fy), flx = floorf(fx);
+    const int iy = (int)fly, ix = (int)flx;
+    float cy[4], cx[4];
+    cubic_coeffs(fy - fly, cy); cubic_coeffs(fx - flx, cx);
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int yy = min(max(iy - 1 + a, 0), h - 1);
+      float row = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) row += cx[b] * src[(size_t)yy * w + min(max(ix - 1 + b, 0), w - 1)];
+      acc += cy[a] * row;
+    }
+    if (clamp01) acc = fminf(fmaxf(acc, 0.f), 1.f);
+    out[i] = acc;
+  }
+}
+void op_bicubic(const float* in, float* out, int planes, int h, int w, int oh, int ow, int clamp01, hipStream_t st) {
+  hipLaunchKernelGGL(k_bicubic, grid1d((size_t)planes * oh * ow), dim3(256), 0, st, in, out, planes, h, w, oh, ow,
+                     clamp01);
+}
+
+// ------------------------------------------------------------------ elementwise helpers
+__global__ void k_sub(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = a[i] - b[i];
+}
+void op_sub(const float* a, const float* b, float* out, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_sub, grid1d(n), dim3(256), 0, st, a, b, out, n);
+}
+__global__ void k_clamp01(float* __restrict__ x, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    x[i] = fminf(fmaxf(x[i], 0.f), 1.f);
+}
+void op_clamp01(float* x, size_t n, hipStream_t st) { hipLaunchKernelGGL(k_clamp01, grid1d(n), dim3(256), 0, st, x, n); }
+
+// (clamp(x,0,1)*255) -> uint8 by truncation, NCHW -> NHWC   (fsrcnn_upscaler.py:232-233, :325-326)
+__global__ void k_f32nchw_to_u8nhwc(const float* __restrict__ in, uint8_t* __restrict__ out, int n, int c, int h,
+                                    int w) {
+  const size_t hw = (size_t)h * w, total = (size_t)n * hw;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t img = i / hw, p = i - img * hw;
+    for (int k = 0; k < c; ++k) {
+      float v = in[(img * c + k) * hw + p];
+      v = fminf(fmaxf(v, 0.f), 1.f) * 255.f;
+      out[i * c + k] = (uint8_t)v;
+    }
+  }
+}
+void op_f32nchw_to_u8nhwc(const float* in, uint8_t* out, int n, int c, int h, int w, hipStream_t st) {
+  hipLaunchKernelGGL(k_f32nchw_to_u8nhwc, grid1d((size_t)n * h * w), dim3(256), 0, st, in, out, n, c, h, w);
+}
+
+// ------------------------------------------------------------------ network input packing
+// NCHW fp32 -> NHWC T with zero channel padding and optional pixel-unshuffle(r) (RRDBNet x2/x1
+// front end, basicsr pixel_unshuffle: channel = c*r*r + dy*r + dx).  fill_ch/fill_val write a
+// constant plane (BSVD noise map, fsrcnn_upscaler.py:262,269-271) into one channel.
+template <typename T>
+__global__ void k_pack_input(const float* __restrict__ in, T* __restrict__ out, int n, int c, int h, int w, int r,
+                             int cpad, int fill_ch, float fill_val) {
+  const int oh = h / r, ow = w / r;
+  const size_t total = (size_t)n * oh * ow;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = i % ow, oy = (i / ow) % oh;
+    const size_t img = i / ((size_t)ow * oh);
+    T* dst = out + i * cpad;
+    int k = 0;
+    for (int ci = 0; ci < c; ++ci)
+      for (int dy = 0; dy < r; ++dy)
+        for (int dx = 0; dx < r; ++dx, ++k)
+          dst[k] = (T)in[((img * c + ci) * h + (size_t)oy * r + dy) * w + (size_t)ox * r + dx];
+    for (; k < cpad; ++k) dst[k] = (T)(k == fill_ch ? fill_val : 0.f);
+  }
+}
+template <typename T>
+void op_pack_input(const float* in, T* out, int n, int c, int h, int w, int r, int cpad, int fill_ch, float fill_val,
+                   hipStream_t st) {
+  hipLaunchKernelGGL((k_pack_input<T>), grid1d((size_t)n * (h / r) * (w / r)), dim3(256), 0, st, in, out, n, c, h, w,
+                     r, cpad, fill_ch, fill_val);
+}
+// SRVGGNetCompact tail (realesrgan/factory.py:77-81): PixelShuffle(r) of an NHWC T tensor into fp32
+// planes plus the nearest-upsampled network input.
+template <typename T>
+__global__ void k_ps_nchw_addbase(const T* __restrict__ src, int cs, float* __restrict__ out,
+                                  const float* __restrict__ base, int n, int h, int w, int r, int cq) {
+  const int OH = h * r, OW = w * r;
+  const size_t total = (size_t)n * cq * OH * OW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = i % OW, oy = (i / OW) % OH;
+    const int c = (i / ((size_t)OW * OH)) % cq;
+    const size_t img = i / ((size_t)OW * OH * cq);
+    const int y = oy / r, x = ox / r, dy = oy - y * r, dx = ox - x * r;
+    const float v = (float)src[((img * h + y) * w + x) * cs + c * r * r + dy * r + dx];
+    out[i] = v + base[((img * cq + c) * h + y) * w + x];
+  }
+}
+template <typename T>
+void op_ps_nchw_addbase(const T* src, int cs, float* out, const float* base, int n, int h, int w, int r, int cq,
+                        hipStream_t st) {
+  hipLaunchKernelGGL((k_ps_nchw_addbase<T>), grid1d((size_t)n * cq * h * r * w * r), dim3(256), 0, st, src, cs, out,
+                     base, n, h, w, r, cq);
+}
+template void op_ps_nchw_addbase<float>(const float*, int, float*, const float*, int, int, int, int, int, hipStream_t);
+template void op_ps_nchw_addbase<__half>(const __half*, int, float*, const float*, int, int, int, int, int, hipStream_t);
+
+template void op_pack_input<float>(const float*, float*, int, int, int, int, int, int, int, float, hipStream_t);
+template void op_pack_input<__half>(const float*, __half*, int, int, int, int, int, int, int, float, hipStream_t);
+
+}  // namespace ss4k

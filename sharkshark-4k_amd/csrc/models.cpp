@@ -1,0 +1,358 @@
+// Network executors: FSRCNN, RRDBNet, SRVGGNetCompact and BSVD(F=1) as sequences of launches of
+// the kernels in conv_mfma.hip / fsrcnn.hip.  Weights arrive as the reference's state_dict
+// flattened in key order (see sharkshark-4k_amd/weights.py) and are repacked once at creation.
+#include "models.h"
+#include <algorithm>
+#include <cmath>
+
+namespace ss4k {
+
+static size_t esz(int dtype) { return dtype == SS4K_F16 ? 2 : 4; }
+static int pad16(int c) { return (c + 15) / 16 * 16; }
+
+// ------------------------------------------------------------------------------------------
+// parameter bookkeeping (must mirror weights.py: *_keys order)
+// ------------------------------------------------------------------------------------------
+struct ParamCursor {
+  const float* base; size_t n, pos = 0;
+  const float* take(size_t k) {
+    SS4K_REQUIRE(pos + k <= n, "weight blob shorter than the model's state_dict");
+    const float* p = base + pos; pos += k; return p;
+  }
+};
+
+static std::vector<std::pair<int, int>> bsvd_denblock_shapes(const int* chns, int in_ch, int out_ch, int interm) {
+  const int c0 = chns[0], c1 = chns[1], c2 = chns[2];
+  // (cout, cin) in weights.py::_bsvd_denblock_convs order
+  return {{interm, in_ch}, {c0, interm}, {c1, c0}, {c1, c1}, {c1, c1}, {c2, c1}, {c2, c2}, {c2, c2},
+          {c2, c2}, {c2, c2}, {c1 * 4, c2}, {c1, c1}, {c1, c1}, {c0 * 4, c1}, {c0, c0}, {out_ch, c0}};
+}
+
+size_t model_param_count(const ss4k_model_desc& d) {
+  switch (d.kind) {
+    case SS4K_FSRCNN:
+      return 56 * 25 + 56 + 56 + 12 * 56 + 12 + 12 + 4 * (12 * 12 * 9 + 12 + 12) + 56 * 12 + 56 + 56 + 56 * 81 + 1;
+    case SS4K_RRDBNET: {
+      const int nf = d.num_feat, g = d.num_grow_ch;
+      const int cin0 = 3 * (d.scale == 2 ? 4 : d.scale == 1 ? 16 : 1);
+      size_t n = (size_t)nf * cin0 * 9 + nf;
+      size_t rdb = 0;
+      for (int c = 0; c < 5; ++c) {
+        const int ci = nf + c * g, co = c < 4 ? g : nf;
+        rdb += (size_t)co * ci * 9 + co;
+      }
+      n += (size_t)d.num_block * 3 * rdb;
+      n += 4 * ((size_t)nf * nf * 9 + nf);  // conv_body, conv_up1, conv_up2, conv_hr
+      n += (size_t)3 * nf * 9 + 3;
+      return n;
+    }
+    case SS4K_SRVGG: {
+      const int nf = d.num_feat, r2 = d.scale * d.scale;
+      size_t n = (size_t)nf * 3 * 9 + nf + nf;
+      n += (size_t)d.num_block * ((size_t)nf * nf * 9 + nf + nf);
+      n += (size_t)3 * r2 * nf * 9 + 3 * r2;
+      return n;
+    }
+    case SS4K_BSVD: {
+      size_t n = 0;
+      for (int blk = 0; blk < 2; ++blk) {
+        const int ci = blk == 0 ? 4 : d.bsvd_mid_ch, co = blk == 0 ? d.bsvd_mid_ch : 3;
+        for (auto& s : bsvd_denblock_shapes(d.bsvd_chns, ci, co, d.bsvd_interm_ch))
+          n += (size_t)s.first * s.second * 9 + s.first;
+      }
+      return n;
+    }
+  }
+  return 0;
+}
+
+static void validate_desc(const ss4k_model_desc& d) {
+  SS4K_REQUIRE(d.dtype == SS4K_F32 || d.dtype == SS4K_F16, "desc.dtype must be SS4K_F32 or SS4K_F16");
+  switch (d.kind) {
+    case SS4K_FSRCNN:
+      SS4K_REQUIRE(d.scale == 2 || d.scale == 4, "FSRCNN scale must be 2 or 4");
+      SS4K_REQUIRE(d.dtype == SS4K_F32, "FSRCNN runs in fp32 (vector-ALU path)");
+      break;
+    case SS4K_RRDBNET:
+      SS4K_REQUIRE(d.scale == 1 || d.scale == 2 || d.scale == 4, "RRDBNet scale must be 1, 2 or 4");
+      SS4K_REQUIRE(d.num_feat > 0 && d.num_feat % 32 == 0 && d.num_grow_ch > 0 && d.num_grow_ch % 32 == 0 && d.num_block > 0,
+                   "RRDBNet: num_feat and num_grow_ch must be multiples of 32");
+      break;
+    case SS4K_SRVGG:
+      SS4K_REQUIRE(d.scale >= 1 && d.scale <= 4, "SRVGG upscale must be 1..4");
+      SS4K_REQUIRE(d.num_feat > 0 && d.num_feat % 16 == 0 && d.num_block >= 0, "SRVGG: num_feat must be a multiple of 16");
+      break;
+    case SS4K_BSVD:
+      SS4K_REQUIRE(d.bsvd_chns[0] % 32 == 0 && d.bsvd_chns[1] % 64 == 0 && d.bsvd_chns[2] % 64 == 0 && d.bsvd_mid_ch % 32 == 0 &&
+                       d.bsvd_interm_ch > 0 && d.bsvd_interm_ch <= 32,
+                   "BSVD: unsupported channel configuration");
+      break;
+    default:
+      throw Error(SS4K_EINVAL, "unknown model kind");
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+static void upload(DevBuf& b, const void* src, size_t bytes) {
+  b.ensure(std::max<size_t>(bytes, 16));
+  SS4K_HIP(hipMemcpy(b.ptr, src, bytes, hipMemcpyHostToDevice));
+}
+
+int Model::add_conv(ParamCursor& pc, int cout, int cin_total, const PackSpec& spec_in, bool has_prelu_after) {
+  PackSpec s = spec_in;
+  s.dtype = desc.dtype; s.cout_real = cout; s.cin_total = cin_total;
+  const float* w = pc.take((size_t)cout * cin_total * 9);
+  const float* b = pc.take(cout);
+  const float* a = has_prelu_after ? pc.take(cout) : nullptr;
+  PackedConv p = pack_conv3x3(s, w, b, a);
+  ConvLayer L;
+  upload(L.w, p.w.data(), p.w.size());
+  upload(L.bias, p.bias.data(), p.bias.size() * 4);
+  if (a) upload(L.prelu, p.prelu.data(), p.prelu.size() * 4);
+  L.has_prelu = a != nullptr;
+  L.cout_real = cout; L.cout_pad = p.cout_pad; L.nchunks0 = p.nchunks0; L.nchunks1 = p.nchunks1;
+  L.cin_real = s.nch0_real + s.nch1_real;
+  L.nch0 = s.nch0; L.nch1 = s.nch1;
+  weight_bytes += p.w.size() + p.bias.size() * 4;
+  layers.push_back(std::move(L));
+  return (int)layers.size() - 1;
+}
+
+static PackSpec spec1(int cin_real, int cin_pad, int cin_first = 0, int ps2 = 0) {
+  PackSpec s{}; s.nch0_real = cin_real; s.nch0 = cin_pad; s.nch1_real = 0; s.nch1 = 0; s.cin_first = cin_first; s.ps2 = ps2;
+  return s;
+}
+static PackSpec spec2(int c0, int c1) {
+  PackSpec s{}; s.nch0_real = c0; s.nch0 = c0; s.nch1_real = c1; s.nch1 = c1; s.cin_first = 0; s.ps2 = 0;
+  return s;
+}
+
+void Model::build(const float* w, size_t n) {
+  validate_desc(desc);
+  SS4K_REQUIRE(n == model_param_count(desc), "weight blob size does not match the model description");
+  ParamCursor pc{w, n};
+  if (desc.kind == SS4K_FSRCNN) {
+    // device blob layout: see FsrcnnWeights (glue.h)
+    std::vector<float> blob;
+    auto push = [&](const std::vector<float>& v) { size_t o = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); while (blob.size() % 4) blob.push_back(0.f); return o; };
+    auto conv_tcico = [&](const float* W, int co, int ci, int k2) {  // OIHW -> [tap][ci][co]
+      std::vector<float> o((size_t)k2 * ci * co);
+      for (int a = 0; a < co; ++a) for (int b = 0; b < ci; ++b) for (int t = 0; t < k2; ++t)
+        o[((size_t)t * ci + b) * co + a] = W[((size_t)a * ci + b) * k2 + t];
+      return o;
+    };
+    auto vec = [&](const float* p, int k) { return std::vector<float>(p, p + k); };
+    size_t off[32]; int k = 0;
+    const float* p;
+    p = pc.take(56 * 25); off[k++] = push(conv_tcico(p, 56, 1, 25));
+    off[k++] = push(vec(pc.take(56), 56)); off[k++] = push(vec(pc.take(56), 56));
+    p = pc.take(12 * 56); off[k++] = push(conv_tcico(p, 12, 56, 1));
+    off[k++] = push(vec(pc.take(12), 12)); off[k++] = push(vec(pc.take(12), 12));
+    for (int l = 0; l < 4; ++l) {
+      p = pc.take(12 * 12 * 9); off[k++] = push(conv_tcico(p, 12, 12, 9));
+      off[k++] = push(vec(pc.take(12), 12)); off[k++] = push(vec(pc.take(12), 12));
+    }
+    p = pc.take(56 * 12); off[k++] = push(conv_tcico(p, 56, 12, 1));
+    off[k++] = push(vec(pc.take(56), 56)); off[k++] = push(vec(pc.take(56), 56));
+    p = pc.take(56 * 81);  // ConvTranspose weight (C_in=56, C_out=1, 9, 9) -> [tap][cin]
+    std::vector<float> wd(81 * 56);
+    for (int c = 0; c < 56; ++c) for (int t = 0; t < 81; ++t) wd[(size_t)t * 56 + c] = p[(size_t)c * 81 + t];
+    off[k++] = push(wd);
+    fsw.b_deconv = *pc.take(1);
+    upload(fs_blob, blob.data(), blob.size() * 4);
+    weight_bytes = blob.size() * 4;
+    const float* d = fs_blob.as<float>(); k = 0;
+    fsw.w_feat = d + off[k++]; fsw.b_feat = d + off[k++]; fsw.a_feat = d + off[k++];
+    fsw.w_shrink = d + off[k++]; fsw.b_shrink = d + off[k++]; fsw.a_shrink = d + off[k++];
+    for (int l = 0; l < 4; ++l) { fsw.w_map[l] = d + off[k++]; fsw.b_map[l] = d + off[k++]; fsw.a_map[l] = d + off[k++]; }
+    fsw.w_expand = d + off[k++]; fsw.b_expand = d + off[k++]; fsw.a_expand = d + off[k++];
+    fsw.w_deconv = d + off[k++];
+  } else if (desc.kind == SS4K_RRDBNET) {
+    const int nf = desc.num_feat, g = desc.num_grow_ch;
+    const int cin0 = 3 * (desc.scale == 2 ? 4 : desc.scale == 1 ? 16 : 1);
+    add_conv(pc, nf, cin0, spec1(cin0, pad16(cin0)), false);
+    for (int b = 0; b < desc.num_block; ++b)
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 5; ++c) {
+          const int co = c < 4 ? g : nf;
+          add_conv(pc, co, nf + c * g, c == 0 ? spec1(nf, nf) : spec2(nf, c * g), false);
+        }
+    for (int i = 0; i < 4; ++i) add_conv(pc, nf, nf, spec1(nf, nf), false);
+    add_conv(pc, 3, nf, spec1(nf, nf), false);
+  } else if (desc.kind == SS4K_SRVGG) {
+    const int nf = desc.num_feat;
+    add_conv(pc, nf, 3, spec1(3, 16), true);
+    for (int i = 0; i < desc.num_block; ++i) add_conv(pc, nf, nf, spec1(nf, nf), true);
+    add_conv(pc, 3 * desc.scale * desc.scale, nf, spec1(nf, nf), false);
+  } else {  // BSVD
+    for (int blk = 0; blk < 2; ++blk) {
+      const int ci = blk == 0 ? 4 : desc.bsvd_mid_ch, co = blk == 0 ? desc.bsvd_mid_ch : 3;
+      auto shapes = bsvd_denblock_shapes(desc.bsvd_chns, ci, co, desc.bsvd_interm_ch);
+      for (size_t i = 0; i < shapes.size(); ++i) {
+        const int cout = shapes[i].first, cin = shapes[i].second;
+        // BiBufferConv layers (memconv.c1/c2): with one frame the first cin/4 input channels are
+        // zeros (bsvd/model.py:50-52,108,123) -> skip them in K
+        const bool masked = (i == 3 || i == 4 || i == 6 || i == 7 || i == 8 || i == 9 || i == 11 || i == 12);
+        const bool ps2 = (i == 10 || i == 13);
+        if (masked) add_conv(pc, cout, cin, spec1(cin - cin / 4, cin - cin / 4, cin / 4, 0), false);
+        else add_conv(pc, cout, cin, spec1(cin, pad16(cin), 0, ps2 ? 1 : 0), false);
+      }
+    }
+  }
+  SS4K_REQUIRE(pc.pos == n, "internal: weight cursor did not consume the blob");
+}
+
+// ------------------------------------------------------------------------------------------
+void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, const ConvOpts& o, hipStream_t st) {
+  const ConvLayer& L = layers[li];
+  ConvArgs a{};
+  a.in0 = in0.p; a.cs0 = in0.cs; a.co0 = in0.co; a.nch0 = L.nch0;
+  if (in1) { a.in1 = in1->p; a.cs1 = in1->cs; a.co1 = in1->co; a.nch1 = L.nch1; }
+  a.N = N; a.H = H; a.W = W; a.ups2 = o.ups2;
+  a.wpk = L.w.ptr; a.bias = L.bias.as<float>(); a.prelu = L.has_prelu ? L.prelu.as<float>() : nullptr;
+  a.act = o.act; a.slope = o.slope; a.alpha = o.alpha; a.gamma = o.gamma;
+  if (o.res1) { a.res1 = o.res1->p; a.r1cs = o.res1->cs; a.r1co = o.res1->co; }
+  if (o.res2) { a.res2 = o.res2->p; a.r2cs = o.res2->cs; a.r2co = o.res2->co; }
+  a.bsvd_resid = o.bsvd_resid;
+  a.epi = o.epi; a.out = o.out.p; a.ocs = o.out.cs; a.oco = o.out.co;
+  a.cout_real = L.cout_real; a.cout_pad = L.cout_pad; a.cout_alloc = o.out.cs - o.out.co;
+  a.nchunks0 = L.nchunks0; a.nchunks1 = L.nchunks1;
+  a.flops = 2.0 * 9.0 * L.cin_real * L.cout_real * (double)N * H * W * (o.epi == EPI_NHWC_SUB2 ? 0.25 : 1.0);
+  launch_conv3x3(ctx, a, desc.dtype, st);
+}
+
+Tens Model::act(int idx, size_t pixels, int channels) {
+  if ((int)acts.size() <= idx) acts.resize(idx + 1);
+  acts[idx].ensure(pixels * channels * esz(desc.dtype));
+  return Tens{acts[idx].ptr, channels, 0};
+}
+
+void Model::out_shape(int n, int h, int w, int* oc, int* oh, int* ow) const {
+  (void)n;
+  switch (desc.kind) {
+    case SS4K_FSRCNN: *oc = 1; *oh = h * desc.scale; *ow = w * desc.scale; break;
+    case SS4K_RRDBNET: *oc = 3; *oh = h * desc.scale; *ow = w * desc.scale; break;
+    case SS4K_SRVGG: *oc = 3; *oh = h * desc.scale; *ow = w * desc.scale; break;
+    default: *oc = 3; *oh = h; *ow = w; break;
+  }
+}
+int Model::in_channels() const {
+  return desc.kind == SS4K_FSRCNN ? 1 : desc.kind == SS4K_BSVD ? 4 : 3;
+}
+
+template <typename T>
+void Model::pack_in(const float* in, const Tens& dst, int n, int c, int h, int w, int r, hipStream_t st) {
+  op_pack_input<T>(in, reinterpret_cast<T*>(dst.p), n, c, h, w, r, dst.cs, -1, 0.f, st);
+}
+
+void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_t st) {
+  SS4K_REQUIRE(n > 0 && h > 0 && w > 0, "forward: empty input");
+  const bool f16 = desc.dtype == SS4K_F16;
+  if (desc.kind == SS4K_FSRCNN) {
+    const size_t px = (size_t)n * h * w;
+    if (acts.size() < 3) acts.resize(3);
+    acts[0].ensure(px * 12 * 4); acts[1].ensure(px * 12 * 4); acts[2].ensure(px * 56 * 4);
+    fsrcnn_forward(ctx, fsw, desc.scale, in, out, n, h, w, acts[0].as<float>(), acts[1].as<float>(), acts[2].as<float>(), st);
+    return;
+  }
+  auto pack = [&](const Tens& dst, int c, int r) {
+    if (f16) pack_in<__half>(in, dst, n, c, h, w, r, st); else pack_in<float>(in, dst, n, c, h, w, r, st);
+  };
+  if (desc.kind == SS4K_RRDBNET) {
+    const int nf = desc.num_feat, g = desc.num_grow_ch;
+    const int r = desc.scale == 2 ? 2 : desc.scale == 1 ? 4 : 1;
+    SS4K_REQUIRE(h % r == 0 && w % r == 0, "RRDBNet: input size must be divisible by the pixel-unshuffle factor");
+    const int H = h / r, W = w / r;
+    const size_t px = (size_t)n * H * W;
+    const int cin0 = 3 * r * r;
+    Tens P = act(0, px, pad16(cin0));
+    Tens F = act(1, px, nf), X[3] = {act(2, px, nf), act(3, px, nf), act(4, px, nf)};
+    Tens G = act(5, px, 4 * g);
+    pack(P, 3, r);
+    int li = 0;
+    { ConvOpts o; o.out = F; conv(li++, P, nullptr, n, H, W, o, st); }
+    Tens cur = F;
+    for (int b = 0; b < desc.num_block; ++b) {
+      const Tens a = cur;
+      const Tens t1 = X[0], t2 = X[1];
+      const Tens dst = (a.p == F.p) ? X[2] : a;
+      const Tens rin[3] = {a, t1, t2};
+      const Tens rout[3] = {t1, t2, dst};
+      for (int rr = 0; rr < 3; ++rr) {
+        for (int c = 0; c < 4; ++c) {
+          ConvOpts o; o.act = ACT_LRELU; o.slope = 0.2f; o.out = Tens{G.p, G.cs, c * g};
+          Tens gin = Tens{G.p, G.cs, 0};
+          conv(li++, rin[rr], c == 0 ? nullptr : &gin, n, H, W, o, st);
+        }
+        ConvOpts o; o.alpha = 0.2f; o.res1 = &rin[rr]; o.out = rout[rr];
+        if (rr == 2) { o.gamma = 0.2f; o.res2 = &a; }
+        Tens gin = Tens{G.p, G.cs, 0};
+        conv(li++, rin[rr], &gin, n, H, W, o, st);
+      }
+      cur = dst;
+    }
+    { ConvOpts o; o.res1 = &F; o.out = X[0]; conv(li++, cur, nullptr, n, H, W, o, st); }  // feat + conv_body(body)
+    Tens U1 = act(6, px * 4, nf), U2 = act(7, px * 16, nf), U3 = act(8, px * 16, nf);
+    { ConvOpts o; o.ups2 = 1; o.act = ACT_LRELU; o.slope = 0.2f; o.out = U1; conv(li++, X[0], nullptr, n, 2 * H, 2 * W, o, st); }
+    { ConvOpts o; o.ups2 = 1; o.act = ACT_LRELU; o.slope = 0.2f; o.out = U2; conv(li++, U1, nullptr, n, 4 * H, 4 * W, o, st); }
+    { ConvOpts o; o.act = ACT_LRELU; o.slope = 0.2f; o.out = U3; conv(li++, U2, nullptr, n, 4 * H, 4 * W, o, st); }
+    { ConvOpts o; o.epi = EPI_NCHW_F32; o.out = Tens{out, 0, 0}; conv(li++, U3, nullptr, n, 4 * H, 4 * W, o, st); }
+    return;
+  }
+  if (desc.kind == SS4K_SRVGG) {
+    const int nf = desc.num_feat;
+    const size_t px = (size_t)n * h * w;
+    Tens P = act(0, px, 16), A = act(1, px, nf), B = act(2, px, nf);
+    pack(P, 3, 1);
+    int li = 0;
+    { ConvOpts o; o.act = ACT_PRELU; o.out = A; conv(li++, P, nullptr, n, h, w, o, st); }
+    Tens cur = A, nxt = B;
+    for (int i = 0; i < desc.num_block; ++i) {
+      ConvOpts o; o.act = ACT_PRELU; o.out = nxt; conv(li++, cur, nullptr, n, h, w, o, st);
+      std::swap(cur, nxt);
+    }
+    const int cz = layers[li].cout_pad;
+    Tens Z = act(3, px, cz);
+    { ConvOpts o; o.out = Z; conv(li++, cur, nullptr, n, h, w, o, st); }
+    if (f16) op_ps_nchw_addbase<__half>(reinterpret_cast<const __half*>(Z.p), cz, out, in, n, h, w, desc.scale, 3, st);
+    else op_ps_nchw_addbase<float>(reinterpret_cast<const float*>(Z.p), cz, out, in, n, h, w, desc.scale, 3, st);
+    return;
+  }
+  // ---- BSVD, one frame per call -----------------------------------------------------------
+  SS4K_REQUIRE(h % 4 == 0 && w % 4 == 0, "BSVD: frame size must be divisible by 4");
+  const int c0 = desc.bsvd_chns[0], c1 = desc.bsvd_chns[1], c2 = desc.bsvd_chns[2], mid = desc.bsvd_mid_ch;
+  const size_t px = (size_t)n * h * w, px2 = px / 4, px4 = px / 16;
+  const int h2 = h / 2, w2 = w / 2, h4 = h / 4, w4 = w / 4;
+  Tens IN0 = act(0, px, 16), MID = act(1, px, mid);
+  pack(IN0, 4, 1);
+  int li = 0;
+  for (int blk = 0; blk < 2; ++blk) {
+    const Tens IN = blk == 0 ? IN0 : MID;
+    Tens I0 = act(2, px, 32), X0 = act(3, px, c0);
+    Tens D0 = act(4, px2, c1), Ma = act(5, px2, c1), X1 = act(6, px2, c1);
+    Tens D1 = act(7, px4, c2), Mb = act(8, px4, c2), X2 = act(9, px4, c2), Mc = act(10, px4, c2);
+    Tens S1 = act(11, px2, c1), S0 = act(12, px, c0), O0 = act(13, px, c0);
+    auto relu6 = [&](Tens outT) { ConvOpts o; o.act = ACT_RELU6; o.out = outT; return o; };
+    auto masked = [&](const Tens& t) { return Tens{t.p, t.cs, t.cs / 4}; };
+    conv(li++, IN, nullptr, n, h, w, relu6(I0), st);                                   // inc.convblock.0
+    conv(li++, I0, nullptr, n, h, w, relu6(X0), st);                                   // inc.convblock.3
+    { ConvOpts o = relu6(D0); o.epi = EPI_NHWC_SUB2; conv(li++, X0, nullptr, n, h, w, o, st); }   // downc0 stride 2
+    conv(li++, masked(D0), nullptr, n, h2, w2, relu6(Ma), st);
+    conv(li++, masked(Ma), nullptr, n, h2, w2, relu6(X1), st);
+    { ConvOpts o = relu6(D1); o.epi = EPI_NHWC_SUB2; conv(li++, X1, nullptr, n, h2, w2, o, st); } // downc1 stride 2
+    conv(li++, masked(D1), nullptr, n, h4, w4, relu6(Mb), st);
+    conv(li++, masked(Mb), nullptr, n, h4, w4, relu6(X2), st);
+    conv(li++, masked(X2), nullptr, n, h4, w4, relu6(Mc), st);                         // upc2.memconv
+    conv(li++, masked(Mc), nullptr, n, h4, w4, relu6(Mb), st);
+    { ConvOpts o; o.epi = EPI_NHWC_PS2; o.res1 = &X1; o.out = S1; conv(li++, Mb, nullptr, n, h4, w4, o, st); }  // PixelShuffle + skip3
+    conv(li++, masked(S1), nullptr, n, h2, w2, relu6(Ma), st);                         // upc1.memconv
+    conv(li++, masked(Ma), nullptr, n, h2, w2, relu6(D0), st);
+    { ConvOpts o; o.epi = EPI_NHWC_PS2; o.res1 = &X0; o.out = S0; conv(li++, D0, nullptr, n, h2, w2, o, st); }  // PixelShuffle + skip2
+    conv(li++, S0, nullptr, n, h, w, relu6(O0), st);                                   // outc.convblock.0
+    { ConvOpts o; o.res1 = &IN; o.bsvd_resid = 1;
+      if (blk == 0) { o.out = MID; } else { o.epi = EPI_NCHW_F32; o.out = Tens{out, 0, 0}; }
+      conv(li++, O0, nullptr, n, h, w, o, st); }                                       // outc.convblock.3 + residual
+  }
+}
+
+}  // namespace ss4k

@@ -1,0 +1,56 @@
+// Model object behind ss4k_model (C ABI in include/ss4k.h).
+#pragma once
+#include "common.h"
+#include "glue.h"
+
+namespace ss4k {
+
+struct Tens { void* p; int cs; int co; };  // NHWC activation view: base, channels per pixel, channel offset
+
+struct ConvLayer {
+  DevBuf w, bias, prelu;
+  bool has_prelu = false;
+  int cout_real = 0, cout_pad = 0, cin_real = 0, nch0 = 0, nch1 = 0, nchunks0 = 0, nchunks1 = 0;
+};
+
+struct ConvOpts {
+  int ups2 = 0;
+  int act = ACT_NONE; float slope = 0.f;
+  float alpha = 1.f, gamma = 1.f;
+  const Tens* res1 = nullptr; const Tens* res2 = nullptr;
+  int bsvd_resid = 0;
+  int epi = EPI_NHWC;
+  Tens out{nullptr, 0, 0};
+};
+
+struct ParamCursor;
+size_t model_param_count(const ss4k_model_desc& d);
+
+struct Model {
+  ss4k_ctx* ctx = nullptr;
+  ss4k_model_desc desc{};
+  std::vector<ConvLayer> layers;
+  std::vector<DevBuf> acts;
+  DevBuf fs_blob; FsrcnnWeights fsw{};
+  size_t weight_bytes = 0;
+
+  void build(const float* w, size_t n);
+  void forward(const float* in, float* out, int n, int h, int w, hipStream_t st);
+  void out_shape(int n, int h, int w, int* oc, int* oh, int* ow) const;
+  int in_channels() const;
+  ~Model() {
+    for (auto& l : layers) { l.w.release(); l.bias.release(); l.prelu.release(); }
+    for (auto& a : acts) a.release();
+    fs_blob.release();
+  }
+
+ private:
+  int add_conv(ParamCursor& pc, int cout, int cin_total, const PackSpec& spec, bool has_prelu_after);
+  void conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, const ConvOpts& o, hipStream_t st);
+  Tens act(int idx, size_t pixels, int channels);
+  template <typename T> void pack_in(const float* in, const Tens& dst, int n, int c, int h, int w, int r, hipStream_t st);
+};
+
+}  // namespace ss4k
+
+struct ss4k_model { ss4k::Model m; };

@@ -1,0 +1,52 @@
+"""Shared helpers for the parity tests (oracle = checker, never the thing under test)."""
+import numpy as np
+import torch
+
+import sharkshark4k_amd  # noqa: F401
+from sharkshark4k_amd import weights as W
+from oracle import nets as onets
+
+RTOL, ATOL = 1e-3, 1e-4  # north_star tolerance for the fp32 path
+
+
+def assert_close(got, want, rtol=RTOL, atol=ATOL, what=""):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want)
+    assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    tol = atol + rtol * np.abs(want.astype(np.float64))
+    bad = err > tol
+    assert not bad.any(), (f"{what}: {bad.sum()} / {bad.size} outside rtol={rtol} atol={atol}; "
+                           f"max err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}")
+
+
+def psnr(a, b, peak=1.0):
+    a = a.detach().cpu().double() if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a)).double()
+    b = b.detach().cpu().double() if isinstance(b, torch.Tensor) else torch.from_numpy(np.asarray(b)).double()
+    mse = torch.mean((a - b) ** 2).item()
+    return float("inf") if mse == 0 else 10.0 * np.log10(peak * peak / mse)
+
+
+def assert_u8_close(got, want, max_lsb=1, max_frac=0.02, what=""):
+    """uint8 frames after truncation: float parity within 1e-4 can flip the integer by one LSB."""
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want)
+    assert got.shape == want.shape and got.dtype == np.uint8, f"{what}: {got.shape} {got.dtype} vs {want.shape}"
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= max_lsb, f"{what}: max |delta| = {d.max()} LSB"
+    frac = float((d > 0).mean())
+    assert frac <= max_frac, f"{what}: {frac:.4f} of the bytes differ"
+
+
+def rrdb_small_table(seed=5, scale=2, num_block=2):
+    return W.rrdbnet_table(seed, scale=scale, num_feat=64, num_block=num_block, num_grow_ch=32)
+
+
+def smooth_u8(seed, shape):
+    n, h, w, c = shape
+    g = np.random.default_rng(seed).random((n, h + 8, w + 8, c)).astype(np.float32)
+    k = 9
+    cs = np.cumsum(np.cumsum(np.pad(g, ((0, 0), (1, 0), (1, 0), (0, 0))), 1), 2)
+    box = (cs[:, k:, k:] - cs[:, :-k, k:] - cs[:, k:, :-k] + cs[:, :-k, :-k]) / (k * k)
+    box = (box - box.min()) / (box.max() - box.min())
+    return (box[:, :h, :w] * 255).astype(np.uint8)

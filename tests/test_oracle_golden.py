@@ -1,0 +1,107 @@
+"""CPU: the oracle reproduces every golden vector captured from the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+import sharkshark4k_amd  # noqa: F401
+from sharkshark4k_amd import weights as W
+from oracle import nets as onets
+from oracle import service as osvc
+from tests.conftest import load_golden, manifest
+
+CASES = manifest()
+
+
+def _t91(factor):
+    import os
+    from tests.conftest import GOLDEN
+    flat = np.load(os.path.join(GOLDEN, f"fsrcnn_x{factor}_T91_flat.npy"))
+    table, pos = {}, 0
+    ref = W.fsrcnn_table(0)
+    for k in W.fsrcnn_keys():
+        n = ref[k].size
+        table[k] = flat[pos:pos + n].reshape(ref[k].shape)
+        pos += n
+    assert pos == flat.size == 12809
+    return table
+
+
+@pytest.mark.parametrize("factor", [2, 4])
+@pytest.mark.parametrize("tag", ["t91", "gen"])
+def test_fsrcnn_matches_reference(factor, tag):
+    g = load_golden(f"fsrcnn_x{factor}_{tag}")
+    table = _t91(factor) if tag == "t91" else W.fsrcnn_table(seed=factor)
+    with torch.no_grad():
+        y = onets.fsrcnn(torch.from_numpy(g["x"]), table, factor).numpy()
+    assert np.array_equal(y, g["y"])
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if n.startswith("srvgg_")])
+def test_srvgg_matches_reference(name):
+    m = CASES[name]
+    g = load_golden(name)
+    seed = int(m["weights"].split("seed=")[1].rstrip(")"))
+    table = W.srvgg_table(seed=seed, num_feat=m["num_feat"], num_conv=m["num_conv"], upscale=m["upscale"])
+    with torch.no_grad():
+        y = onets.srvgg(torch.from_numpy(g["x"]), table, m["num_conv"], m["upscale"]).numpy()
+    assert np.array_equal(y, g["y"])
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if n.startswith("bsvd32_")])
+def test_bsvd_f1_matches_reference(name):
+    g = load_golden(name)
+    with torch.no_grad():
+        y = onets.bsvd_f1(torch.from_numpy(g["x"]), W.bsvd_table(seed=21)).numpy()
+    assert np.array_equal(y, g["y"])
+
+
+def oracle_service_from_manifest(m):
+    if m["sr"] == "srvgg":
+        t = W.srvgg_table(seed=m["seed"], num_feat=m["num_feat"], num_conv=m["num_conv"], upscale=m["upscale"])
+        model = lambda x: onets.srvgg(x, t, m["num_conv"], m["upscale"])
+    else:
+        t = W.fsrcnn_table(seed=m["seed"])
+        model = lambda x: onets.fsrcnn(x, t, m["factor"])
+    bs = W.bsvd_table(seed=m["bsvd_seed"])
+    return osvc.OracleUpscaler(model, denoising=m["denoising"], denoise_rate=m["denoise_rate"], upscaler_model=m["mode"],
+                               lr_hr_resize=m["lr_hr_resize"], denoise_model=lambda x: onets.bsvd_f1(x, bs),
+                               output_shape=None if m["output_shape"] is None else tuple(m["output_shape"]),
+                               single_mode=m["single_mode"], lr_shape=tuple(m["lr_shape"]))
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if n.startswith("svc_")])
+def test_service_glue_matches_reference(name):
+    g = load_golden(name)
+    svc = oracle_service_from_manifest(CASES[name])
+    frames = torch.from_numpy(g["frames"])
+    assert np.array_equal(svc.upscale(frames).numpy(), g["out1"])
+    assert np.array_equal(svc.upscale(frames).numpy(), g["out2"])  # second job: later-frame noise map
+
+
+def test_resample_known_answers():
+    g = load_golden("kat_resample")
+    x = torch.from_numpy(g["x"])
+    assert np.array_equal(osvc.depthwise_reflect(x, osvc.gaussian_kernel2d(17, 8.0)).numpy(), g["blur17"])
+    assert np.array_equal(osvc.depthwise_reflect(x, osvc.sharpen_kernel2d(0.00007)).numpy(), g["sharpen_hr"])
+    assert np.array_equal(osvc.gaussian_kernel2d(17, 8.0).numpy(), g["blur17_weight"])
+    assert np.array_equal(osvc.sharpen_kernel2d(0.00002).numpy(), g["sharpen_weight"])
+
+
+def test_rrdbnet_self_checks():
+    """RRDBNet is unpinned by the reference (basicsr absent): check structure only."""
+    assert W.num_params(W.rrdbnet_table(0, scale=2)) == 16_703_171
+    assert W.num_params(W.rrdbnet_table(0, scale=4)) == 16_697_987
+    t = W.rrdbnet_table(3, scale=2, num_block=1)
+    x = torch.rand(1, 3, 16, 24)
+    with torch.no_grad():
+        y = onets.rrdbnet(x, t, 2, 1)
+    assert y.shape == (1, 3, 32, 48) and torch.isfinite(y).all()
+    t4 = W.rrdbnet_table(3, scale=4, num_block=1)
+    with torch.no_grad():
+        assert onets.rrdbnet(x, t4, 4, 1).shape == (1, 3, 64, 96)
+
+
+def test_param_counts():
+    assert W.num_params(W.fsrcnn_table(0)) == 12_809
+    assert W.num_params(W.srvgg_table(0)) == 1_213_296
+    assert W.num_params(W.bsvd_table(0)) == 2_454_583
