@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: upscaled frames/s at 720p -> 1440p x2 on MI355X.
+
+One "step" = one call of the frame-in/frame-out hot path (``ss4k_upscale_frames``: uint8 NHWC
+frames resident in HBM -> uint8 NHWC upscaled frames in HBM) over one batch of synthetic frames.
+Default workload (BASELINE.json configs[2], the one the >=24 fps target is quoted on):
+RealESRGAN RRDBNet x2 (23 blocks), fp16 storage / fp32 accumulate.  Other BASELINE configs via
+--workload {fsrcnn,rrdbnet,pipeline,srvgg}.
+
+Multi-GPU (launched by torchrun, one rank per GPU): frames are sharded one-per-GPU with no
+data-path collective (weak scaling: every rank runs the same per-GPU batch); the weight blob is
+broadcast once from rank 0 over RCCL.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import sharkshark4k_amd  # noqa: E402,F401
+from sharkshark4k_amd import _capi, sharding, weights as W  # noqa: E402
+from sharkshark4k_amd.upscale import model as factory  # noqa: E402
+
+MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16
+F32_VECTOR_PEAK_TFLOPS = 157.3
+
+WORKLOADS = {
+    "rrdbnet": "RealESRGAN RRDBNet x2 (23 blocks) 720p->1440p fp16 [BASELINE configs[2]]",
+    "fsrcnn": "FSRCNN x2 720p->1440p fp32 [BASELINE configs[1]]",
+    "pipeline": "BSVD denoise + RealESRGAN RRDBNet x2 720p->1440p fp16, per-frame path [BASELINE configs[3]]",
+    "srvgg": "SRVGGNetCompact realesr-general-x4v3 x4 + bicubic to 1440p fp16 (the reference's shipped default)",
+}
+
+
+def build_upscaler(ctx, workload, device, lr_shape=(720, 1280)):
+    """Returns (upscaler, keepalive, algorithmic FLOPs per frame of the networks)."""
+    px = lr_shape[0] * lr_shape[1]
+    def bcast(table, keys):
+        flat = W.flatten(table, keys) if table is not None else None
+        n = sum(int(np.prod(v.shape)) for v in table.values()) if table is not None else 0
+        return flat, n
+    rank = int(os.environ.get("RANK", "0"))
+    if workload == "fsrcnn":
+        table = W.fsrcnn_table(0)
+        flat = sharding.broadcast_weights(W.flatten(table, W.fsrcnn_keys()) if rank == 0 else None, 12809, device)
+        sr = _capi.Model(ctx, _capi.make_desc(_capi.FSRCNN, _capi.F32, scale=2), flat)
+        up = _capi.Upscaler(ctx, sr, lr_shape, None, True, True, None, 1.0)
+        return up, (sr,), 74784.0 * px
+    if workload in ("rrdbnet", "pipeline"):
+        n = 16_703_171
+        flat = sharding.broadcast_weights(W.flatten(W.rrdbnet_table(0, scale=2), W.rrdbnet_keys(23)) if rank == 0 else None, n, device)
+        sr = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2), flat)
+        flops = 8.263e12 * px / (720 * 1280)
+        if workload == "rrdbnet":
+            up = _capi.Upscaler(ctx, sr, lr_shape, None, True, False, None, 1.0)
+            return up, (sr,), flops
+        nb = 2_454_583
+        fb = sharding.broadcast_weights(W.flatten(W.bsvd_table(0), W.bsvd_keys()) if rank == 0 else None, nb, device)
+        dn = _capi.Model(ctx, _capi.make_desc(_capi.BSVD, _capi.F16, scale=1), fb)
+        up = _capi.Upscaler(ctx, sr, lr_shape, None, True, True, dn, 1.0)
+        return up, (sr, dn), flops + 590256.0 * px
+    if workload == "srvgg":
+        t = W.dni_blend(W.srvgg_table(0), W.srvgg_table(1), 0.5)
+        flat = sharding.broadcast_weights(W.flatten(t, W.srvgg_keys(32)) if rank == 0 else None, 1_213_296, device)
+        sr = _capi.Model(ctx, _capi.make_desc(_capi.SRVGG, _capi.F16, scale=4, num_feat=64, num_block=32), flat)
+        up = _capi.Upscaler(ctx, sr, lr_shape, (1440, 2560), True, False, None, 1.0)
+        return up, (sr,), 2.0 * 1_209_024 * px
+    raise SystemExit(f"unknown workload {workload}")
+
+
+def synthetic_frames(batch, shape, seed):
+    return torch.from_numpy(np.random.default_rng(seed).integers(0, 256, (batch, shape[0], shape[1], 3), dtype=np.uint8))
+
+
+def cpu_baseline(workload, gpu_ctx, seconds_budget=25.0):
+    """Oracle timed on this box's host cores on a bounded crop of the same workload; also the
+    PSNR of the GPU production path against it on that crop."""
+    from oracle import nets as onets
+    from oracle import service as osvc
+    # many-core hosts oversubscribe small convs badly (256 threads: 285 s for a 96x160 crop); 16 is the sweet spot
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    if workload == "fsrcnn":
+        crop, table = (360, 640), W.fsrcnn_table(0)
+        model = lambda x: onets.fsrcnn(x, table, 2)
+        osv = osvc.OracleUpscaler(model, upscaler_model="fsrcnn", lr_shape=crop)
+        sr = _capi.Model(gpu_ctx, _capi.make_desc(_capi.FSRCNN, _capi.F32, scale=2), W.flatten(table, W.fsrcnn_keys()))
+        up = _capi.Upscaler(gpu_ctx, sr, crop, None, True, True, None, 1.0)
+    else:
+        crop, table = (96, 160), W.rrdbnet_table(0, scale=2)
+        model = lambda x: onets.rrdbnet(x, table, 2, 23)
+        osv = osvc.OracleUpscaler(model, upscaler_model="realesrgan", lr_shape=crop)
+        sr = _capi.Model(gpu_ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2), W.flatten(table, W.rrdbnet_keys(23)))
+        up = _capi.Upscaler(gpu_ctx, sr, crop, None, True, False, None, 1.0)
+    frames = synthetic_frames(1, crop, 123)
+    # smooth content for a meaningful PSNR
+    from tests.helpers import smooth_u8
+    frames = torch.from_numpy(smooth_u8(123, (1, crop[0], crop[1], 3)))
+    osv.upscale(frames)  # warm-up
+    t0 = time.perf_counter(); reps = 0
+    while True:
+        want = osv.upscale(frames); reps += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget * 0.5 or reps >= 5:
+            break
+    sec_per_crop = el / reps
+    frac = (crop[0] * crop[1]) / (720 * 1280)
+    got = up(frames.cuda()).cpu()
+    mse = torch.mean((got.double() - want.double()) ** 2).item()
+    psnr = float("inf") if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+    return {"value": frac / sec_per_crop, "unit": "frames/s (720p-frame equivalents)", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"oracle (PyTorch CPU fp32) on one {crop[0]}x{crop[1]} crop = {frac:.4f} of a 720p frame, "
+                      f"{reps} reps, {sec_per_crop:.2f} s each"}, psnr
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1, help="frames per step per GPU")
+    ap.add_argument("--workload", default="rrdbnet", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = sharding.init_distributed()
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    ctx = _capi.Context(local)
+    up, keep, flops_per_frame = build_upscaler(ctx, args.workload, device)
+
+    # every rank gets its own shard of the synthetic stream: frames rank, rank+world, ...
+    frames = synthetic_frames(args.batch, (720, 1280), seed=1000 + rank).to(device)
+    oh, ow = up.out_shape(args.batch, 720, 1280)
+    out = torch.empty((args.batch, oh, ow, 3), dtype=torch.uint8, device=device)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        up(frames, out)
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        up(frames, out)
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_frames = args.batch * args.steps * world
+    fps = total_frames / elapsed
+
+    result = {
+        "metric": "upscaled frames/sec at 720p->1440p x2 (whole job)", "value": fps, "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.workload == "fsrcnn" else "f16", "data": "synthetic",
+        "config": {"workload": WORKLOADS[args.workload], "frames_per_step_per_gpu": args.batch,
+                   "in": [720, 1280, 3], "out": [oh, ow, 3], "io": "uint8 NHWC resident in HBM",
+                   "parallelism": f"frame-sharded x{world}, weights broadcast once (RCCL)",
+                   "fps_per_gpu": fps / world, "net_tflops_per_gpu": flops_per_frame * fps / world / 1e12},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel, timed live with HIP events on the launch stream (untimed extra steps)
+        ctx.prof_reset(); ctx.prof_enable(True)
+        psteps = 3
+        for _ in range(psteps):
+            up(frames, out)
+        torch.cuda.synchronize()
+        launches, ms, flops = ctx.prof_read()
+        ctx.prof_enable(False)
+        if launches > 0 and ms > 0:
+            ach = flops / (ms * 1e-3) / 1e12
+            result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": ach / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": None,
+                                  "kernel": "ss4k::conv3x3_kernel<__half,NB> (implicit-GEMM 3x3 conv, v_mfma_f32_32x32x16_f16)",
+                                  "launches_per_frame": launches / (psteps * args.batch),
+                                  "avg_launch_us": 1000.0 * ms / launches,
+                                  "algorithmic_gflop_per_launch": flops / launches / 1e9,
+                                  "kernel_time_share_of_step": (ms / psteps) / (1000.0 * elapsed / args.steps)}
+        elif args.workload == "fsrcnn":
+            ach = flops_per_frame * fps / world / 1e12
+            result["roofline"] = {"bound": "valu-fp32", "achieved": ach, "peak": F32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": ach / F32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                                  "kernel": "fsrcnn VALU kernels (whole-step average; no MFMA kernel in this workload)"}
+    if rank == 0 and not args.no_cpu_baseline:
+        cb, psnr = cpu_baseline(args.workload, ctx)
+        result["cpu_baseline"] = cb
+        result["psnr_db_vs_cpu_ref"] = psnr
+    if world > 1:
+        barrier()
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

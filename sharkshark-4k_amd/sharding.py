@@ -1,0 +1,73 @@
+"""Frame sharding across the GPUs of one node: one process per GPU, no data-path collective.
+
+The reference runs one upscaler process on one GPU (``pipeline.py:20``); every frame (job) is
+independent, so jobs are dealt round-robin by ``step``: job ``s`` goes to rank
+``s % world``.  The only collective is one broadcast of the packed weight blob from rank 0 at
+start-up (RCCL over xGMI with backend ``nccl``; ``gloo`` in the CPU tests), so every rank runs
+bit-identical weights without touching the filesystem/network again.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from the torchrun environment; initialises the process group."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def owner_of(step: int, world: int) -> int:
+    return step % world
+
+
+def my_steps(steps: Iterable[int], rank: int, world: int) -> List[int]:
+    return [s for s in steps if owner_of(s, world) == rank]
+
+
+def broadcast_weights(flat: Optional[np.ndarray], n_floats: int, device: torch.device, src: int = 0) -> np.ndarray:
+    """Rank ``src`` passes the flat fp32 state_dict blob, the others ``None``; all get a copy."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        assert flat is not None
+        return np.ascontiguousarray(flat, dtype=np.float32)
+    t = torch.empty(n_floats, dtype=torch.float32, device=device)
+    if dist.get_rank() == src:
+        assert flat is not None and flat.size == n_floats
+        t.copy_(torch.from_numpy(np.ascontiguousarray(flat, dtype=np.float32)))
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
+def reorder_results(results: Sequence[Tuple[int, object]]) -> List[object]:
+    """Fan-in: results arrive per rank in any interleaving; the sink emits them ordered by step
+    (the reference's streamer only warns on out-of-order steps, ``streamer.py:77-78``)."""
+    return [r for _, r in sorted(results, key=lambda sr: sr[0])]
+
+
+def gather_step_results(local: Dict[int, torch.Tensor], world: int) -> Dict[int, torch.Tensor]:
+    """Debug/test helper: collect every rank's {step: tensor} on all ranks (object collective;
+    NOT on the timed path — production sinks read each rank's queue directly)."""
+    if world == 1:
+        return dict(local)
+    payload = {s: t.cpu() for s, t in local.items()}
+    out: List[Optional[dict]] = [None] * world
+    dist.all_gather_object(out, payload)
+    merged: Dict[int, torch.Tensor] = {}
+    for d in out:
+        merged.update(d)
+    return merged
