@@ -63,6 +63,11 @@ struct ss4k_ctx {
   std::vector<ss4k::ProfEvent> prof_pool;
   int64_t prof_launches = 0;
   double prof_ms = 0, prof_flops = 0;
+  const char* zero_page() {
+    auto& b = scratch["zero_page"];
+    if (!b.ptr) { b.ensure(256); (void)hipMemset(b.ptr, 0, 256); }
+    return b.as<char>();
+  }
   ss4k::DevBuf& buf(const std::string& name, size_t bytes) {
     auto& b = scratch[name];
     b.ensure(bytes);
@@ -80,47 +85,46 @@ enum Epi {
   EPI_NCHW_F32 = 3     // final fp32 planes out[((n*C+c)*H+y)*W+x], c < cout_real
 };
 
-// One 3x3 / pad 1 / stride 1 convolution over NHWC activations as an implicit GEMM.
+// One 3x3 / pad 1 / stride 1 convolution over "planes" activations (see conv_mfma.hip) as an implicit GEMM.
 struct ConvArgs {
-  const void* in0; int cs0, co0, nch0;  // segment 0: channel stride, channel offset, #channels (padded)
-  const void* in1; int cs1, co1, nch1;  // optional segment 1 (dense concat is free)
+  const char* in0; uint32_t in0_plane_bytes; int in0_plane0, nchunks0;  // segment 0: one plane per K-chunk
+  const char* in1; uint32_t in1_plane_bytes; int in1_plane0, nchunks1;  // optional segment 1 (dense concat is free)
+  const char* zero_page;                // >= 64 zero bytes: DMA source for the zero padding
   int N, H, W;                          // conv grid (== output grid before SUB2/PS2)
   int ups2;                             // input is the nearest-x2 upsampling of an (H/2, W/2) tensor
-  const void* wpk;                      // packed weights [group][chunk][tap][ks][nb][lane][E]
+  const void* wpk;                      // packed weights [group][chunk][dx,ks][dy][nb][lane][E]
   const float* bias;                    // [cout_pad] virtual order
   const float* prelu;                   // [cout_pad] or null
   int act; float slope;
   float alpha, gamma;                   // v = (act(acc+bias)*alpha + res1)*gamma + res2
-  const void* res1; int r1cs, r1co;
-  const void* res2; int r2cs, r2co;
+  const char* res1; uint32_t r1_plane_bytes; int r1_plane0;
+  const char* res2; uint32_t r2_plane_bytes; int r2_plane0;
   int bsvd_resid;                       // channels < 3: v = res1 - v (bsvd/model.py:436-442)
   int epi;
-  void* out; int ocs, oco;
-  int cout_real, cout_pad, cout_alloc;  // real couts, padded to NB*32 multiples, channels the NHWC dst holds
-  int nchunks0, nchunks1;
+  char* out; uint32_t out_plane_bytes; int out_plane0;
+  int cout_real, cout_pad;
   int tiles_x, tiles_y;
   double flops;                         // algorithmic FLOPs of this layer (profiling only)
 };
 
 // launchers (conv_mfma.hip)
 void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a, int dtype, hipStream_t st);
-int conv_kc(int dtype);  // channels per K-chunk: 32 (f16) / 16 (f32)
+int conv_cw(int dtype);  // channels per plane / K-chunk: 32 (f16) / 16 (f32)
 
 // weight packing (pack.cpp) --------------------------------------------------------------
 struct PackSpec {
   int dtype;
   int cout_real, cin_total;        // OIHW dims of the source tensor
-  int nch0_real, nch0;             // logical cin [0,nch0_real) live in segment 0 padded to nch0
-  int nch1_real, nch1;             // remaining logical cin in segment 1
-  int cin_first;                   // first logical cin used (BSVD masked convs skip [0, C/4))
+  std::vector<int> cin_map;        // [nchunks * CW] logical cin of every channel slot the conv reads, -1 = none
+  int nchunks0, nchunks1;          // how the chunks split over the two input segments
   int ps2;                         // virtual cout order [sub][c'] for PixelShuffle(2)
 };
 struct PackedConv {
   std::vector<uint8_t> w;          // device-order bytes
   std::vector<float> bias, prelu;  // [cout_pad]
-  int cout_pad, nb, groups, nchunks0, nchunks1;
+  int cout_pad, nb, groups;
 };
 PackedConv pack_conv3x3(const PackSpec& s, const float* w_oihw, const float* bias, const float* prelu);
-int virt_to_real_cout(const PackSpec& s, int v, int cout_pad);
+int virt_to_real_cout(const PackSpec& s, int v);
 
 }  // namespace ss4k

@@ -17,12 +17,9 @@ void op_sub(const float* a, const float* b, float* out, size_t n, hipStream_t st
 void op_clamp01(float* x, size_t n, hipStream_t st);
 void op_f32nchw_to_u8nhwc(const float* in, uint8_t* out, int n, int c, int h, int w, hipStream_t st);
 template <typename T>
-void op_pack_input(const float* in, T* out, int n, int c, int h, int w, int r, int cpad, int fill_ch, float fill_val,
-                   hipStream_t st);
-
+void op_pack_input(const float* in, T* out, int n, int c, int h, int w, int r, int nplanes, hipStream_t st);
 template <typename T>
-void op_ps_nchw_addbase(const T* src, int cs, float* out, const float* base, int n, int h, int w, int r, int cq,
-                        hipStream_t st);
+void op_ps_nchw_addbase(const T* src, float* out, const float* base, int n, int h, int w, int r, int cq, hipStream_t st);
 
 // FSRCNN (fsrcnn.hip): whole-network forward on fp32 planes, weights in the device layout
 // produced by fsrcnn_pack_weights.

@@ -230,59 +230,63 @@ void op_f32nchw_to_u8nhwc(const float* in, uint8_t* out, int n, int c, int h, in
   hipLaunchKernelGGL(k_f32nchw_to_u8nhwc, grid1d((size_t)n * h * w), dim3(256), 0, st, in, out, n, c, h, w);
 }
 
-// ------------------------------------------------------------------ network input packing
-// NCHW fp32 -> NHWC T with zero channel padding and optional pixel-unshuffle(r) (RRDBNet x2/x1
-// front end, basicsr pixel_unshuffle: channel = c*r*r + dy*r + dx).  fill_ch/fill_val write a
-// constant plane (BSVD noise map, fsrcnn_upscaler.py:262,269-271) into one channel.
+// ------------------------------------------------------------------ network input / output layout converters
+// NCHW fp32 -> "planes" T (conv_mfma.hip): channel k lives in plane k / CW at offset k % CW of the
+// pixel's 64-byte record; optional pixel-unshuffle(r) (RRDBNet x2/x1 front end, basicsr
+// pixel_unshuffle: channel = c*r*r + dy*r + dx); unused channels of the last plane are zeroed.
 template <typename T>
 __global__ void k_pack_input(const float* __restrict__ in, T* __restrict__ out, int n, int c, int h, int w, int r,
-                             int cpad, int fill_ch, float fill_val) {
+                             int nplanes) {
+  constexpr int CW = 64 / sizeof(T);
   const int oh = h / r, ow = w / r;
   const size_t total = (size_t)n * oh * ow;
+  const int creal = c * r * r;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int ox = i % ow, oy = (i / ow) % oh;
     const size_t img = i / ((size_t)ow * oh);
-    T* dst = out + i * cpad;
-    int k = 0;
-    for (int ci = 0; ci < c; ++ci)
-      for (int dy = 0; dy < r; ++dy)
-        for (int dx = 0; dx < r; ++dx, ++k)
-          dst[k] = (T)in[((img * c + ci) * h + (size_t)oy * r + dy) * w + (size_t)ox * r + dx];
-    for (; k < cpad; ++k) dst[k] = (T)(k == fill_ch ? fill_val : 0.f);
+    for (int k = 0; k < nplanes * CW; ++k) {
+      float v = 0.f;
+      if (k < creal) {
+        const int ci = k / (r * r), rem = k - ci * r * r, dy = rem / r, dx = rem - dy * r;
+        v = in[((img * c + ci) * h + (size_t)oy * r + dy) * w + (size_t)ox * r + dx];
+      }
+      out[((size_t)(k / CW) * total + i) * CW + (k % CW)] = (T)v;
+    }
   }
 }
 template <typename T>
-void op_pack_input(const float* in, T* out, int n, int c, int h, int w, int r, int cpad, int fill_ch, float fill_val,
-                   hipStream_t st) {
+void op_pack_input(const float* in, T* out, int n, int c, int h, int w, int r, int nplanes, hipStream_t st) {
   hipLaunchKernelGGL((k_pack_input<T>), grid1d((size_t)n * (h / r) * (w / r)), dim3(256), 0, st, in, out, n, c, h, w,
-                     r, cpad, fill_ch, fill_val);
+                     r, nplanes);
 }
-// SRVGGNetCompact tail (realesrgan/factory.py:77-81): PixelShuffle(r) of an NHWC T tensor into fp32
-// planes plus the nearest-upsampled network input.
+template void op_pack_input<float>(const float*, float*, int, int, int, int, int, int, hipStream_t);
+template void op_pack_input<__half>(const float*, __half*, int, int, int, int, int, int, hipStream_t);
+
+// SRVGGNetCompact tail (realesrgan/factory.py:77-81): PixelShuffle(r) of a "planes" T tensor into
+// fp32 NCHW planes plus the nearest-upsampled network input.
 template <typename T>
-__global__ void k_ps_nchw_addbase(const T* __restrict__ src, int cs, float* __restrict__ out,
-                                  const float* __restrict__ base, int n, int h, int w, int r, int cq) {
+__global__ void k_ps_nchw_addbase(const T* __restrict__ src, float* __restrict__ out, const float* __restrict__ base,
+                                  int n, int h, int w, int r, int cq) {
+  constexpr int CW = 64 / sizeof(T);
   const int OH = h * r, OW = w * r;
-  const size_t total = (size_t)n * cq * OH * OW;
+  const size_t total = (size_t)n * cq * OH * OW, npix = (size_t)n * h * w;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int ox = i % OW, oy = (i / OW) % OH;
     const int c = (i / ((size_t)OW * OH)) % cq;
     const size_t img = i / ((size_t)OW * OH * cq);
     const int y = oy / r, x = ox / r, dy = oy - y * r, dx = ox - x * r;
-    const float v = (float)src[((img * h + y) * w + x) * cs + c * r * r + dy * r + dx];
+    const int ch = c * r * r + dy * r + dx;
+    const size_t pix = (img * h + y) * w + x;
+    const float v = (float)src[((size_t)(ch / CW) * npix + pix) * CW + (ch % CW)];
     out[i] = v + base[((img * cq + c) * h + y) * w + x];
   }
 }
 template <typename T>
-void op_ps_nchw_addbase(const T* src, int cs, float* out, const float* base, int n, int h, int w, int r, int cq,
-                        hipStream_t st) {
-  hipLaunchKernelGGL((k_ps_nchw_addbase<T>), grid1d((size_t)n * cq * h * r * w * r), dim3(256), 0, st, src, cs, out,
-                     base, n, h, w, r, cq);
+void op_ps_nchw_addbase(const T* src, float* out, const float* base, int n, int h, int w, int r, int cq, hipStream_t st) {
+  hipLaunchKernelGGL((k_ps_nchw_addbase<T>), grid1d((size_t)n * cq * h * r * w * r), dim3(256), 0, st, src, out, base,
+                     n, h, w, r, cq);
 }
-template void op_ps_nchw_addbase<float>(const float*, int, float*, const float*, int, int, int, int, int, hipStream_t);
-template void op_ps_nchw_addbase<__half>(const __half*, int, float*, const float*, int, int, int, int, int, hipStream_t);
-
-template void op_pack_input<float>(const float*, float*, int, int, int, int, int, int, int, float, hipStream_t);
-template void op_pack_input<__half>(const float*, __half*, int, int, int, int, int, int, int, float, hipStream_t);
+template void op_ps_nchw_addbase<float>(const float*, float*, const float*, int, int, int, int, int, hipStream_t);
+template void op_ps_nchw_addbase<__half>(const __half*, float*, const float*, int, int, int, int, int, hipStream_t);
 
 }  // namespace ss4k

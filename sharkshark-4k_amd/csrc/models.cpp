@@ -98,8 +98,7 @@ static void upload(DevBuf& b, const void* src, size_t bytes) {
   SS4K_HIP(hipMemcpy(b.ptr, src, bytes, hipMemcpyHostToDevice));
 }
 
-int Model::add_conv(ParamCursor& pc, int cout, int cin_total, const PackSpec& spec_in, bool has_prelu_after) {
-  PackSpec s = spec_in;
+int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool has_prelu_after) {
   s.dtype = desc.dtype; s.cout_real = cout; s.cin_total = cin_total;
   const float* w = pc.take((size_t)cout * cin_total * 9);
   const float* b = pc.take(cout);
@@ -110,20 +109,39 @@ int Model::add_conv(ParamCursor& pc, int cout, int cin_total, const PackSpec& sp
   upload(L.bias, p.bias.data(), p.bias.size() * 4);
   if (a) upload(L.prelu, p.prelu.data(), p.prelu.size() * 4);
   L.has_prelu = a != nullptr;
-  L.cout_real = cout; L.cout_pad = p.cout_pad; L.nchunks0 = p.nchunks0; L.nchunks1 = p.nchunks1;
-  L.cin_real = s.nch0_real + s.nch1_real;
-  L.nch0 = s.nch0; L.nch1 = s.nch1;
+  L.cout_real = cout; L.cout_pad = p.cout_pad; L.nchunks0 = s.nchunks0; L.nchunks1 = s.nchunks1;
+  L.cin_real = 0;
+  for (int c : s.cin_map) L.cin_real += c >= 0;
   weight_bytes += p.w.size() + p.bias.size() * 4;
   layers.push_back(std::move(L));
   return (int)layers.size() - 1;
 }
 
-static PackSpec spec1(int cin_real, int cin_pad, int cin_first = 0, int ps2 = 0) {
-  PackSpec s{}; s.nch0_real = cin_real; s.nch0 = cin_pad; s.nch1_real = 0; s.nch1 = 0; s.cin_first = cin_first; s.ps2 = ps2;
+// all of a tensor's channels, padded to whole planes
+PackSpec Model::spec_plain(int cin_real, int ps2) const {
+  PackSpec s{}; s.ps2 = ps2; s.nchunks0 = planes_for(cin_real); s.nchunks1 = 0;
+  s.cin_map.assign((size_t)s.nchunks0 * cw(), -1);
+  for (int j = 0; j < cin_real; ++j) s.cin_map[j] = j;
   return s;
 }
-static PackSpec spec2(int c0, int c1) {
-  PackSpec s{}; s.nch0_real = c0; s.nch0 = c0; s.nch1_real = c1; s.nch1 = c1; s.cin_first = 0; s.ps2 = 0;
+// torch.cat((x, growth[:c1]), 1): segment 0 = x (c0 channels), segment 1 = the growth planes
+PackSpec Model::spec_concat(int c0, int c1) const {
+  PackSpec s{}; s.nchunks0 = planes_for(c0); s.nchunks1 = planes_for(c1);
+  s.cin_map.assign((size_t)(s.nchunks0 + s.nchunks1) * cw(), -1);
+  for (int j = 0; j < c0; ++j) s.cin_map[j] = j;
+  for (int j = 0; j < c1; ++j) s.cin_map[(size_t)s.nchunks0 * cw() + j] = c0 + j;
+  return s;
+}
+// BiBufferConv fed one frame: input channels [0, c/4) are zeros (bsvd/model.py:50-52,108,123):
+// start at the first plane that holds a live channel and give the dead ones zero weights
+PackSpec Model::spec_masked(int c) const {
+  PackSpec s{}; const int first = (c / 4) / cw();
+  s.nchunks0 = planes_for(c) - first; s.nchunks1 = 0;
+  s.cin_map.assign((size_t)s.nchunks0 * cw(), -1);
+  for (int j = 0; j < s.nchunks0 * cw(); ++j) {
+    const int ch = first * cw() + j;
+    if (ch >= c / 4 && ch < c) s.cin_map[j] = ch;
+  }
   return s;
 }
 
@@ -170,32 +188,29 @@ void Model::build(const float* w, size_t n) {
   } else if (desc.kind == SS4K_RRDBNET) {
     const int nf = desc.num_feat, g = desc.num_grow_ch;
     const int cin0 = 3 * (desc.scale == 2 ? 4 : desc.scale == 1 ? 16 : 1);
-    add_conv(pc, nf, cin0, spec1(cin0, pad16(cin0)), false);
+    add_conv(pc, nf, cin0, spec_plain(cin0), false);
     for (int b = 0; b < desc.num_block; ++b)
       for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 5; ++c) {
           const int co = c < 4 ? g : nf;
-          add_conv(pc, co, nf + c * g, c == 0 ? spec1(nf, nf) : spec2(nf, c * g), false);
+          add_conv(pc, co, nf + c * g, c == 0 ? spec_plain(nf) : spec_concat(nf, c * g), false);
         }
-    for (int i = 0; i < 4; ++i) add_conv(pc, nf, nf, spec1(nf, nf), false);
-    add_conv(pc, 3, nf, spec1(nf, nf), false);
+    for (int i = 0; i < 4; ++i) add_conv(pc, nf, nf, spec_plain(nf), false);
+    add_conv(pc, 3, nf, spec_plain(nf), false);
   } else if (desc.kind == SS4K_SRVGG) {
     const int nf = desc.num_feat;
-    add_conv(pc, nf, 3, spec1(3, 16), true);
-    for (int i = 0; i < desc.num_block; ++i) add_conv(pc, nf, nf, spec1(nf, nf), true);
-    add_conv(pc, 3 * desc.scale * desc.scale, nf, spec1(nf, nf), false);
+    add_conv(pc, nf, 3, spec_plain(3), true);
+    for (int i = 0; i < desc.num_block; ++i) add_conv(pc, nf, nf, spec_plain(nf), true);
+    add_conv(pc, 3 * desc.scale * desc.scale, nf, spec_plain(nf), false);
   } else {  // BSVD
     for (int blk = 0; blk < 2; ++blk) {
       const int ci = blk == 0 ? 4 : desc.bsvd_mid_ch, co = blk == 0 ? desc.bsvd_mid_ch : 3;
       auto shapes = bsvd_denblock_shapes(desc.bsvd_chns, ci, co, desc.bsvd_interm_ch);
       for (size_t i = 0; i < shapes.size(); ++i) {
         const int cout = shapes[i].first, cin = shapes[i].second;
-        // BiBufferConv layers (memconv.c1/c2): with one frame the first cin/4 input channels are
-        // zeros (bsvd/model.py:50-52,108,123) -> skip them in K
         const bool masked = (i == 3 || i == 4 || i == 6 || i == 7 || i == 8 || i == 9 || i == 11 || i == 12);
         const bool ps2 = (i == 10 || i == 13);
-        if (masked) add_conv(pc, cout, cin, spec1(cin - cin / 4, cin - cin / 4, cin / 4, 0), false);
-        else add_conv(pc, cout, cin, spec1(cin, pad16(cin), 0, ps2 ? 1 : 0), false);
+        add_conv(pc, cout, cin, masked ? spec_masked(cin) : spec_plain(cin, ps2 ? 1 : 0), false);
       }
     }
   }
@@ -206,25 +221,30 @@ void Model::build(const float* w, size_t n) {
 void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, const ConvOpts& o, hipStream_t st) {
   const ConvLayer& L = layers[li];
   ConvArgs a{};
-  a.in0 = in0.p; a.cs0 = in0.cs; a.co0 = in0.co; a.nch0 = L.nch0;
-  if (in1) { a.in1 = in1->p; a.cs1 = in1->cs; a.co1 = in1->co; a.nch1 = L.nch1; }
+  a.in0 = in0.p; a.in0_plane_bytes = in0.plane_bytes; a.in0_plane0 = in0.plane0; a.nchunks0 = L.nchunks0;
+  if (in1) { a.in1 = in1->p; a.in1_plane_bytes = in1->plane_bytes; a.in1_plane0 = in1->plane0; a.nchunks1 = L.nchunks1; }
+  SS4K_REQUIRE((in1 != nullptr) == (L.nchunks1 > 0), "internal: conv segment mismatch");
   a.N = N; a.H = H; a.W = W; a.ups2 = o.ups2;
   a.wpk = L.w.ptr; a.bias = L.bias.as<float>(); a.prelu = L.has_prelu ? L.prelu.as<float>() : nullptr;
   a.act = o.act; a.slope = o.slope; a.alpha = o.alpha; a.gamma = o.gamma;
-  if (o.res1) { a.res1 = o.res1->p; a.r1cs = o.res1->cs; a.r1co = o.res1->co; }
-  if (o.res2) { a.res2 = o.res2->p; a.r2cs = o.res2->cs; a.r2co = o.res2->co; }
+  if (o.res1) { a.res1 = o.res1->p; a.r1_plane_bytes = o.res1->plane_bytes; a.r1_plane0 = o.res1->plane0; }
+  if (o.res2) { a.res2 = o.res2->p; a.r2_plane_bytes = o.res2->plane_bytes; a.r2_plane0 = o.res2->plane0; }
   a.bsvd_resid = o.bsvd_resid;
-  a.epi = o.epi; a.out = o.out.p; a.ocs = o.out.cs; a.oco = o.out.co;
-  a.cout_real = L.cout_real; a.cout_pad = L.cout_pad; a.cout_alloc = o.out.cs - o.out.co;
-  a.nchunks0 = L.nchunks0; a.nchunks1 = L.nchunks1;
+  a.epi = o.epi; a.out = o.out.p; a.out_plane_bytes = o.out.plane_bytes; a.out_plane0 = o.out.plane0;
+  a.cout_real = L.cout_real; a.cout_pad = L.cout_pad;
   a.flops = 2.0 * 9.0 * L.cin_real * L.cout_real * (double)N * H * W * (o.epi == EPI_NHWC_SUB2 ? 0.25 : 1.0);
   launch_conv3x3(ctx, a, desc.dtype, st);
 }
 
+// activation buffer idx holding `channels` channels (rounded up to whole 32-cout groups of planes,
+// which is what a producing conv writes) for `pixels` pixels
 Tens Model::act(int idx, size_t pixels, int channels) {
   if ((int)acts.size() <= idx) acts.resize(idx + 1);
-  acts[idx].ensure(pixels * channels * esz(desc.dtype));
-  return Tens{acts[idx].ptr, channels, 0};
+  const int ch32 = (channels + 31) / 32 * 32;
+  const int planes = planes_for(ch32);
+  SS4K_REQUIRE((double)pixels * 64.0 < 4294967296.0, "activation plane must stay below 4 GiB");
+  acts[idx].ensure((size_t)planes * pixels * 64);
+  return Tens{acts[idx].as<char>(), (uint32_t)(pixels * 64), 0};
 }
 
 void Model::out_shape(int n, int h, int w, int* oc, int* oh, int* ow) const {
@@ -240,9 +260,9 @@ int Model::in_channels() const {
   return desc.kind == SS4K_FSRCNN ? 1 : desc.kind == SS4K_BSVD ? 4 : 3;
 }
 
-template <typename T>
-void Model::pack_in(const float* in, const Tens& dst, int n, int c, int h, int w, int r, hipStream_t st) {
-  op_pack_input<T>(in, reinterpret_cast<T*>(dst.p), n, c, h, w, r, dst.cs, -1, 0.f, st);
+void Model::pack_in(const float* in, const Tens& dst, int nplanes, int n, int c, int h, int w, int r, hipStream_t st) {
+  if (desc.dtype == SS4K_F16) op_pack_input<__half>(in, reinterpret_cast<__half*>(dst.p), n, c, h, w, r, nplanes, st);
+  else op_pack_input<float>(in, reinterpret_cast<float*>(dst.p), n, c, h, w, r, nplanes, st);
 }
 
 void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_t st) {
@@ -255,9 +275,9 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
     fsrcnn_forward(ctx, fsw, desc.scale, in, out, n, h, w, acts[0].as<float>(), acts[1].as<float>(), acts[2].as<float>(), st);
     return;
   }
-  auto pack = [&](const Tens& dst, int c, int r) {
-    if (f16) pack_in<__half>(in, dst, n, c, h, w, r, st); else pack_in<float>(in, dst, n, c, h, w, r, st);
-  };
+  // plane index of channel c inside a tensor
+  auto plane_of = [&](const Tens& t, int channel) { return Tens{t.p, t.plane_bytes, t.plane0 + channel / cw()}; };
+  auto nchw_out = [&]() { return Tens{reinterpret_cast<char*>(out), 0, 0}; };
   if (desc.kind == SS4K_RRDBNET) {
     const int nf = desc.num_feat, g = desc.num_grow_ch;
     const int r = desc.scale == 2 ? 2 : desc.scale == 1 ? 4 : 1;
@@ -265,10 +285,10 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
     const int H = h / r, W = w / r;
     const size_t px = (size_t)n * H * W;
     const int cin0 = 3 * r * r;
-    Tens P = act(0, px, pad16(cin0));
+    Tens P = act(0, px, cin0);
     Tens F = act(1, px, nf), X[3] = {act(2, px, nf), act(3, px, nf), act(4, px, nf)};
     Tens G = act(5, px, 4 * g);
-    pack(P, 3, r);
+    pack_in(in, P, planes_for(cin0), n, 3, h, w, r, st);
     int li = 0;
     { ConvOpts o; o.out = F; conv(li++, P, nullptr, n, H, W, o, st); }
     Tens cur = F;
@@ -280,14 +300,12 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
       const Tens rout[3] = {t1, t2, dst};
       for (int rr = 0; rr < 3; ++rr) {
         for (int c = 0; c < 4; ++c) {
-          ConvOpts o; o.act = ACT_LRELU; o.slope = 0.2f; o.out = Tens{G.p, G.cs, c * g};
-          Tens gin = Tens{G.p, G.cs, 0};
-          conv(li++, rin[rr], c == 0 ? nullptr : &gin, n, H, W, o, st);
+          ConvOpts o; o.act = ACT_LRELU; o.slope = 0.2f; o.out = plane_of(G, c * g);
+          conv(li++, rin[rr], c == 0 ? nullptr : &G, n, H, W, o, st);
         }
         ConvOpts o; o.alpha = 0.2f; o.res1 = &rin[rr]; o.out = rout[rr];
         if (rr == 2) { o.gamma = 0.2f; o.res2 = &a; }
-        Tens gin = Tens{G.p, G.cs, 0};
-        conv(li++, rin[rr], &gin, n, H, W, o, st);
+        conv(li++, rin[rr], &G, n, H, W, o, st);
       }
       cur = dst;
     }
@@ -296,14 +314,14 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
     { ConvOpts o; o.ups2 = 1; o.act = ACT_LRELU; o.slope = 0.2f; o.out = U1; conv(li++, X[0], nullptr, n, 2 * H, 2 * W, o, st); }
     { ConvOpts o; o.ups2 = 1; o.act = ACT_LRELU; o.slope = 0.2f; o.out = U2; conv(li++, U1, nullptr, n, 4 * H, 4 * W, o, st); }
     { ConvOpts o; o.act = ACT_LRELU; o.slope = 0.2f; o.out = U3; conv(li++, U2, nullptr, n, 4 * H, 4 * W, o, st); }
-    { ConvOpts o; o.epi = EPI_NCHW_F32; o.out = Tens{out, 0, 0}; conv(li++, U3, nullptr, n, 4 * H, 4 * W, o, st); }
+    { ConvOpts o; o.epi = EPI_NCHW_F32; o.out = nchw_out(); conv(li++, U3, nullptr, n, 4 * H, 4 * W, o, st); }
     return;
   }
   if (desc.kind == SS4K_SRVGG) {
     const int nf = desc.num_feat;
     const size_t px = (size_t)n * h * w;
-    Tens P = act(0, px, 16), A = act(1, px, nf), B = act(2, px, nf);
-    pack(P, 3, 1);
+    Tens P = act(0, px, 3), A = act(1, px, nf), B = act(2, px, nf);
+    pack_in(in, P, planes_for(3), n, 3, h, w, 1, st);
     int li = 0;
     { ConvOpts o; o.act = ACT_PRELU; o.out = A; conv(li++, P, nullptr, n, h, w, o, st); }
     Tens cur = A, nxt = B;
@@ -311,11 +329,10 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
       ConvOpts o; o.act = ACT_PRELU; o.out = nxt; conv(li++, cur, nullptr, n, h, w, o, st);
       std::swap(cur, nxt);
     }
-    const int cz = layers[li].cout_pad;
-    Tens Z = act(3, px, cz);
+    Tens Z = act(3, px, layers[li].cout_pad);
     { ConvOpts o; o.out = Z; conv(li++, cur, nullptr, n, h, w, o, st); }
-    if (f16) op_ps_nchw_addbase<__half>(reinterpret_cast<const __half*>(Z.p), cz, out, in, n, h, w, desc.scale, 3, st);
-    else op_ps_nchw_addbase<float>(reinterpret_cast<const float*>(Z.p), cz, out, in, n, h, w, desc.scale, 3, st);
+    if (f16) op_ps_nchw_addbase<__half>(reinterpret_cast<const __half*>(Z.p), out, in, n, h, w, desc.scale, 3, st);
+    else op_ps_nchw_addbase<float>(reinterpret_cast<const float*>(Z.p), out, in, n, h, w, desc.scale, 3, st);
     return;
   }
   // ---- BSVD, one frame per call -----------------------------------------------------------
@@ -323,8 +340,8 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
   const int c0 = desc.bsvd_chns[0], c1 = desc.bsvd_chns[1], c2 = desc.bsvd_chns[2], mid = desc.bsvd_mid_ch;
   const size_t px = (size_t)n * h * w, px2 = px / 4, px4 = px / 16;
   const int h2 = h / 2, w2 = w / 2, h4 = h / 4, w4 = w / 4;
-  Tens IN0 = act(0, px, 16), MID = act(1, px, mid);
-  pack(IN0, 4, 1);
+  Tens IN0 = act(0, px, 4), MID = act(1, px, mid);
+  pack_in(in, IN0, planes_for(4), n, 4, h, w, 1, st);
   int li = 0;
   for (int blk = 0; blk < 2; ++blk) {
     const Tens IN = blk == 0 ? IN0 : MID;
@@ -333,24 +350,25 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
     Tens D1 = act(7, px4, c2), Mb = act(8, px4, c2), X2 = act(9, px4, c2), Mc = act(10, px4, c2);
     Tens S1 = act(11, px2, c1), S0 = act(12, px, c0), O0 = act(13, px, c0);
     auto relu6 = [&](Tens outT) { ConvOpts o; o.act = ACT_RELU6; o.out = outT; return o; };
-    auto masked = [&](const Tens& t) { return Tens{t.p, t.cs, t.cs / 4}; };
+    // masked conv input: skip the planes that only hold dead channels (see spec_masked)
+    auto masked = [&](const Tens& t, int c) { return Tens{t.p, t.plane_bytes, t.plane0 + (c / 4) / cw()}; };
     conv(li++, IN, nullptr, n, h, w, relu6(I0), st);                                   // inc.convblock.0
     conv(li++, I0, nullptr, n, h, w, relu6(X0), st);                                   // inc.convblock.3
     { ConvOpts o = relu6(D0); o.epi = EPI_NHWC_SUB2; conv(li++, X0, nullptr, n, h, w, o, st); }   // downc0 stride 2
-    conv(li++, masked(D0), nullptr, n, h2, w2, relu6(Ma), st);
-    conv(li++, masked(Ma), nullptr, n, h2, w2, relu6(X1), st);
+    conv(li++, masked(D0, c1), nullptr, n, h2, w2, relu6(Ma), st);
+    conv(li++, masked(Ma, c1), nullptr, n, h2, w2, relu6(X1), st);
     { ConvOpts o = relu6(D1); o.epi = EPI_NHWC_SUB2; conv(li++, X1, nullptr, n, h2, w2, o, st); } // downc1 stride 2
-    conv(li++, masked(D1), nullptr, n, h4, w4, relu6(Mb), st);
-    conv(li++, masked(Mb), nullptr, n, h4, w4, relu6(X2), st);
-    conv(li++, masked(X2), nullptr, n, h4, w4, relu6(Mc), st);                         // upc2.memconv
-    conv(li++, masked(Mc), nullptr, n, h4, w4, relu6(Mb), st);
+    conv(li++, masked(D1, c2), nullptr, n, h4, w4, relu6(Mb), st);
+    conv(li++, masked(Mb, c2), nullptr, n, h4, w4, relu6(X2), st);
+    conv(li++, masked(X2, c2), nullptr, n, h4, w4, relu6(Mc), st);                     // upc2.memconv
+    conv(li++, masked(Mc, c2), nullptr, n, h4, w4, relu6(Mb), st);
     { ConvOpts o; o.epi = EPI_NHWC_PS2; o.res1 = &X1; o.out = S1; conv(li++, Mb, nullptr, n, h4, w4, o, st); }  // PixelShuffle + skip3
-    conv(li++, masked(S1), nullptr, n, h2, w2, relu6(Ma), st);                         // upc1.memconv
-    conv(li++, masked(Ma), nullptr, n, h2, w2, relu6(D0), st);
+    conv(li++, masked(S1, c1), nullptr, n, h2, w2, relu6(Ma), st);                     // upc1.memconv
+    conv(li++, masked(Ma, c1), nullptr, n, h2, w2, relu6(D0), st);
     { ConvOpts o; o.epi = EPI_NHWC_PS2; o.res1 = &X0; o.out = S0; conv(li++, D0, nullptr, n, h2, w2, o, st); }  // PixelShuffle + skip2
     conv(li++, S0, nullptr, n, h, w, relu6(O0), st);                                   // outc.convblock.0
     { ConvOpts o; o.res1 = &IN; o.bsvd_resid = 1;
-      if (blk == 0) { o.out = MID; } else { o.epi = EPI_NCHW_F32; o.out = Tens{out, 0, 0}; }
+      if (blk == 0) { o.out = MID; } else { o.epi = EPI_NCHW_F32; o.out = nchw_out(); }
       conv(li++, O0, nullptr, n, h, w, o, st); }                                       // outc.convblock.3 + residual
   }
 }

@@ -5,12 +5,13 @@
 
 namespace ss4k {
 
-struct Tens { void* p; int cs; int co; };  // NHWC activation view: base, channels per pixel, channel offset
+// activation view in the "planes" layout (conv_mfma.hip): base, bytes per plane (N*H*W*64), first plane
+struct Tens { char* p; uint32_t plane_bytes; int plane0; };
 
 struct ConvLayer {
   DevBuf w, bias, prelu;
   bool has_prelu = false;
-  int cout_real = 0, cout_pad = 0, cin_real = 0, nch0 = 0, nch1 = 0, nchunks0 = 0, nchunks1 = 0;
+  int cout_real = 0, cout_pad = 0, cin_real = 0, nchunks0 = 0, nchunks1 = 0;
 };
 
 struct ConvOpts {
@@ -45,10 +46,15 @@ struct Model {
   }
 
  private:
-  int add_conv(ParamCursor& pc, int cout, int cin_total, const PackSpec& spec, bool has_prelu_after);
+  int add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec spec, bool has_prelu_after);
+  PackSpec spec_plain(int cin_real, int ps2 = 0) const;
+  PackSpec spec_concat(int c0, int c1) const;
+  PackSpec spec_masked(int c) const;
+  int cw() const { return conv_cw(desc.dtype); }
+  int planes_for(int channels) const { return (channels + cw() - 1) / cw(); }
   void conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, const ConvOpts& o, hipStream_t st);
   Tens act(int idx, size_t pixels, int channels);
-  template <typename T> void pack_in(const float* in, const Tens& dst, int n, int c, int h, int w, int r, hipStream_t st);
+  void pack_in(const float* in, const Tens& dst, int nplanes, int n, int c, int h, int w, int r, hipStream_t st);
 };
 
 }  // namespace ss4k

@@ -1,5 +1,9 @@
 // Host-side repacking of PyTorch OIHW conv weights into the MFMA fragment order the conv kernel
-// streams straight into LDS (see conv_mfma.hip).  Pure host code: no HIP calls.
+// DMAs straight into LDS (see conv_mfma.hip).  Pure host code: no HIP calls.
+//
+// Packed order: [group][chunk][dx(3) x ks(2)][dy(3)][nb][lane(64)][E]
+//   lane l: MFMA row rho = l & 31 (-> output channel, permuted so a lane of the result holds 16
+//   contiguous channels), k half hk = l >> 5; element e: channel (2*ks + hk) * E + e of the chunk.
 #include "common.h"
 #include <cmath>
 
@@ -28,7 +32,7 @@ static inline uint16_t f32_to_f16_bits(float f) {
   return (uint16_t)(sign | h);
 }
 
-int virt_to_real_cout(const PackSpec& s, int v, int /*cout_pad*/) {
+int virt_to_real_cout(const PackSpec& s, int v) {
   if (v >= s.cout_real) return -1;
   if (s.ps2) {
     const int cp = s.cout_real / 4, sub = v / cp, c = v - sub * cp;
@@ -38,50 +42,42 @@ int virt_to_real_cout(const PackSpec& s, int v, int /*cout_pad*/) {
 }
 
 PackedConv pack_conv3x3(const PackSpec& s, const float* w, const float* bias, const float* prelu) {
-  const int E = s.dtype == SS4K_F16 ? 8 : 4, KC = 4 * E;
+  const int E = s.dtype == SS4K_F16 ? 8 : 4, CW = 4 * E;
+  const int nchunks = s.nchunks0 + s.nchunks1;
+  SS4K_REQUIRE((int)s.cin_map.size() == nchunks * CW, "pack_conv3x3: cin_map size");
   PackedConv p;
   p.nb = s.cout_real <= 32 ? 1 : 2;
   const int gw = p.nb * 32;
   p.cout_pad = (s.cout_real + gw - 1) / gw * gw;
   p.groups = p.cout_pad / gw;
-  p.nchunks0 = (s.nch0 + KC - 1) / KC;
-  p.nchunks1 = (s.nch1 + KC - 1) / KC;
-  const int nchunks = p.nchunks0 + p.nchunks1;
   const size_t esz = s.dtype == SS4K_F16 ? 2 : 4;
-  const size_t nelem = (size_t)p.groups * nchunks * 9 * 2 * p.nb * 64 * E;
+  const size_t nelem = (size_t)p.groups * nchunks * 18 * p.nb * 64 * E;
   p.w.assign(nelem * esz, 0);
   p.bias.assign(p.cout_pad, 0.f);
   p.prelu.assign(p.cout_pad, 0.f);
   for (int v = 0; v < p.cout_pad; ++v) {
-    const int co = virt_to_real_cout(s, v, p.cout_pad);
+    const int co = virt_to_real_cout(s, v);
     if (co >= 0) { p.bias[v] = bias ? bias[co] : 0.f; p.prelu[v] = prelu ? prelu[co] : 0.f; }
   }
   size_t idx = 0;
   for (int g = 0; g < p.groups; ++g)
     for (int c = 0; c < nchunks; ++c)
-      for (int tap = 0; tap < 9; ++tap)
+      for (int dx = 0; dx < 3; ++dx)
         for (int ks = 0; ks < 2; ++ks)
-          for (int nb = 0; nb < p.nb; ++nb)
-            for (int lane = 0; lane < 64; ++lane) {
-              const int rho = lane & 31, hk = lane >> 5;
-              const int v = (g * p.nb + nb) * 32 + 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);
-              const int co = virt_to_real_cout(s, v, p.cout_pad);
-              for (int e = 0; e < E; ++e, ++idx) {
-                const int k = (2 * ks + hk) * E + e;
-                int ci = -1;
-                if (c < p.nchunks0) {
-                  const int kk = c * KC + k;
-                  if (kk < s.nch0_real) ci = s.cin_first + kk;
-                } else {
-                  const int kk = (c - p.nchunks0) * KC + k;
-                  if (kk < s.nch1_real) ci = s.cin_first + s.nch0_real + kk;
+          for (int dy = 0; dy < 3; ++dy)
+            for (int nb = 0; nb < p.nb; ++nb)
+              for (int lane = 0; lane < 64; ++lane) {
+                const int rho = lane & 31, hk = lane >> 5;
+                const int v = (g * p.nb + nb) * 32 + 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);
+                const int co = virt_to_real_cout(s, v);
+                for (int e = 0; e < E; ++e, ++idx) {
+                  const int ci = s.cin_map[(size_t)c * CW + (2 * ks + hk) * E + e];
+                  float val = 0.f;
+                  if (ci >= 0 && co >= 0) val = w[((size_t)co * s.cin_total + ci) * 9 + dy * 3 + dx];
+                  if (esz == 2) { const uint16_t h = f32_to_f16_bits(val); std::memcpy(&p.w[idx * 2], &h, 2); }
+                  else std::memcpy(&p.w[idx * 4], &val, 4);
                 }
-                float val = 0.f;
-                if (ci >= 0 && co >= 0) val = w[((size_t)co * s.cin_total + ci) * 9 + tap];
-                if (esz == 2) { const uint16_t h = f32_to_f16_bits(val); std::memcpy(&p.w[idx * 2], &h, 2); }
-                else std::memcpy(&p.w[idx * 4], &val, 4);
               }
-            }
   return p;
 }
 
