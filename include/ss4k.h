@@ -153,6 +153,11 @@ int ss4k_op_f32nchw_to_u8nhwc(ss4k_ctx* ctx, const float* in_dev, uint8_t* out_d
 /* ---- measurement hooks (bench.py: live per-kernel timing with HIP events on the launch stream) */
 /* When enabled, every launch of the dominant conv kernel is bracketed with hipEvents on the
  * stream it is launched on; ss4k_prof_read returns (#launches, total ms, algorithmic FLOPs). */
+/* Times ONE 3x3 conv layer (cin0 [+ cin1 concat] -> cout, LeakyReLU) in isolation on synthetic data:
+ * avg microseconds per launch over `iters` launches.  flags = ablation bits (1 no store, 2 no MFMA,
+ * 4 no activation DMA, 8 no weight DMA, 16 no epilogue); 0 = the production kernel. */
+int ss4k_bench_conv(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, int n, int h, int w, int flags,
+                    int iters, double* avg_us, void* hip_stream);
 int ss4k_prof_enable(ss4k_ctx* ctx, int enable);
 int ss4k_prof_reset(ss4k_ctx* ctx);
 int ss4k_prof_read(ss4k_ctx* ctx, int64_t* launches, double* total_ms, double* flops);

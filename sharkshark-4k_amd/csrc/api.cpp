@@ -338,6 +338,14 @@ int ss4k_op_f32nchw_to_u8nhwc(ss4k_ctx* c, const float* in, uint8_t* out, int n,
   return guard([&] { SS4K_REQUIRE(c && in && out, "NULL argument"); op_f32nchw_to_u8nhwc(in, out, n, ch, h, w, (hipStream_t)s); SS4K_HIP(hipGetLastError()); });
 }
 
+int ss4k_bench_conv(ss4k_ctx* c, int dtype, int cin0, int cin1, int cout, int n, int h, int w, int flags, int iters,
+                    double* avg_us, void* stream) {
+  return guard([&] {
+    SS4K_REQUIRE(c && avg_us && iters > 0, "bad argument");
+    *avg_us = bench_conv_layer(c, dtype, cin0, cin1, cout, n, h, w, flags, iters, (hipStream_t)stream);
+  });
+}
+
 // ---- profiling hooks --------------------------------------------------------------------------
 static void prof_collect(ss4k_ctx* c) {
   for (auto& e : c->prof_events) {

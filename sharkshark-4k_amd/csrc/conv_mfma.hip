@@ -46,10 +46,20 @@ template <> struct Tr<float> { static constexpr int E = 4, CW = 16; };
 
 int conv_cw(int dtype) { return dtype == SS4K_F16 ? 32 : 16; }
 
-__device__ __forceinline__ void dma16(const void* g, void* lds_wave_uniform) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds_wave_uniform, 16, 0, 0);
+// One wave-level LDS-DMA: every lane moves 16 bytes from ITS global address to LDS byte
+// lds_addr + 16*lane.  Written as inline asm so hipcc does not count it: the compiler would
+// otherwise put s_waitcnt vmcnt(0) in front of the first ds_read that follows (it cannot prove the
+// DMA target and the buffer being read are different halves of the one LDS array), which serialises
+// the prefetch with the MFMAs.  Completion is awaited explicitly (dma_wait) before the barrier that
+// hands the buffer to the readers.
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_addr_wave_uniform) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr_wave_uniform)
+               : "memory");
 }
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <typename T> __device__ __forceinline__ void load16(const char* p, float* v);
 template <> __device__ __forceinline__ void load16<__half>(const char* p, float* v) {
@@ -96,13 +106,15 @@ __device__ __forceinline__ f32x16 mma(const uint4& w, const uint4& x, f32x16 acc
   }
 }
 
-template <typename T, int NB>
+template <typename T, int NB, int DBG>
 __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) {
   constexpr int CW = Tr<T>::CW;
   constexpr int WSLOTS = 18 * NB * 64;  // weight slots per chunk
+  constexpr int RV = (int)(16 * sizeof(T) / 16);  // uint4 per 16-channel group
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [tile buf 0][tile buf 1][weights buf 0][weights buf 1]
   constexpr int TILE_BYTES = TILE_BUF_SLOTS * 16, W_BYTES = WSLOTS * 16;
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,7 +125,19 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
   const char* wbase = reinterpret_cast<const char*>(a.wpk) + (size_t)grp * nchunks * W_BYTES;
   const int Hs = a.ups2 ? (a.H >> 1) : a.H, Ws = a.ups2 ? (a.W >> 1) : a.W;
 
-  // per-lane read bases: slot = pixel*4 + ((2ks+lh) ^ ((x>>2)&3)), x = lr+dx; rows are immediates
+  // XCD-aware persistent tile walk: workgroups b and b+8 share an XCD (and its L2); give each XCD
+  // a contiguous band of tiles so halo rows and the planes a layer just wrote are re-read from
+  // the same L2.  Placement only changes speed, never results.
+  const bool banded = (gridDim.x % 8 == 0) && ntiles >= (int)gridDim.x;
+  const int tpx = (ntiles + 7) / 8;
+  auto tile_of = [&](int k) -> int {
+    if (!banded) { const int t = blockIdx.x + k * gridDim.x; return t < ntiles ? t : -1; }
+    const int j = (blockIdx.x >> 3) + k * (gridDim.x >> 3);
+    const int t = (blockIdx.x & 7) * tpx + j;
+    return (j < tpx && t < ntiles) ? t : -1;
+  };
+
+  // per-lane operand read base (bytes): slot = pixel*4 + ((2ks+lh) ^ ((x>>2)&3)), x = lr+dx
   int rd_base[3][2];
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx)
@@ -123,6 +147,16 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
       rd_base[dx][ks] = (((wave * MB) * IN_W + x) * 4 + ((2 * ks + lh) ^ ((x >> 2) & 3))) * 16;
     }
 
+  // tile-independent part of the DMA plan: LDS slot s = 64k + lane holds pixel (row, x), source
+  // channel group gq ^ swz(x)
+  int plan[DMA_PER_WAVE];  // row | x << 8 | group*16 << 16 | valid << 31
+#pragma unroll
+  for (int j = 0; j < DMA_PER_WAVE; ++j) {
+    const int s = (wave + 4 * j) * 64 + lane;
+    const int p = s >> 2, gq = s & 3;
+    const int row = p / IN_W, x = p - row * IN_W;
+    plan[j] = (s < TILE_SLOTS) ? (row | (x << 8) | (((gq ^ ((x >> 2) & 3)) * 16) << 16)) : -1;
+  }
   uint32_t src_off[DMA_PER_WAVE];
   auto setup_tile = [&](int tile, int& n, int& y0, int& x0) {
     const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
@@ -130,45 +164,68 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
     n = tyn / a.tiles_y; y0 = ty * TH; x0 = tx * TW;
 #pragma unroll
     for (int j = 0; j < DMA_PER_WAVE; ++j) {
-      const int s = (wave + 4 * j) * 64 + lane;
-      const int p = s >> 2, gq = s & 3;
-      const int row = p / IN_W, x = p - row * IN_W;
-      const int iy = y0 - 1 + row, ix = x0 - 1 + x;
-      const bool ok = (s < TILE_SLOTS) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const int iy = y0 - 1 + (plan[j] & 0xff), ix = x0 - 1 + ((plan[j] >> 8) & 0xff);
+      const bool ok = plan[j] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
       const int sy = a.ups2 ? (iy >> 1) : iy, sx = a.ups2 ? (ix >> 1) : ix;
-      const uint32_t pixel = (uint32_t)((n * Hs + sy) * Ws + sx);
-      src_off[j] = ok ? pixel * 64u + (uint32_t)((gq ^ ((x >> 2) & 3)) * 16) : OOB;
+      src_off[j] = ok ? (uint32_t)((n * Hs + sy) * Ws + sx) * 64u + (uint32_t)((plan[j] >> 16) & 0xff) : OOB;
     }
   };
   auto issue = [&](int c, int buf) {
     const char* plane = (c < a.nchunks0)
                             ? a.in0 + (size_t)(a.in0_plane0 + c) * a.in0_plane_bytes
                             : a.in1 + (size_t)(a.in1_plane0 + c - a.nchunks0) * a.in1_plane_bytes;
-    char* tdst = smem + buf * TILE_BYTES;
+    const uint32_t tdst = lds0 + buf * TILE_BYTES;
 #pragma unroll
     for (int j = 0; j < DMA_PER_WAVE; ++j) {
       const int k = wave + 4 * j;
-      if (k < TILE_DMA) {
+      if (k < TILE_DMA && !(DBG & DBG_NO_TILE_DMA)) {
         const char* src = src_off[j] != OOB ? plane + src_off[j] : a.zero_page + (lane & 3) * 16;
-        dma16(src, tdst + k * 1024);
+        dma16(src, __builtin_amdgcn_readfirstlane(tdst + k * 1024));
       }
     }
     const char* wsrc = wbase + (size_t)c * W_BYTES + lane * 16;
-    char* wdst = smem + 2 * TILE_BYTES + buf * W_BYTES;
+    const uint32_t wdst = lds0 + 2 * TILE_BYTES + buf * W_BYTES;
 #pragma unroll
     for (int j = 0; j < (18 * NB + 3) / 4; ++j) {
       const int k = wave + 4 * j;
-      if (k < 18 * NB) dma16(wsrc + k * 1024, wdst + k * 1024);
+      if (k < 18 * NB && !(DBG & DBG_NO_W_DMA)) dma16(wsrc + k * 1024, __builtin_amdgcn_readfirstlane(wdst + k * 1024));
     }
   };
 
-  int tile = blockIdx.x;
-  if (tile >= ntiles) return;
+  // epilogue constants that do not depend on the tile (bias, negative slope per channel) live in LDS
+  float* epi_lds = reinterpret_cast<float*>(smem + 2 * TILE_BYTES + 2 * W_BYTES);  // [NB*32][2]
+  if (tid < NB * 32) {
+    const int v = grp * NB * 32 + tid;
+    epi_lds[tid] = v < a.cout_pad ? a.bias[v] : 0.f;
+    epi_lds[NB * 32 + tid] = (a.act == ACT_PRELU && v < a.cout_pad) ? a.prelu[v] : a.slope;
+  }
+
+  // DBG_STAMP build only: per-phase cycle totals of wave 0 (s_memtime), written once at the end
+  unsigned long long st_dma = 0, st_mma = 0, st_epi = 0, st_bar = 0, st_t = 0, st_store = 0;
+  auto stamp = [&]() -> unsigned long long {
+    if constexpr ((DBG & DBG_STAMP) != 0) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      return t;
+    } else {
+      return 0ull;
+    }
+  };
+  const unsigned long long st_begin = stamp();
+
+  int kt = 0;
+  int tile = tile_of(0);
+  if (tile < 0) return;
   int n, y0, x0;
   setup_tile(tile, n, y0, x0);
   issue(0, 0);
+  dma_wait();
   __syncthreads();
   int buf = 0;
+
+  struct Frags { uint4 wf[3][NB]; uint4 af[MB + 2]; };
 
   while (true) {
     f32x16 acc[NB][MB];
@@ -180,67 +237,123 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
         for (int i = 0; i < 16; ++i) acc[nb][mb][i] = 0.f;
 
     const int cur_n = n, cur_y0 = y0, cur_x0 = x0;
-    const int next_tile = tile + gridDim.x;
+    const int next_tile = tile_of(kt + 1);
+    const int xo = cur_x0 + lr;
+
     for (int c = 0; c < nchunks; ++c) {
+      st_t = stamp();
       // put the next K-chunk (or the next tile's first chunk) in flight into the other buffer
       if (c + 1 < nchunks) {
         issue(c + 1, buf ^ 1);
-      } else if (next_tile < ntiles) {
-        setup_tile(next_tile, n, y0, x0);
-        issue(0, buf ^ 1);
-      }
-      const char* tb = smem + buf * TILE_BYTES;
-      const char* wb = smem + 2 * TILE_BYTES + buf * W_BYTES + lane * 16;
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          uint4 wf[3][NB];
-#pragma unroll
-          for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-              wf[dy][nb] = *reinterpret_cast<const uint4*>(wb + ((((dx * 2 + ks) * 3 + dy) * NB + nb) * 64) * 16);
-#pragma unroll
-          for (int ir = 0; ir < MB + 2; ++ir) {
-            const uint4 af = *reinterpret_cast<const uint4*>(tb + rd_base[dx][ks] + ir * IN_W * 64);
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-              const int mb = ir - dy;
-              if (mb >= 0 && mb < MB) {
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nb][mb] = mma<T>(wf[dy][nb], af, acc[nb][mb]);
-              }
-            }
-          }
+      } else {
+        if (next_tile >= 0) {
+          setup_tile(next_tile, n, y0, x0);
+          issue(0, buf ^ 1);
         }
       }
+      { const unsigned long long t = stamp(); st_dma += t - st_t; st_t = t; }
+      const char* tb = smem + buf * TILE_BYTES;
+      const char* wb = smem + 2 * TILE_BYTES + buf * W_BYTES + lane * 16;
+      auto load_group = [&](Frags& f, int g) {
+        const int dx = g >> 1, ks = g & 1;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            f.wf[dy][nb] = *reinterpret_cast<const uint4*>(wb + (((g * 3 + dy) * NB + nb) * 64) * 16);
+#pragma unroll
+        for (int ir = 0; ir < MB + 2; ++ir)
+          f.af[ir] = *reinterpret_cast<const uint4*>(tb + rd_base[dx][ks] + ir * IN_W * 64);
+      };
+      auto mma_group = [&](const Frags& f) {
+#pragma unroll
+        for (int ir = 0; ir < MB + 2; ++ir)
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const int mb = ir - dy;
+            if (mb >= 0 && mb < MB) {
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb) acc[nb][mb] = mma<T>(f.wf[dy][nb], f.af[ir], acc[nb][mb]);
+            }
+          }
+      };
+      if constexpr (!(DBG & DBG_NO_MMA)) {
+        // software pipeline over the six (dx, k-step) groups: the LDS reads of group g+1 are in
+        // flight while the 12*NB MFMAs of group g issue (one wave per SIMD: nobody else hides them)
+        Frags fa, fb;
+        load_group(fa, 0);
+#pragma unroll
+        for (int g = 0; g < 6; g += 2) {
+          load_group(fb, g + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_group(fa);
+          __builtin_amdgcn_sched_barrier(0);
+          if (g + 2 < 6) load_group(fa, g + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_group(fb);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      { const unsigned long long t = stamp(); st_mma += t - st_t; st_t = t; }
       if (c + 1 < nchunks) {
-        __syncthreads();  // next chunk landed (vmcnt(0)) and everyone is done reading this buffer
+        dma_wait();       // next chunk has landed in the other buffer
+        __syncthreads();  // and every wave is done reading this one
         buf ^= 1;
+        { const unsigned long long t = stamp(); st_bar += t - st_t; st_t = t; }
       }
     }
 
     // ---------------- epilogue: bias, activation, residuals, layout-aware store ----------------
-    const int x = cur_x0 + lr;
+    // The RRDB output is written in place over res2, so the compiler cannot hoist residual loads
+    // past the stores: per 32-channel block issue every row's residual loads first, then consume
+    // (one memory round trip per block instead of one per row).
+    const bool batch_res = a.epi == EPI_NHWC && !a.bsvd_resid && (a.res1 || a.res2);
+    if constexpr (!(DBG & DBG_NO_EPILOGUE))
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const int y = cur_y0 + wave * MB + mb;
-      if (y < a.H && x < a.W) {
-        const size_t ipix = ((size_t)cur_n * a.H + y) * a.W + x;
+    for (int nb = 0; nb < NB; ++nb) {
+      const int vbase = (grp * NB + nb) * 32 + 16 * lh;
+      if (vbase >= a.cout_pad) continue;
+      float bias_v[16], slope_v[16];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          const int vbase = (grp * NB + nb) * 32 + 16 * lh;
-          if (vbase >= a.cout_pad) continue;
+      for (int q = 0; q < 4; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4*>(epi_lds + nb * 32 + 16 * lh + 4 * q);
+        const float4 s4 = *reinterpret_cast<const float4*>(epi_lds + NB * 32 + nb * 32 + 16 * lh + 4 * q);
+        bias_v[4 * q] = b4.x; bias_v[4 * q + 1] = b4.y; bias_v[4 * q + 2] = b4.z; bias_v[4 * q + 3] = b4.w;
+        slope_v[4 * q] = s4.x; slope_v[4 * q + 1] = s4.y; slope_v[4 * q + 2] = s4.z; slope_v[4 * q + 3] = s4.w;
+      }
+      uint4 r1v[MB][RV], r2v[MB][RV];
+      if (batch_res) {
+        const int opl = vbase / CW;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const int y = cur_y0 + wave * MB + mb;
+          const bool ok = y < a.H && xo < a.W;
+          const size_t ipix = ((size_t)cur_n * a.H + min(y, a.H - 1)) * a.W + min(xo, a.W - 1);
+          const size_t orec = ipix * 64 + (size_t)(vbase - opl * CW) * sizeof(T);
+#pragma unroll
+          for (int q = 0; q < RV; ++q) {
+            r1v[mb][q] = (a.res1 && ok) ? *reinterpret_cast<const uint4*>(a.res1 + (size_t)(a.r1_plane0 + opl) * a.r1_plane_bytes + orec + 16 * q)
+                                        : make_uint4(0, 0, 0, 0);
+            r2v[mb][q] = (a.res2 && ok) ? *reinterpret_cast<const uint4*>(a.res2 + (size_t)(a.r2_plane0 + opl) * a.r2_plane_bytes + orec + 16 * q)
+                                        : make_uint4(0, 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int y = cur_y0 + wave * MB + mb;
+        if (y < a.H && xo < a.W) {
+          const size_t ipix = ((size_t)cur_n * a.H + y) * a.W + xo;
           float v[16];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) v[i] = acc[nb][mb][i] + a.bias[vbase + i];
-          if (a.act == ACT_LRELU) {
+          for (int i = 0; i < 16; ++i) v[i] = acc[nb][mb][i] + bias_v[i];
+          if (a.act == ACT_LRELU || a.act == ACT_PRELU) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = v[i] >= 0.f ? v[i] : v[i] * a.slope;
-          } else if (a.act == ACT_PRELU) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = v[i] >= 0.f ? v[i] : v[i] * a.prelu[vbase + i];
+            for (int i = 0; i < 16; ++i) {
+              const float neg = v[i] * slope_v[i];  // unconditional: a select, not a branch per element
+              v[i] = v[i] >= 0.f ? v[i] : neg;
+            }
           } else if (a.act == ACT_RELU6) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = fminf(fmaxf(v[i], 0.f), 6.f);
@@ -248,74 +361,117 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
           // where this 16-channel group lands
           size_t opix = ipix; int oc = vbase; bool keep = true;
           if (a.epi == EPI_NHWC_SUB2) {
-            keep = !((y | x) & 1);
-            opix = ((size_t)cur_n * ((a.H + 1) >> 1) + (y >> 1)) * ((a.W + 1) >> 1) + (x >> 1);
+            keep = !((y | xo) & 1);
+            opix = ((size_t)cur_n * ((a.H + 1) >> 1) + (y >> 1)) * ((a.W + 1) >> 1) + (xo >> 1);
           } else if (a.epi == EPI_NHWC_PS2) {
             const int cp = a.cout_real >> 2, sub = vbase / cp;
             oc = vbase - sub * cp;
-            opix = ((size_t)cur_n * 2 * a.H + 2 * y + (sub >> 1)) * (2 * a.W) + 2 * x + (sub & 1);
+            opix = ((size_t)cur_n * 2 * a.H + 2 * y + (sub >> 1)) * (2 * a.W) + 2 * xo + (sub & 1);
             keep = vbase < a.cout_real;
           }
-          if (!keep) continue;
-          if (a.alpha != 1.f) {
+          if (keep) {
+            if (a.alpha != 1.f) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] *= a.alpha;
-          }
-          const int opl = oc / CW;
-          const size_t orec = opix * 64 + (size_t)(oc - opl * CW) * sizeof(T);
-          if (a.res1 && (!a.bsvd_resid || vbase == 0)) {
-            float r[16];
-            const size_t rrec = (a.epi <= EPI_NHWC_PS2) ? orec : ipix * 64;
-            load16<T>(a.res1 + (size_t)(a.r1_plane0 + opl) * a.r1_plane_bytes + rrec, r);
-            if (a.bsvd_resid) {
-#pragma unroll
-              for (int i = 0; i < 3; ++i) v[i] = r[i] - v[i];
-            } else {
-#pragma unroll
-              for (int i = 0; i < 16; ++i) v[i] += r[i];
+              for (int i = 0; i < 16; ++i) v[i] *= a.alpha;
             }
-          }
-          if (a.res2) {
-            float r[16];
-            load16<T>(a.res2 + (size_t)(a.r2_plane0 + opl) * a.r2_plane_bytes + orec, r);
+            const int opl = oc / CW;
+            const size_t orec = opix * 64 + (size_t)(oc - opl * CW) * sizeof(T);
+            if (batch_res) {
+              if (a.res1) {
+                float r[16];
+                load16<T>(reinterpret_cast<const char*>(&r1v[mb][0]), r);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = v[i] * a.gamma + r[i];
-          }
-          if (a.epi <= EPI_NHWC_PS2) {
-            store16<T>(a.out + (size_t)(a.out_plane0 + opl) * a.out_plane_bytes + orec, v);
-          } else {  // EPI_NCHW_F32
-            float* o = reinterpret_cast<float*>(a.out);
-            const size_t plane = (size_t)a.H * a.W;
+                for (int i = 0; i < 16; ++i) v[i] += r[i];
+              }
+              if (a.res2) {
+                float r[16];
+                load16<T>(reinterpret_cast<const char*>(&r2v[mb][0]), r);
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-              if (vbase + i < a.cout_real)
-                o[((size_t)cur_n * a.cout_real + vbase + i) * plane + (size_t)y * a.W + x] = v[i];
+                for (int i = 0; i < 16; ++i) v[i] = v[i] * a.gamma + r[i];
+              }
+            } else {
+              if (a.res1 && (!a.bsvd_resid || vbase == 0)) {
+                float r[16];
+                const size_t rrec = (a.epi <= EPI_NHWC_PS2) ? orec : ipix * 64;
+                load16<T>(a.res1 + (size_t)(a.r1_plane0 + opl) * a.r1_plane_bytes + rrec, r);
+                if (a.bsvd_resid) {
+#pragma unroll
+                  for (int i = 0; i < 3; ++i) v[i] = r[i] - v[i];
+                } else {
+#pragma unroll
+                  for (int i = 0; i < 16; ++i) v[i] += r[i];
+                }
+              }
+              if (a.res2) {
+                float r[16];
+                load16<T>(a.res2 + (size_t)(a.r2_plane0 + opl) * a.r2_plane_bytes + orec, r);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = v[i] * a.gamma + r[i];
+              }
+            }
+            if constexpr ((DBG & DBG_NO_STORE) != 0) {
+              if (v[0] == 12345.678f) a.out[0] = 1;  // keep the values live without storing
+            } else if (a.epi <= EPI_NHWC_PS2) {
+              const unsigned long long ts0 = stamp();
+              store16<T>(a.out + (size_t)(a.out_plane0 + opl) * a.out_plane_bytes + orec, v);
+              st_store += stamp() - ts0;
+            } else {  // EPI_NCHW_F32
+              float* o = reinterpret_cast<float*>(a.out);
+              const size_t plane = (size_t)a.H * a.W;
+#pragma unroll
+              for (int i = 0; i < 16; ++i)
+                if (vbase + i < a.cout_real)
+                  o[((size_t)cur_n * a.cout_real + vbase + i) * plane + (size_t)y * a.W + xo] = v[i];
+            }
           }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
 
-    if (next_tile >= ntiles) break;
-    tile = next_tile;
-    __syncthreads();  // next tile's first chunk landed; all waves are done with the last buffer
+    { const unsigned long long t = stamp(); st_epi += t - st_t; st_t = t; }
+    if (next_tile < 0) break;
+    tile = next_tile; ++kt;
+    dma_wait();       // next tile's first chunk has landed
+    __syncthreads();  // all waves are done with the last buffer
     buf ^= 1;
+    { const unsigned long long t = stamp(); st_bar += t - st_t; st_t = t; }
+  }
+  if constexpr ((DBG & DBG_STAMP) != 0) {
+    const unsigned long long st_end = stamp();
+    if (tid == 0 && a.dbg_buf) {
+      unsigned long long* o = a.dbg_buf + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;
+      o[0] = st_end - st_begin; o[1] = st_dma; o[2] = st_mma; o[3] = st_epi; o[4] = st_bar; o[5] = kt + 1;
+      o[6] = __builtin_amdgcn_s_memrealtime(); o[7] = st_store;
+    }
   }
 }
 
-template <typename T, int NB>
+template <typename T, int NB, int DBG>
 static void launch_t(ss4k_ctx* ctx, const ConvArgs& a, int groups, hipStream_t st) {
-  constexpr size_t lds = (size_t)(2 * TILE_BUF_SLOTS + 2 * 18 * NB * 64) * 16;
+  constexpr size_t lds = (size_t)(2 * TILE_BUF_SLOTS + 2 * 18 * NB * 64) * 16 + NB * 32 * 2 * 4;
   static_assert(lds <= 160 * 1024, "LDS budget");
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
   static bool attr_set = false;
   if (!attr_set) {
-    SS4K_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, NB>),
+    SS4K_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, NB, DBG>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   int gx = std::min(ntiles, std::max(1, ctx->num_cu / groups));
-  hipLaunchKernelGGL((conv3x3_kernel<T, NB>), dim3(gx, groups), dim3(NTHREADS), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_kernel<T, NB, DBG>), dim3(gx, groups), dim3(NTHREADS), lds, st, a);
   SS4K_HIP(hipGetLastError());
+}
+
+template <int NB>
+static void launch_dbg(ss4k_ctx* ctx, const ConvArgs& a, int groups, hipStream_t st) {
+  switch (a.dbg) {  // ablation builds of the fp16 kernel for ss4k_bench_conv
+    case DBG_NO_EPILOGUE: launch_t<__half, NB, DBG_NO_EPILOGUE>(ctx, a, groups, st); break;
+    case DBG_NO_TILE_DMA | DBG_NO_W_DMA | DBG_NO_EPILOGUE: launch_t<__half, NB, DBG_NO_TILE_DMA | DBG_NO_W_DMA | DBG_NO_EPILOGUE>(ctx, a, groups, st); break;
+    case DBG_NO_MMA | DBG_NO_EPILOGUE: launch_t<__half, NB, DBG_NO_MMA | DBG_NO_EPILOGUE>(ctx, a, groups, st); break;
+    case DBG_STAMP: launch_t<__half, NB, DBG_STAMP>(ctx, a, groups, st); break;
+    default: throw Error(SS4K_EINVAL, "ss4k_bench_conv: unsupported ablation flags (0, 16, 28, 18, 32)");
+  }
 }
 
 void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st) {
@@ -334,10 +490,13 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
     else { SS4K_HIP(hipEventCreate(&pe.a)); SS4K_HIP(hipEventCreate(&pe.b)); }
     SS4K_HIP(hipEventRecord(pe.a, st));
   }
-  if (dtype == SS4K_F16) {
-    if (nb == 1) launch_t<__half, 1>(ctx, a, groups, st); else launch_t<__half, 2>(ctx, a, groups, st);
+  if (a.dbg) {
+    SS4K_REQUIRE(dtype == SS4K_F16, "ablation builds exist for fp16 only");
+    if (nb == 1) launch_dbg<1>(ctx, a, groups, st); else launch_dbg<2>(ctx, a, groups, st);
+  } else if (dtype == SS4K_F16) {
+    if (nb == 1) launch_t<__half, 1, 0>(ctx, a, groups, st); else launch_t<__half, 2, 0>(ctx, a, groups, st);
   } else {
-    if (nb == 1) launch_t<float, 1>(ctx, a, groups, st); else launch_t<float, 2>(ctx, a, groups, st);
+    if (nb == 1) launch_t<float, 1, 0>(ctx, a, groups, st); else launch_t<float, 2, 0>(ctx, a, groups, st);
   }
   if (ctx->prof) {
     SS4K_HIP(hipEventRecord(pe.b, st));

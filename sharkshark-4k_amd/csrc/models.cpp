@@ -232,6 +232,7 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
   a.bsvd_resid = o.bsvd_resid;
   a.epi = o.epi; a.out = o.out.p; a.out_plane_bytes = o.out.plane_bytes; a.out_plane0 = o.out.plane0;
   a.cout_real = L.cout_real; a.cout_pad = L.cout_pad;
+  a.dbg = dbg; a.dbg_buf = dbg_buf;
   a.flops = 2.0 * 9.0 * L.cin_real * L.cout_real * (double)N * H * W * (o.epi == EPI_NHWC_SUB2 ? 0.25 : 1.0);
   launch_conv3x3(ctx, a, desc.dtype, st);
 }
@@ -371,6 +372,45 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
       if (blk == 0) { o.out = MID; } else { o.epi = EPI_NCHW_F32; o.out = nchw_out(); }
       conv(li++, O0, nullptr, n, h, w, o, st); }                                       // outc.convblock.3 + residual
   }
+}
+
+
+// ---- measurement hook: one conv layer in isolation (ss4k_bench_conv) --------------------------
+double bench_conv_layer(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, int n, int h, int w, int flags,
+                        int iters, hipStream_t st) {
+  ss4k_model_desc d{}; d.kind = SS4K_RRDBNET; d.dtype = dtype; d.scale = 2; d.num_feat = 64; d.num_block = 1; d.num_grow_ch = 32;
+  Model m; m.ctx = ctx; m.desc = d;
+  const int cin = cin0 + cin1;
+  std::vector<float> blob((size_t)cout * cin * 9 + cout);
+  uint32_t s = 12345;
+  for (auto& v : blob) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0f * 0.02f - 0.01f; }
+  ParamCursor pc{blob.data(), blob.size()};
+  const int li = m.add_conv(pc, cout, cin, cin1 ? m.spec_concat(cin0, cin1) : m.spec_plain(cin0), false);
+  const size_t px = (size_t)n * h * w;
+  Tens X = m.act(0, px, cin0), G = m.act(1, px, std::max(cin1, 32)), O = m.act(2, px, cout);
+  SS4K_HIP(hipMemsetAsync(X.p, 0x11, (size_t)m.planes_for(cin0) * px * 64, st));
+  SS4K_HIP(hipMemsetAsync(G.p, 0x11, (size_t)m.planes_for(std::max(cin1, 32)) * px * 64, st));
+  ConvOpts o; o.act = ACT_LRELU; o.slope = 0.2f; o.out = O;
+  m.dbg = flags;
+  DevBuf dbgb; dbgb.ensure(1024 * 8 * 8); SS4K_HIP(hipMemsetAsync(dbgb.ptr, 0, 1024 * 8 * 8, st)); m.dbg_buf = dbgb.as<unsigned long long>();
+  for (int i = 0; i < 3; ++i) m.conv(li, X, cin1 ? &G : nullptr, n, h, w, o, st);
+  hipEvent_t e0, e1; SS4K_HIP(hipEventCreate(&e0)); SS4K_HIP(hipEventCreate(&e1));
+  SS4K_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) m.conv(li, X, cin1 ? &G : nullptr, n, h, w, o, st);
+  SS4K_HIP(hipEventRecord(e1, st));
+  SS4K_HIP(hipEventSynchronize(e1));
+  float ms = 0; SS4K_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (flags & DBG_STAMP) {  // print the phase breakdown of the last launch (wave 0 of every workgroup)
+    std::vector<unsigned long long> h((size_t)1024 * 8);
+    SS4K_HIP(hipMemcpy(h.data(), m.dbg_buf, h.size() * 8, hipMemcpyDeviceToHost));
+    double tot = 0, dma = 0, mma = 0, epi = 0, bar = 0, tiles = 0, sto = 0; int nwg = 0;
+    for (int i = 0; i < 1024; ++i) if (h[i * 8 + 5]) { tot += h[i*8]; dma += h[i*8+1]; mma += h[i*8+2]; epi += h[i*8+3]; bar += h[i*8+4]; tiles += h[i*8+5]; sto += h[i*8+7]; ++nwg; }
+    if (nwg) fprintf(stderr, "[stamp] %d WGs, avg tiles %.2f, cycles(100MHz ticks?) total %.0f  issue %.0f  mma %.0f  epilogue %.0f (stores %.0f)  barrier %.0f\n",
+                     nwg, tiles / nwg, tot / nwg, dma / nwg, mma / nwg, epi / nwg, sto / nwg, bar / nwg);
+  }
+  dbgb.release();
+  return 1000.0 * ms / iters;
 }
 
 }  // namespace ss4k

@@ -34,6 +34,8 @@ struct Model {
   std::vector<DevBuf> acts;
   DevBuf fs_blob; FsrcnnWeights fsw{};
   size_t weight_bytes = 0;
+  int dbg = 0;  // ablation build selector forwarded to the conv kernel (bench only)
+  unsigned long long* dbg_buf = nullptr;
 
   void build(const float* w, size_t n);
   void forward(const float* in, float* out, int n, int h, int w, hipStream_t st);
@@ -45,7 +47,6 @@ struct Model {
     fs_blob.release();
   }
 
- private:
   int add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec spec, bool has_prelu_after);
   PackSpec spec_plain(int cin_real, int ps2 = 0) const;
   PackSpec spec_concat(int c0, int c1) const;
@@ -59,4 +60,8 @@ struct Model {
 
 }  // namespace ss4k
 
+namespace ss4k {
+double bench_conv_layer(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, int n, int h, int w, int flags,
+                        int iters, hipStream_t st);
+}
 struct ss4k_model { ss4k::Model m; };
