@@ -106,7 +106,9 @@ __device__ __forceinline__ f32x16 mma(const uint4& w, const uint4& x, f32x16 acc
   }
 }
 
-template <typename T, int NB, int DBG>
+// GEN = false: only the plain-layout epilogue is compiled (every RRDBNet / SRVGG body layer);
+// GEN = true adds the stride-2 / PixelShuffle / NCHW / BSVD-residual / ReLU6 epilogues.
+template <typename T, int NB, int DBG, bool GEN>
 __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) {
   constexpr int CW = Tr<T>::CW;
   constexpr int WSLOTS = 18 * NB * 64;  // weight slots per chunk
@@ -170,25 +172,31 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
       src_off[j] = ok ? (uint32_t)((n * Hs + sy) * Ws + sx) * 64u + (uint32_t)((plan[j] >> 16) & 0xff) : OOB;
     }
   };
-  auto issue = [&](int c, int buf) {
-    const char* plane = (c < a.nchunks0)
-                            ? a.in0 + (size_t)(a.in0_plane0 + c) * a.in0_plane_bytes
-                            : a.in1 + (size_t)(a.in1_plane0 + c - a.nchunks0) * a.in1_plane_bytes;
-    const uint32_t tdst = lds0 + buf * TILE_BYTES;
-#pragma unroll
-    for (int j = 0; j < DMA_PER_WAVE; ++j) {
-      const int k = wave + 4 * j;
+  // One K-chunk prefetch = NDMA wave-level DMA instructions per wave (halo tile, then weights).
+  // They are not issued in a burst: dma_op(i) is called from slots spread through the MFMA stream
+  // of the chunk being computed, so their issue cost hides under matrix-pipe time.
+  constexpr int NDMA_T = DMA_PER_WAVE, NDMA_W = (18 * NB + 3) / 4, NDMA = NDMA_T + NDMA_W;
+  const char* pf_plane = nullptr; const char* pf_wsrc = nullptr;
+  uint32_t pf_tdst = 0, pf_wdst = 0; bool pf_on = false;
+  auto prefetch_begin = [&](int c, int buf) {
+    pf_plane = (c < a.nchunks0) ? a.in0 + (size_t)(a.in0_plane0 + c) * a.in0_plane_bytes
+                                : a.in1 + (size_t)(a.in1_plane0 + c - a.nchunks0) * a.in1_plane_bytes;
+    pf_tdst = lds0 + buf * TILE_BYTES;
+    pf_wsrc = wbase + (size_t)c * W_BYTES + lane * 16;
+    pf_wdst = lds0 + 2 * TILE_BYTES + buf * W_BYTES;
+    pf_on = true;
+  };
+  auto dma_op = [&](int idx) {
+    if (!pf_on) return;
+    if (idx < NDMA_T) {
+      const int k = wave + 4 * idx;
       if (k < TILE_DMA && !(DBG & DBG_NO_TILE_DMA)) {
-        const char* src = src_off[j] != OOB ? plane + src_off[j] : a.zero_page + (lane & 3) * 16;
-        dma16(src, __builtin_amdgcn_readfirstlane(tdst + k * 1024));
+        const char* src = src_off[idx] != OOB ? pf_plane + src_off[idx] : a.zero_page + (lane & 3) * 16;
+        dma16(src, __builtin_amdgcn_readfirstlane(pf_tdst + k * 1024));
       }
-    }
-    const char* wsrc = wbase + (size_t)c * W_BYTES + lane * 16;
-    const uint32_t wdst = lds0 + 2 * TILE_BYTES + buf * W_BYTES;
-#pragma unroll
-    for (int j = 0; j < (18 * NB + 3) / 4; ++j) {
-      const int k = wave + 4 * j;
-      if (k < 18 * NB && !(DBG & DBG_NO_W_DMA)) dma16(wsrc + k * 1024, __builtin_amdgcn_readfirstlane(wdst + k * 1024));
+    } else if (idx < NDMA) {
+      const int k = wave + 4 * (idx - NDMA_T);
+      if (k < 18 * NB && !(DBG & DBG_NO_W_DMA)) dma16(pf_wsrc + k * 1024, __builtin_amdgcn_readfirstlane(pf_wdst + k * 1024));
     }
   };
 
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
   if (tid < NB * 32) {
     const int v = grp * NB * 32 + tid;
     epi_lds[tid] = v < a.cout_pad ? a.bias[v] : 0.f;
-    epi_lds[NB * 32 + tid] = (a.act == ACT_PRELU && v < a.cout_pad) ? a.prelu[v] : a.slope;
+    epi_lds[NB * 32 + tid] = a.act == ACT_PRELU ? (v < a.cout_pad ? a.prelu[v] : 1.f) : (a.act == ACT_LRELU ? a.slope : 1.f);
   }
 
   // DBG_STAMP build only: per-phase cycle totals of wave 0 (s_memtime), written once at the end
@@ -220,7 +228,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
   if (tile < 0) return;
   int n, y0, x0;
   setup_tile(tile, n, y0, x0);
-  issue(0, 0);
+  prefetch_begin(0, 0);
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) dma_op(i);
   dma_wait();
   __syncthreads();
   int buf = 0;
@@ -228,13 +238,20 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
   struct Frags { uint4 wf[3][NB]; uint4 af[MB + 2]; };
 
   while (true) {
-    f32x16 acc[NB][MB];
+    f32x16 acc[NB][MB];  // start from the bias: one less pass over the tile in the epilogue
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int nb = 0; nb < NB; ++nb) {
+      float bias_v[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4*>(epi_lds + nb * 32 + 16 * lh + 4 * q);
+        bias_v[4 * q] = b4.x; bias_v[4 * q + 1] = b4.y; bias_v[4 * q + 2] = b4.z; bias_v[4 * q + 3] = b4.w;
+      }
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nb][mb][i] = 0.f;
+        for (int i = 0; i < 16; ++i) acc[nb][mb][i] = bias_v[i];
+    }
 
     const int cur_n = n, cur_y0 = y0, cur_x0 = x0;
     const int next_tile = tile_of(kt + 1);
@@ -243,13 +260,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
     for (int c = 0; c < nchunks; ++c) {
       st_t = stamp();
       // put the next K-chunk (or the next tile's first chunk) in flight into the other buffer
+      pf_on = false;
       if (c + 1 < nchunks) {
-        issue(c + 1, buf ^ 1);
-      } else {
-        if (next_tile >= 0) {
-          setup_tile(next_tile, n, y0, x0);
-          issue(0, buf ^ 1);
-        }
+        prefetch_begin(c + 1, buf ^ 1);
+      } else if (next_tile >= 0) {
+        setup_tile(next_tile, n, y0, x0);
+        prefetch_begin(0, buf ^ 1);
       }
       { const unsigned long long t = stamp(); st_dma += t - st_t; st_t = t; }
       const char* tb = smem + buf * TILE_BYTES;
@@ -265,18 +281,27 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
         for (int ir = 0; ir < MB + 2; ++ir)
           f.af[ir] = *reinterpret_cast<const uint4*>(tb + rd_base[dx][ks] + ir * IN_W * 64);
       };
-      auto mma_group = [&](const Frags& f) {
+      // the 12 (input row, dy) pairs of one group, in an order that never repeats an accumulator
+      // back to back; after every third MFMA one DMA instruction of the prefetch is issued
+      auto mma_group = [&](const Frags& f, int g) {
+        constexpr int IR[12] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+        constexpr int DY[12] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 1, 2, 2};
 #pragma unroll
-        for (int ir = 0; ir < MB + 2; ++ir)
+        for (int m = 0; m < 12; ++m) {
 #pragma unroll
-          for (int dy = 0; dy < 3; ++dy) {
-            const int mb = ir - dy;
-            if (mb >= 0 && mb < MB) {
-#pragma unroll
-              for (int nb = 0; nb < NB; ++nb) acc[nb][mb] = mma<T>(f.wf[dy][nb], f.af[ir], acc[nb][mb]);
-            }
+          for (int nb = 0; nb < NB; ++nb)
+            acc[nb][IR[m] - DY[m]] = mma<T>(f.wf[DY[m]][nb], f.af[IR[m]], acc[nb][IR[m] - DY[m]]);
+          if (m % 3 == 1 && g * 4 + m / 3 < NDMA) {
+            __builtin_amdgcn_sched_barrier(0);
+            dma_op(g * 4 + m / 3);
+            __builtin_amdgcn_sched_barrier(0);
           }
+        }
       };
+      if constexpr ((DBG & DBG_NO_MMA) != 0) {
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) dma_op(i);
+      }
       if constexpr (!(DBG & DBG_NO_MMA)) {
         // software pipeline over the six (dx, k-step) groups: the LDS reads of group g+1 are in
         // flight while the 12*NB MFMAs of group g issue (one wave per SIMD: nobody else hides them)
@@ -286,11 +311,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
         for (int g = 0; g < 6; g += 2) {
           load_group(fb, g + 1);
           __builtin_amdgcn_sched_barrier(0);
-          mma_group(fa);
+          mma_group(fa, g);
           __builtin_amdgcn_sched_barrier(0);
           if (g + 2 < 6) load_group(fa, g + 2);
           __builtin_amdgcn_sched_barrier(0);
-          mma_group(fb);
+          mma_group(fb, g + 1);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -308,18 +333,74 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
     // past the stores: per 32-channel block issue every row's residual loads first, then consume
     // (one memory round trip per block instead of one per row).
     const bool batch_res = a.epi == EPI_NHWC && !a.bsvd_resid && (a.res1 || a.res2);
+    // Fast path (every RRDBNet / SRVGG body layer): plain layout, branch-free arithmetic
+    //   v = act(acc) * alpha + res1;  v = v * gamma + res2      (absent residuals are zeros,
+    // absent activation is slope 1, so the same instruction stream serves every such layer)
+    const bool fast_epi = !GEN || (a.epi == EPI_NHWC && !a.bsvd_resid && a.act != ACT_RELU6);
     if constexpr (!(DBG & DBG_NO_EPILOGUE))
+    if (fast_epi) {
+      const float alpha = a.alpha, gamma = a.gamma;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int vbase = (grp * NB + nb) * 32 + 16 * lh;
+        if ((grp * NB + nb) * 32 >= a.cout_pad) continue;
+        float slope_v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 s4 = *reinterpret_cast<const float4*>(epi_lds + NB * 32 + nb * 32 + 16 * lh + 4 * q);
+          slope_v[4 * q] = s4.x; slope_v[4 * q + 1] = s4.y; slope_v[4 * q + 2] = s4.z; slope_v[4 * q + 3] = s4.w;
+        }
+        const int opl = vbase / CW;
+        const size_t sub = (size_t)(vbase - opl * CW) * sizeof(T);
+        const char* r1p = a.res1 ? a.res1 + (size_t)(a.r1_plane0 + opl) * a.r1_plane_bytes + sub : nullptr;
+        const char* r2p = a.res2 ? a.res2 + (size_t)(a.r2_plane0 + opl) * a.r2_plane_bytes + sub : nullptr;
+        char* outp = a.out + (size_t)(a.out_plane0 + opl) * a.out_plane_bytes + sub;
+        const size_t pix0 = ((size_t)cur_n * a.H + cur_y0 + wave * MB) * a.W + xo;
+        uint4 r1v[MB][RV], r2v[MB][RV];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const bool ok = (cur_y0 + wave * MB + mb) < a.H && xo < a.W;
+          const size_t rec = (pix0 + (size_t)mb * a.W) * 64;
+#pragma unroll
+          for (int q = 0; q < RV; ++q) {
+            r1v[mb][q] = (r1p && ok) ? *reinterpret_cast<const uint4*>(r1p + rec + 16 * q) : make_uint4(0, 0, 0, 0);
+            r2v[mb][q] = (r2p && ok) ? *reinterpret_cast<const uint4*>(r2p + rec + 16 * q) : make_uint4(0, 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const bool ok = (cur_y0 + wave * MB + mb) < a.H && xo < a.W;
+          float v[16], r1[16], r2[16];
+          load16<T>(reinterpret_cast<const char*>(&r1v[mb][0]), r1);
+          load16<T>(reinterpret_cast<const char*>(&r2v[mb][0]), r2);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float t = acc[nb][mb][i];
+            const float neg = t * slope_v[i];
+            t = t >= 0.f ? t : neg;
+            t = t * alpha + r1[i];
+            v[i] = t * gamma + r2[i];
+          }
+          if (ok) {
+            if constexpr ((DBG & DBG_NO_STORE) != 0) { if (v[0] == 12345.678f) a.out[0] = 1; }
+            else store16<T>(outp + (pix0 + (size_t)mb * a.W) * 64, v);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (GEN)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const int vbase = (grp * NB + nb) * 32 + 16 * lh;
       if (vbase >= a.cout_pad) continue;
-      float bias_v[16], slope_v[16];
+      float slope_v[16];
+      if (a.act == ACT_PRELU) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 b4 = *reinterpret_cast<const float4*>(epi_lds + nb * 32 + 16 * lh + 4 * q);
-        const float4 s4 = *reinterpret_cast<const float4*>(epi_lds + NB * 32 + nb * 32 + 16 * lh + 4 * q);
-        bias_v[4 * q] = b4.x; bias_v[4 * q + 1] = b4.y; bias_v[4 * q + 2] = b4.z; bias_v[4 * q + 3] = b4.w;
-        slope_v[4 * q] = s4.x; slope_v[4 * q + 1] = s4.y; slope_v[4 * q + 2] = s4.z; slope_v[4 * q + 3] = s4.w;
+        for (int q = 0; q < 4; ++q) {
+          const float4 s4 = *reinterpret_cast<const float4*>(epi_lds + NB * 32 + nb * 32 + 16 * lh + 4 * q);
+          slope_v[4 * q] = s4.x; slope_v[4 * q + 1] = s4.y; slope_v[4 * q + 2] = s4.z; slope_v[4 * q + 3] = s4.w;
+        }
       }
       uint4 r1v[MB][RV], r2v[MB][RV];
       if (batch_res) {
@@ -347,8 +428,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
           const size_t ipix = ((size_t)cur_n * a.H + y) * a.W + xo;
           float v[16];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) v[i] = acc[nb][mb][i] + bias_v[i];
-          if (a.act == ACT_LRELU || a.act == ACT_PRELU) {
+          for (int i = 0; i < 16; ++i) v[i] = acc[nb][mb][i];
+          if (a.act == ACT_LRELU) {  // slope in [0,1] (checked on the host): max(v, slope*v)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], v[i] * a.slope);
+          } else if (a.act == ACT_PRELU) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
               const float neg = v[i] * slope_v[i];  // unconditional: a select, not a branch per element
@@ -447,29 +531,29 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
   }
 }
 
-template <typename T, int NB, int DBG>
+template <typename T, int NB, int DBG, bool GEN>
 static void launch_t(ss4k_ctx* ctx, const ConvArgs& a, int groups, hipStream_t st) {
   constexpr size_t lds = (size_t)(2 * TILE_BUF_SLOTS + 2 * 18 * NB * 64) * 16 + NB * 32 * 2 * 4;
   static_assert(lds <= 160 * 1024, "LDS budget");
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
   static bool attr_set = false;
   if (!attr_set) {
-    SS4K_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, NB, DBG>),
+    SS4K_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, NB, DBG, GEN>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   int gx = std::min(ntiles, std::max(1, ctx->num_cu / groups));
-  hipLaunchKernelGGL((conv3x3_kernel<T, NB, DBG>), dim3(gx, groups), dim3(NTHREADS), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_kernel<T, NB, DBG, GEN>), dim3(gx, groups), dim3(NTHREADS), lds, st, a);
   SS4K_HIP(hipGetLastError());
 }
 
 template <int NB>
 static void launch_dbg(ss4k_ctx* ctx, const ConvArgs& a, int groups, hipStream_t st) {
   switch (a.dbg) {  // ablation builds of the fp16 kernel for ss4k_bench_conv
-    case DBG_NO_EPILOGUE: launch_t<__half, NB, DBG_NO_EPILOGUE>(ctx, a, groups, st); break;
-    case DBG_NO_TILE_DMA | DBG_NO_W_DMA | DBG_NO_EPILOGUE: launch_t<__half, NB, DBG_NO_TILE_DMA | DBG_NO_W_DMA | DBG_NO_EPILOGUE>(ctx, a, groups, st); break;
-    case DBG_NO_MMA | DBG_NO_EPILOGUE: launch_t<__half, NB, DBG_NO_MMA | DBG_NO_EPILOGUE>(ctx, a, groups, st); break;
-    case DBG_STAMP: launch_t<__half, NB, DBG_STAMP>(ctx, a, groups, st); break;
+    case DBG_NO_EPILOGUE: launch_t<__half, NB, DBG_NO_EPILOGUE, false>(ctx, a, groups, st); break;
+    case DBG_NO_TILE_DMA | DBG_NO_W_DMA | DBG_NO_EPILOGUE: launch_t<__half, NB, DBG_NO_TILE_DMA | DBG_NO_W_DMA | DBG_NO_EPILOGUE, false>(ctx, a, groups, st); break;
+    case DBG_NO_MMA | DBG_NO_EPILOGUE: launch_t<__half, NB, DBG_NO_MMA | DBG_NO_EPILOGUE, false>(ctx, a, groups, st); break;
+    case DBG_STAMP: launch_t<__half, NB, DBG_STAMP, false>(ctx, a, groups, st); break;
     default: throw Error(SS4K_EINVAL, "ss4k_bench_conv: unsupported ablation flags (0, 16, 28, 18, 32)");
   }
 }
@@ -482,6 +566,7 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
   const int nb = a.cout_pad <= 32 ? 1 : 2;
   const int groups = (a.cout_pad + nb * 32 - 1) / (nb * 32);
   SS4K_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0, "conv3x3: empty grid");
+  SS4K_REQUIRE(a.act != ACT_LRELU || (a.slope >= 0.f && a.slope <= 1.f), "conv3x3: LeakyReLU slope must be in [0,1]");
   SS4K_REQUIRE(!a.ups2 || ((a.H % 2 == 0) && (a.W % 2 == 0)), "conv3x3: ups2 needs even grid");
   SS4K_REQUIRE((double)a.N * a.H * a.W * 64.0 < 4294967296.0, "conv3x3: a plane must stay below 4 GiB");
   ProfEvent pe{};
@@ -493,10 +578,15 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
   if (a.dbg) {
     SS4K_REQUIRE(dtype == SS4K_F16, "ablation builds exist for fp16 only");
     if (nb == 1) launch_dbg<1>(ctx, a, groups, st); else launch_dbg<2>(ctx, a, groups, st);
-  } else if (dtype == SS4K_F16) {
-    if (nb == 1) launch_t<__half, 1, 0>(ctx, a, groups, st); else launch_t<__half, 2, 0>(ctx, a, groups, st);
   } else {
-    if (nb == 1) launch_t<float, 1, 0>(ctx, a, groups, st); else launch_t<float, 2, 0>(ctx, a, groups, st);
+    const bool gen = !(a.epi == EPI_NHWC && !a.bsvd_resid && a.act != ACT_RELU6);
+    if (dtype == SS4K_F16) {
+      if (nb == 1) { if (gen) launch_t<__half, 1, 0, true>(ctx, a, groups, st); else launch_t<__half, 1, 0, false>(ctx, a, groups, st); }
+      else { if (gen) launch_t<__half, 2, 0, true>(ctx, a, groups, st); else launch_t<__half, 2, 0, false>(ctx, a, groups, st); }
+    } else {
+      if (nb == 1) { if (gen) launch_t<float, 1, 0, true>(ctx, a, groups, st); else launch_t<float, 1, 0, false>(ctx, a, groups, st); }
+      else { if (gen) launch_t<float, 2, 0, true>(ctx, a, groups, st); else launch_t<float, 2, 0, false>(ctx, a, groups, st); }
+    }
   }
   if (ctx->prof) {
     SS4K_HIP(hipEventRecord(pe.b, st));
