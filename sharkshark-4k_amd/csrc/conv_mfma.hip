@@ -356,35 +356,63 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
         const char* r2p = a.res2 ? a.res2 + (size_t)(a.r2_plane0 + opl) * a.r2_plane_bytes + sub : nullptr;
         char* outp = a.out + (size_t)(a.out_plane0 + opl) * a.out_plane_bytes + sub;
         const size_t pix0 = ((size_t)cur_n * a.H + cur_y0 + wave * MB) * a.W + xo;
-        uint4 r1v[MB][RV], r2v[MB][RV];
+        if (!r1p && !r2p) {
+          // activation only (four of the five RDB convs): max-form LeakyReLU / identity when every
+          // slope is in [0,1] (a.act != PRELU), select form for learned PReLU slopes
+          const bool select_form = a.act == ACT_PRELU;
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          const bool ok = (cur_y0 + wave * MB + mb) < a.H && xo < a.W;
-          const size_t rec = (pix0 + (size_t)mb * a.W) * 64;
+          for (int mb = 0; mb < MB; ++mb) {
+            const bool ok = (cur_y0 + wave * MB + mb) < a.H && xo < a.W;
+            float v[16];
+            if (select_form) {
 #pragma unroll
-          for (int q = 0; q < RV; ++q) {
-            r1v[mb][q] = (r1p && ok) ? *reinterpret_cast<const uint4*>(r1p + rec + 16 * q) : make_uint4(0, 0, 0, 0);
-            r2v[mb][q] = (r2p && ok) ? *reinterpret_cast<const uint4*>(r2p + rec + 16 * q) : make_uint4(0, 0, 0, 0);
+              for (int i = 0; i < 16; ++i) {
+                const float t = acc[nb][mb][i], neg = t * slope_v[i];
+                v[i] = (t >= 0.f ? t : neg) * alpha;
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < 16; ++i) {
+                const float t = acc[nb][mb][i];
+                v[i] = fmaxf(t, t * slope_v[i]) * alpha;
+              }
+            }
+            if (ok) {
+              if constexpr ((DBG & DBG_NO_STORE) != 0) { if (v[0] == 12345.678f) a.out[0] = 1; }
+              else store16<T>(outp + (pix0 + (size_t)mb * a.W) * 64, v);
+            }
           }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        } else {
+          uint4 r1v[MB][RV], r2v[MB][RV];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          const bool ok = (cur_y0 + wave * MB + mb) < a.H && xo < a.W;
-          float v[16], r1[16], r2[16];
-          load16<T>(reinterpret_cast<const char*>(&r1v[mb][0]), r1);
-          load16<T>(reinterpret_cast<const char*>(&r2v[mb][0]), r2);
+          for (int mb = 0; mb < MB; ++mb) {
+            const bool ok = (cur_y0 + wave * MB + mb) < a.H && xo < a.W;
+            const size_t rec = (pix0 + (size_t)mb * a.W) * 64;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            float t = acc[nb][mb][i];
-            const float neg = t * slope_v[i];
-            t = t >= 0.f ? t : neg;
-            t = t * alpha + r1[i];
-            v[i] = t * gamma + r2[i];
+            for (int q = 0; q < RV; ++q) {
+              r1v[mb][q] = (r1p && ok) ? *reinterpret_cast<const uint4*>(r1p + rec + 16 * q) : make_uint4(0, 0, 0, 0);
+              r2v[mb][q] = (r2p && ok) ? *reinterpret_cast<const uint4*>(r2p + rec + 16 * q) : make_uint4(0, 0, 0, 0);
+            }
           }
-          if (ok) {
-            if constexpr ((DBG & DBG_NO_STORE) != 0) { if (v[0] == 12345.678f) a.out[0] = 1; }
-            else store16<T>(outp + (pix0 + (size_t)mb * a.W) * 64, v);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            const bool ok = (cur_y0 + wave * MB + mb) < a.H && xo < a.W;
+            float v[16], r1[16], r2[16];
+            load16<T>(reinterpret_cast<const char*>(&r1v[mb][0]), r1);
+            load16<T>(reinterpret_cast<const char*>(&r2v[mb][0]), r2);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              float t = acc[nb][mb][i];
+              const float neg = t * slope_v[i];
+              t = t >= 0.f ? t : neg;
+              t = t * alpha + r1[i];
+              v[i] = t * gamma + r2[i];
+            }
+            if (ok) {
+              if constexpr ((DBG & DBG_NO_STORE) != 0) { if (v[0] == 12345.678f) a.out[0] = 1; }
+              else store16<T>(outp + (pix0 + (size_t)mb * a.W) * 64, v);
+            }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
