@@ -108,7 +108,7 @@ struct ConvArgs {
   int dbg;                              // selects an ablation build (ss4k_bench_conv only; 0 in production)
   unsigned long long* dbg_buf;          // DBG_STAMP: per-workgroup phase cycle counters
 };
-enum { DBG_NO_STORE = 1, DBG_NO_MMA = 2, DBG_NO_TILE_DMA = 4, DBG_NO_W_DMA = 8, DBG_NO_EPILOGUE = 16, DBG_STAMP = 32 };
+enum { DBG_NO_STORE = 1, DBG_NO_MMA = 2, DBG_NO_TILE_DMA = 4, DBG_NO_W_DMA = 8, DBG_NO_EPILOGUE = 16, DBG_STAMP = 32, DBG_MB4 = 64 };
 
 // launchers (conv_mfma.hip)
 void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a, int dtype, hipStream_t st);

@@ -32,13 +32,17 @@ namespace ss4k {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int TW = 32, TH = 16, MB = 4, NTHREADS = 256;
-constexpr int IN_W = TW + 2, IN_H = TH + 2, IN_PIX = IN_W * IN_H;
-constexpr int TILE_SLOTS = IN_PIX * 4;                  // 16-byte slots actually used
-constexpr int TILE_DMA = (TILE_SLOTS + 63) / 64;        // wave-level DMA instructions per tile (39)
-constexpr int TILE_BUF_SLOTS = TILE_DMA * 64;           // padded so a full last instruction stays inside
-constexpr int DMA_PER_WAVE = (TILE_DMA + 3) / 4;
+constexpr int TW = 32, NTHREADS = 256, IN_W = TW + 2;
 constexpr uint32_t OOB = 0xFFFFFFFFu;
+// Tile geometry for MB output rows per wave (4 waves): MB = 4 -> 16x32 tile, one workgroup per CU
+// (115/153 KB LDS); MB = 2 -> 8x32 tile, 80 KB LDS so TWO workgroups share a CU and one's epilogue /
+// barrier / DMA-wait time is covered by the other's MFMAs (used for the 32-cout layers).
+template <int MB> struct Geo {
+  static constexpr int TH = 4 * MB, IN_H = TH + 2, IN_PIX = IN_W * IN_H;
+  static constexpr int TILE_SLOTS = IN_PIX * 4;            // 16-byte LDS slots per halo tile
+  static constexpr int TILE_DMA = (TILE_SLOTS + 63) / 64;  // wave-level DMA instructions per tile
+  static constexpr int DMA_PER_WAVE = (TILE_DMA + 3) / 4;
+};
 
 template <typename T> struct Tr;
 template <> struct Tr<__half> { static constexpr int E = 8, CW = 32; };
@@ -108,14 +112,16 @@ __device__ __forceinline__ f32x16 mma(const uint4& w, const uint4& x, f32x16 acc
 
 // GEN = false: only the plain-layout epilogue is compiled (every RRDBNet / SRVGG body layer);
 // GEN = true adds the stride-2 / PixelShuffle / NCHW / BSVD-residual / ReLU6 epilogues.
-template <typename T, int NB, int DBG, bool GEN>
-__global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) {
+template <typename T, int NB, int MB, int DBG, bool GEN>
+__global__ __launch_bounds__(NTHREADS, MB == 2 ? 2 : 1) void conv3x3_kernel(const ConvArgs a) {
   constexpr int CW = Tr<T>::CW;
+  constexpr int TH = Geo<MB>::TH, TILE_SLOTS = Geo<MB>::TILE_SLOTS, TILE_DMA = Geo<MB>::TILE_DMA;
+  constexpr int DMA_PER_WAVE = Geo<MB>::DMA_PER_WAVE;
   constexpr int WSLOTS = 18 * NB * 64;  // weight slots per chunk
   constexpr int RV = (int)(16 * sizeof(T) / 16);  // uint4 per 16-channel group
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [tile buf 0][tile buf 1][weights buf 0][weights buf 1]
-  constexpr int TILE_BYTES = TILE_BUF_SLOTS * 16, W_BYTES = WSLOTS * 16;
+  constexpr int TILE_BYTES = TILE_SLOTS * 16, W_BYTES = WSLOTS * 16;
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -176,6 +182,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
   // They are not issued in a burst: dma_op(i) is called from slots spread through the MFMA stream
   // of the chunk being computed, so their issue cost hides under matrix-pipe time.
   constexpr int NDMA_T = DMA_PER_WAVE, NDMA_W = (18 * NB + 3) / 4, NDMA = NDMA_T + NDMA_W;
+  static_assert(NDMA <= 6 * MB, "not enough DMA slots in the MFMA stream");
   const char* pf_plane = nullptr; const char* pf_wsrc = nullptr;
   uint32_t pf_tdst = 0, pf_wdst = 0; bool pf_on = false;
   auto prefetch_begin = [&](int c, int buf) {
@@ -192,7 +199,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
       const int k = wave + 4 * idx;
       if (k < TILE_DMA && !(DBG & DBG_NO_TILE_DMA)) {
         const char* src = src_off[idx] != OOB ? pf_plane + src_off[idx] : a.zero_page + (lane & 3) * 16;
-        dma16(src, __builtin_amdgcn_readfirstlane(pf_tdst + k * 1024));
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(pf_tdst + k * 1024);
+        if (plan[idx] >= 0) dma16(src, dst);  // lanes past the tile's last slot are masked off (EXEC)
       }
     } else if (idx < NDMA) {
       const int k = wave + 4 * (idx - NDMA_T);
@@ -284,19 +292,25 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
       // the 12 (input row, dy) pairs of one group, in an order that never repeats an accumulator
       // back to back; after every third MFMA one DMA instruction of the prefetch is issued
       auto mma_group = [&](const Frags& f, int g) {
-        constexpr int IR[12] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 5};
-        constexpr int DY[12] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 1, 2, 2};
+        // the 3*MB (input row, dy) pairs of one group; after every third MFMA (x NB) one DMA
+        // instruction of the prefetch is issued
+        int m = 0;
 #pragma unroll
-        for (int m = 0; m < 12; ++m) {
+        for (int ir = 0; ir < MB + 2; ++ir)
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            acc[nb][IR[m] - DY[m]] = mma<T>(f.wf[DY[m]][nb], f.af[IR[m]], acc[nb][IR[m] - DY[m]]);
-          if (m % 3 == 1 && g * 4 + m / 3 < NDMA) {
-            __builtin_amdgcn_sched_barrier(0);
-            dma_op(g * 4 + m / 3);
-            __builtin_amdgcn_sched_barrier(0);
+          for (int dy = 0; dy < 3; ++dy) {
+            const int mb = ir - dy;
+            if (mb >= 0 && mb < MB) {
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb) acc[nb][mb] = mma<T>(f.wf[dy][nb], f.af[ir], acc[nb][mb]);
+              if (m % 3 == 1 && g * MB + m / 3 < NDMA) {
+                __builtin_amdgcn_sched_barrier(0);
+                dma_op(g * MB + m / 3);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+              ++m;
+            }
           }
-        }
       };
       if constexpr ((DBG & DBG_NO_MMA) != 0) {
 #pragma unroll
@@ -559,37 +573,40 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_kernel(const ConvArgs a) 
   }
 }
 
-template <typename T, int NB, int DBG, bool GEN>
-static void launch_t(ss4k_ctx* ctx, const ConvArgs& a, int groups, hipStream_t st) {
-  constexpr size_t lds = (size_t)(2 * TILE_BUF_SLOTS + 2 * 18 * NB * 64) * 16 + NB * 32 * 2 * 4;
-  static_assert(lds <= 160 * 1024, "LDS budget");
+template <typename T, int NB, int MB, int DBG, bool GEN>
+static void launch_t(ss4k_ctx* ctx, const ConvArgs& a0, int groups, hipStream_t st) {
+  constexpr size_t lds = (size_t)(2 * Geo<MB>::TILE_SLOTS + 2 * 18 * NB * 64) * 16 + NB * 32 * 2 * 4;
+  static_assert(lds <= (MB == 2 ? 80 : 160) * 1024, "LDS budget");
+  ConvArgs a = a0;
+  a.tiles_y = (a.H + Geo<MB>::TH - 1) / Geo<MB>::TH;
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
   static bool attr_set = false;
   if (!attr_set) {
-    SS4K_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, NB, DBG, GEN>),
+    SS4K_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, NB, MB, DBG, GEN>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  int gx = std::min(ntiles, std::max(1, ctx->num_cu / groups));
-  hipLaunchKernelGGL((conv3x3_kernel<T, NB, DBG, GEN>), dim3(gx, groups), dim3(NTHREADS), lds, st, a);
+  const int per_cu = MB == 2 ? 2 : 1;
+  int gx = std::min(ntiles, std::max(1, ctx->num_cu * per_cu / groups));
+  hipLaunchKernelGGL((conv3x3_kernel<T, NB, MB, DBG, GEN>), dim3(gx, groups), dim3(NTHREADS), lds, st, a);
   SS4K_HIP(hipGetLastError());
 }
 
-template <int NB>
+template <int NB, int MB>
 static void launch_dbg(ss4k_ctx* ctx, const ConvArgs& a, int groups, hipStream_t st) {
-  switch (a.dbg) {  // ablation builds of the fp16 kernel for ss4k_bench_conv
-    case DBG_NO_EPILOGUE: launch_t<__half, NB, DBG_NO_EPILOGUE, false>(ctx, a, groups, st); break;
-    case DBG_NO_TILE_DMA | DBG_NO_W_DMA | DBG_NO_EPILOGUE: launch_t<__half, NB, DBG_NO_TILE_DMA | DBG_NO_W_DMA | DBG_NO_EPILOGUE, false>(ctx, a, groups, st); break;
-    case DBG_NO_MMA | DBG_NO_EPILOGUE: launch_t<__half, NB, DBG_NO_MMA | DBG_NO_EPILOGUE, false>(ctx, a, groups, st); break;
-    case DBG_STAMP: launch_t<__half, NB, DBG_STAMP, false>(ctx, a, groups, st); break;
-    default: throw Error(SS4K_EINVAL, "ss4k_bench_conv: unsupported ablation flags (0, 16, 28, 18, 32)");
+  switch (a.dbg & ~DBG_MB4) {  // ablation builds of the fp16 kernel for ss4k_bench_conv
+    case DBG_NO_EPILOGUE: launch_t<__half, NB, MB, DBG_NO_EPILOGUE, false>(ctx, a, groups, st); break;
+    case DBG_NO_TILE_DMA | DBG_NO_W_DMA | DBG_NO_EPILOGUE: launch_t<__half, NB, MB, DBG_NO_TILE_DMA | DBG_NO_W_DMA | DBG_NO_EPILOGUE, false>(ctx, a, groups, st); break;
+    case DBG_NO_MMA | DBG_NO_EPILOGUE: launch_t<__half, NB, MB, DBG_NO_MMA | DBG_NO_EPILOGUE, false>(ctx, a, groups, st); break;
+    case DBG_STAMP: launch_t<__half, NB, MB, DBG_STAMP, false>(ctx, a, groups, st); break;
+    case 0: launch_t<__half, NB, MB, 0, false>(ctx, a, groups, st); break;
+    default: throw Error(SS4K_EINVAL, "ss4k_bench_conv: unsupported ablation flags (0, 16, 28, 18, 32 [+64])");
   }
 }
 
 void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st) {
   ConvArgs a = a0;
   a.tiles_x = (a.W + TW - 1) / TW;
-  a.tiles_y = (a.H + TH - 1) / TH;
   a.zero_page = ctx->zero_page();
   const int nb = a.cout_pad <= 32 ? 1 : 2;
   const int groups = (a.cout_pad + nb * 32 - 1) / (nb * 32);
@@ -603,17 +620,21 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
     else { SS4K_HIP(hipEventCreate(&pe.a)); SS4K_HIP(hipEventCreate(&pe.b)); }
     SS4K_HIP(hipEventRecord(pe.a, st));
   }
+  // 32-cout fp16 layers run the 8-row-tile build (two workgroups per CU); DBG_MB4 forces 16 rows
+  const bool mb2 = dtype == SS4K_F16 && nb == 1 && !(a.dbg & DBG_MB4);
   if (a.dbg) {
     SS4K_REQUIRE(dtype == SS4K_F16, "ablation builds exist for fp16 only");
-    if (nb == 1) launch_dbg<1>(ctx, a, groups, st); else launch_dbg<2>(ctx, a, groups, st);
+    if (nb == 1) { if (mb2) launch_dbg<1, 2>(ctx, a, groups, st); else launch_dbg<1, 4>(ctx, a, groups, st); }
+    else launch_dbg<2, 4>(ctx, a, groups, st);
   } else {
     const bool gen = !(a.epi == EPI_NHWC && !a.bsvd_resid && a.act != ACT_RELU6);
     if (dtype == SS4K_F16) {
-      if (nb == 1) { if (gen) launch_t<__half, 1, 0, true>(ctx, a, groups, st); else launch_t<__half, 1, 0, false>(ctx, a, groups, st); }
-      else { if (gen) launch_t<__half, 2, 0, true>(ctx, a, groups, st); else launch_t<__half, 2, 0, false>(ctx, a, groups, st); }
+      if (mb2) { if (gen) launch_t<__half, 1, 2, 0, true>(ctx, a, groups, st); else launch_t<__half, 1, 2, 0, false>(ctx, a, groups, st); }
+      else if (nb == 1) { if (gen) launch_t<__half, 1, 4, 0, true>(ctx, a, groups, st); else launch_t<__half, 1, 4, 0, false>(ctx, a, groups, st); }
+      else { if (gen) launch_t<__half, 2, 4, 0, true>(ctx, a, groups, st); else launch_t<__half, 2, 4, 0, false>(ctx, a, groups, st); }
     } else {
-      if (nb == 1) { if (gen) launch_t<float, 1, 0, true>(ctx, a, groups, st); else launch_t<float, 1, 0, false>(ctx, a, groups, st); }
-      else { if (gen) launch_t<float, 2, 0, true>(ctx, a, groups, st); else launch_t<float, 2, 0, false>(ctx, a, groups, st); }
+      if (nb == 1) { if (gen) launch_t<float, 1, 4, 0, true>(ctx, a, groups, st); else launch_t<float, 1, 4, 0, false>(ctx, a, groups, st); }
+      else { if (gen) launch_t<float, 2, 4, 0, true>(ctx, a, groups, st); else launch_t<float, 2, 4, 0, false>(ctx, a, groups, st); }
     }
   }
   if (ctx->prof) {
