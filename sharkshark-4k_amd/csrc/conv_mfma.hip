@@ -213,7 +213,7 @@ __global__ __launch_bounds__(NTHREADS, MB == 2 ? 2 : 1) void conv3x3_kernel(cons
   if (tid < NB * 32) {
     const int v = grp * NB * 32 + tid;
     epi_lds[tid] = v < a.cout_pad ? a.bias[v] : 0.f;
-    epi_lds[NB * 32 + tid] = a.act == ACT_PRELU ? (v < a.cout_pad ? a.prelu[v] : 1.f) : (a.act == ACT_LRELU ? a.slope : 1.f);
+    epi_lds[NB * 32 + tid] = a.act == ACT_PRELU ? (v < a.cout_pad ? a.prelu[v] : 1.f) : (a.act == ACT_LRELU ? a.slope : (a.act == ACT_RELU6 ? 0.f : 1.f));
   }
 
   // DBG_STAMP build only: per-phase cycle totals of wave 0 (s_memtime), written once at the end
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(NTHREADS, MB == 2 ? 2 : 1) void conv3x3_kernel(cons
     // Fast path (every RRDBNet / SRVGG body layer): plain layout, branch-free arithmetic
     //   v = act(acc) * alpha + res1;  v = v * gamma + res2      (absent residuals are zeros,
     // absent activation is slope 1, so the same instruction stream serves every such layer)
-    const bool fast_epi = !GEN || (a.epi == EPI_NHWC && !a.bsvd_resid && a.act != ACT_RELU6);
+    const bool fast_epi = !GEN || (a.epi == EPI_NHWC && !a.bsvd_resid);
     if constexpr (!(DBG & DBG_NO_EPILOGUE))
     if (fast_epi) {
       const float alpha = a.alpha, gamma = a.gamma;
@@ -378,7 +378,10 @@ __global__ __launch_bounds__(NTHREADS, MB == 2 ? 2 : 1) void conv3x3_kernel(cons
           for (int mb = 0; mb < MB; ++mb) {
             const bool ok = (cur_y0 + wave * MB + mb) < a.H && xo < a.W;
             float v[16];
-            if (select_form) {
+            if (a.act == ACT_RELU6) {
+#pragma unroll
+              for (int i = 0; i < 16; ++i) v[i] = fminf(fmaxf(acc[nb][mb][i], 0.f), 6.f) * alpha;
+            } else if (select_form) {
 #pragma unroll
               for (int i = 0; i < 16; ++i) {
                 const float t = acc[nb][mb][i], neg = t * slope_v[i];
@@ -420,6 +423,7 @@ __global__ __launch_bounds__(NTHREADS, MB == 2 ? 2 : 1) void conv3x3_kernel(cons
               float t = acc[nb][mb][i];
               const float neg = t * slope_v[i];
               t = t >= 0.f ? t : neg;
+              if (a.act == ACT_RELU6) t = fminf(t, 6.f);  // slope is 0 for ReLU6: the select above is the ReLU
               t = t * alpha + r1[i];
               v[i] = t * gamma + r2[i];
             }
@@ -627,7 +631,7 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
     if (nb == 1) { if (mb2) launch_dbg<1, 2>(ctx, a, groups, st); else launch_dbg<1, 4>(ctx, a, groups, st); }
     else launch_dbg<2, 4>(ctx, a, groups, st);
   } else {
-    const bool gen = !(a.epi == EPI_NHWC && !a.bsvd_resid && a.act != ACT_RELU6);
+    const bool gen = !(a.epi == EPI_NHWC && !a.bsvd_resid);
     if (dtype == SS4K_F16) {
       if (mb2) { if (gen) launch_t<__half, 1, 2, 0, true>(ctx, a, groups, st); else launch_t<__half, 1, 2, 0, false>(ctx, a, groups, st); }
       else if (nb == 1) { if (gen) launch_t<__half, 1, 4, 0, true>(ctx, a, groups, st); else launch_t<__half, 1, 4, 0, false>(ctx, a, groups, st); }
