@@ -79,45 +79,49 @@ def synthetic_frames(batch, shape, seed):
     return torch.from_numpy(np.random.default_rng(seed).integers(0, 256, (batch, shape[0], shape[1], 3), dtype=np.uint8))
 
 
-def cpu_baseline(workload, gpu_ctx, seconds_budget=25.0):
-    """Oracle timed on this box's host cores on a bounded crop of the same workload; also the
-    PSNR of the GPU production path against it on that crop."""
+def cpu_baseline(workload, gpu_ctx, seconds_budget=14.0):
+    """Oracle timed on this box's host cores on a bounded sample of the same workload (the largest
+    crop of a 720p frame whose estimated time fits the budget, up to the whole frame); also the PSNR
+    of the GPU production path against the oracle on that sample."""
     from oracle import nets as onets
     from oracle import service as osvc
+    from tests.helpers import smooth_u8
     # many-core hosts oversubscribe small convs badly (256 threads: 285 s for a 96x160 crop); 16 is the sweet spot
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     if workload == "fsrcnn":
-        crop, table = (360, 640), W.fsrcnn_table(0)
-        model = lambda x: onets.fsrcnn(x, table, 2)
-        osv = osvc.OracleUpscaler(model, upscaler_model="fsrcnn", lr_shape=crop)
-        sr = _capi.Model(gpu_ctx, _capi.make_desc(_capi.FSRCNN, _capi.F32, scale=2), W.flatten(table, W.fsrcnn_keys()))
-        up = _capi.Upscaler(gpu_ctx, sr, crop, None, True, True, None, 1.0)
+        table = W.fsrcnn_table(0)
+        def make(crop):
+            osv = osvc.OracleUpscaler(lambda x: onets.fsrcnn(x, table, 2), upscaler_model="fsrcnn", lr_shape=crop)
+            sr = _capi.Model(gpu_ctx, _capi.make_desc(_capi.FSRCNN, _capi.F32, scale=2), W.flatten(table, W.fsrcnn_keys()))
+            return osv, _capi.Upscaler(gpu_ctx, sr, crop, None, True, True, None, 1.0), sr
     else:
-        crop, table = (96, 160), W.rrdbnet_table(0, scale=2)
-        model = lambda x: onets.rrdbnet(x, table, 2, 23)
-        osv = osvc.OracleUpscaler(model, upscaler_model="realesrgan", lr_shape=crop)
-        sr = _capi.Model(gpu_ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2), W.flatten(table, W.rrdbnet_keys(23)))
-        up = _capi.Upscaler(gpu_ctx, sr, crop, None, True, False, None, 1.0)
-    frames = synthetic_frames(1, crop, 123)
-    # smooth content for a meaningful PSNR
-    from tests.helpers import smooth_u8
-    frames = torch.from_numpy(smooth_u8(123, (1, crop[0], crop[1], 3)))
-    osv.upscale(frames)  # warm-up
-    t0 = time.perf_counter(); reps = 0
-    while True:
-        want = osv.upscale(frames); reps += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget * 0.5 or reps >= 5:
+        table = W.rrdbnet_table(0, scale=2)
+        flat = W.flatten(table, W.rrdbnet_keys(23))
+        def make(crop):
+            osv = osvc.OracleUpscaler(lambda x: onets.rrdbnet(x, table, 2, 23), upscaler_model="realesrgan", lr_shape=crop)
+            sr = _capi.Model(gpu_ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2), flat)
+            return osv, _capi.Upscaler(gpu_ctx, sr, crop, None, True, False, None, 1.0), sr
+    probe = (90, 160)
+    osv, _, _ = make(probe)
+    pf = torch.from_numpy(smooth_u8(7, (1, probe[0], probe[1], 3)))
+    osv.upscale(pf)
+    t0 = time.perf_counter(); osv.upscale(pf); t_probe = time.perf_counter() - t0
+    crop = probe
+    for cand in ((720, 1280), (360, 640), (180, 320)):
+        if t_probe * (cand[0] * cand[1]) / (probe[0] * probe[1]) <= seconds_budget:
+            crop = cand
             break
-    sec_per_crop = el / reps
+    osv, up, keep = make(crop)
+    frames = torch.from_numpy(smooth_u8(123, (1, crop[0], crop[1], 3)))
+    t0 = time.perf_counter(); want = osv.upscale(frames); sec = time.perf_counter() - t0
     frac = (crop[0] * crop[1]) / (720 * 1280)
     got = up(frames.cuda()).cpu()
     mse = torch.mean((got.double() - want.double()) ** 2).item()
     psnr = float("inf") if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
-    return {"value": frac / sec_per_crop, "unit": "frames/s (720p-frame equivalents)", "cores": torch.get_num_threads(),
+    return {"value": frac / sec, "unit": "frames/s (720p-frame equivalents)", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": f"oracle (PyTorch CPU fp32) on one {crop[0]}x{crop[1]} crop = {frac:.4f} of a 720p frame, "
-                      f"{reps} reps, {sec_per_crop:.2f} s each"}, psnr
+            "sample": f"oracle (PyTorch CPU fp32, {torch.get_num_threads()} threads) on one {crop[0]}x{crop[1]} frame crop "
+                      f"= {frac:.4f} of a 720p frame: {sec:.2f} s"}, psnr
 
 
 def main():
