@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--workload", default="rrdbnet", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the short secondary-workload measurements")
     args = ap.parse_args()
 
     rank, world, local = sharding.init_distributed()
@@ -210,6 +211,25 @@ def main():
             result["roofline"] = {"bound": "valu-fp32", "achieved": ach, "peak": F32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": ach / F32_VECTOR_PEAK_TFLOPS, "traffic": None,
                                   "kernel": "fsrcnn VALU kernels (whole-step average; no MFMA kernel in this workload)"}
+    if rank == 0 and not args.no_also and args.workload == "rrdbnet":
+        # the other single-GPU BASELINE configs, measured the same way (short, outside the headline timing)
+        also = {}
+        for wl in ("fsrcnn", "pipeline", "srvgg"):
+            up2, keep2, _ = build_upscaler(ctx, wl, device) if world == 1 else (None, None, None)
+            if up2 is None:
+                break
+            o2h, o2w = up2.out_shape(1, 720, 1280)
+            out2 = torch.empty((1, o2h, o2w, 3), dtype=torch.uint8, device=device)
+            f1 = frames[:1]
+            for _ in range(3):
+                up2(f1, out2)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(10):
+                up2(f1, out2)
+            torch.cuda.synchronize()
+            also[wl] = {"workload": WORKLOADS[wl], "fps": 10 / (time.perf_counter() - t1)}
+            del up2, keep2
+        result["also"] = also
     if rank == 0 and not args.no_cpu_baseline:
         cb, psnr = cpu_baseline(args.workload, ctx)
         result["cpu_baseline"] = cb

@@ -1,0 +1,123 @@
+"""Stream-mode caller of the upscaler service(s): the hot path's immediate neighbour.
+
+Restates what the reference's ``TwitchUpscalerPostStreamer`` does around the upscaler
+(``src/sharkshark/pipeline.py:61-149``), generalised from one GPU to G:
+
+* a recorder batch (1 s of frames) is cut into jobs of ``small_batch_size = min(4, fps)`` frames
+  (``pipeline.py:31,80-84``), each tagged with a monotonically increasing ``step``;
+* job ``step`` goes to service ``step % G`` with ``push_job_nowait``; a full queue drops the job
+  (frame-skip back-pressure, ``pipeline.py:103-108``) unless ``frame_skips=False``;
+* results come back per service in any interleaving and are re-ordered by ``step`` before they
+  are handed to the sink (the reference only warns on out-of-order steps, ``streamer.py:77-78``);
+* the sink gets ``'upscaler.upscale.per_frame_ms'`` and queue depths in the profiler
+  (``pipeline.py:140-149``).
+"""
+from __future__ import annotations
+
+import math
+import queue
+import time
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+
+from .upscale.upscaler_base import UpscalerQueueEntry
+from .util.profiler import Profiler
+
+
+class StreamDispatcher:
+    def __init__(self, services: Sequence, fps: int = 24, frame_skips: bool = True,
+                 on_result: Optional[Callable[[UpscalerQueueEntry], None]] = None, max_reorder: int = 64):
+        assert len(services) >= 1
+        self.services = list(services)
+        self.fps = fps
+        self.small_batch_size = min(4, int(fps))
+        self.frame_skips = frame_skips
+        self.on_result = on_result
+        self.frame_step = 0
+        self.next_emit = 0
+        self.dropped: List[int] = []
+        self._pending: Dict[int, UpscalerQueueEntry] = {}
+        self.max_reorder = max_reorder
+        self.last_reported = time.time()
+
+    # pipeline.py:61-108
+    def submit_batch(self, frames, audio_segment=None, profiler: Optional[Profiler] = None) -> List[int]:
+        """Cut one recorder batch into jobs and fan them out; returns the steps actually queued."""
+        assert self.small_batch_size != 0
+        profiler = profiler or Profiler()
+        njobs = math.ceil(len(frames) / self.small_batch_size)
+        queued = []
+        for i in range(njobs):
+            profiler.start("recoder.output.entry")
+            chunk = torch.as_tensor(frames[i * self.small_batch_size:(i + 1) * self.small_batch_size])
+            audio = None
+            if audio_segment is not None:
+                per = len(audio_segment) // njobs
+                audio = torch.as_tensor(audio_segment[i * per:(i + 1) * per])
+            step = self.frame_step
+            self.frame_step += 1
+            entry = UpscalerQueueEntry(frames=chunk, audio_segment=audio, step=step, profiler=profiler)
+            profiler.set("recoder.output.frames.shape", str(tuple(chunk.shape)))
+            profiler.end("recoder.output.entry")
+            svc = self.services[step % len(self.services)]
+            try:
+                if self.frame_skips:
+                    svc.push_job_nowait(entry)
+                else:
+                    svc.push_job(entry)
+                queued.append(step)
+            except queue.Full:
+                self.dropped.append(step)
+                print("StreamDispatcher: upscaler queue full, job skipped")
+        return queued
+
+    def _emit_ready(self, force: bool = False):
+        out = []
+        while True:
+            if self.next_emit in self._pending:
+                out.append(self._pending.pop(self.next_emit))
+                self.next_emit += 1
+            elif self.next_emit in self.dropped:
+                self.next_emit += 1
+            elif force and self._pending:
+                self.next_emit = min(self._pending)  # a step was lost downstream: do not stall the stream
+            else:
+                break
+        for e in out:
+            if e.profiler is not None and "upscaler.upscale" in e.profiler.data and e.frames is not None:
+                e.profiler.set("upscaler.upscale.per_frame_ms", e.profiler.data["upscaler.upscale"] / len(e.frames) * 1000)
+            if self.on_result is not None:
+                self.on_result(e)
+        return out
+
+    def poll(self, timeout: float = 0.0) -> List[UpscalerQueueEntry]:
+        """Collect finished jobs from every service and return those that can be emitted in order."""
+        deadline = time.time() + timeout
+        while True:
+            got_any = False
+            for svc in self.services:
+                try:
+                    e = svc.result_queue.get_nowait()
+                    self._pending[e.step] = e
+                    got_any = True
+                except queue.Empty:
+                    pass
+            ready = self._emit_ready(force=len(self._pending) > self.max_reorder)
+            if ready or time.time() >= deadline:
+                return ready
+            if not got_any:
+                time.sleep(0.001)
+
+    def drain(self, expected_steps: Sequence[int], timeout: float = 60.0) -> List[UpscalerQueueEntry]:
+        out, want = [], set(expected_steps)
+        deadline = time.time() + timeout
+        while want and time.time() < deadline:
+            for e in self.poll(timeout=0.05):
+                out.append(e)
+                want.discard(e.step)
+        return out
+
+    def report(self) -> dict:
+        return {"frame_step": self.frame_step, "dropped": len(self.dropped), "pending": len(self._pending),
+                "upscaler.inputq": [s.job_queue.qsize() for s in self.services]}
