@@ -32,16 +32,19 @@ namespace ss4k {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int TW = 32, NTHREADS = 256, IN_W = TW + 2;
+constexpr int TW = 32, IN_W = TW + 2;
 constexpr uint32_t OOB = 0xFFFFFFFFu;
 // Tile geometry for MB output rows per wave (4 waves): MB = 4 -> 16x32 tile, one workgroup per CU
 // (115/153 KB LDS); MB = 2 -> 8x32 tile, 80 KB LDS so TWO workgroups share a CU and one's epilogue /
 // barrier / DMA-wait time is covered by the other's MFMAs (used for the 32-cout layers).
-template <int MB> struct Geo {
-  static constexpr int TH = 4 * MB, IN_H = TH + 2, IN_PIX = IN_W * IN_H;
+// NW waves per workgroup: 8 waves (two per SIMD inside ONE workgroup) are used for the 64-cout build,
+// whose LDS footprint allows only one workgroup per CU: the second wave of a SIMD fills the first
+// one's LDS-latency / DMA-issue bubbles and halves each wave's share of the epilogue.
+template <int MB, int NW> struct Geo {
+  static constexpr int TH = NW * MB, IN_H = TH + 2, IN_PIX = IN_W * IN_H;
   static constexpr int TILE_SLOTS = IN_PIX * 4;            // 16-byte LDS slots per halo tile
   static constexpr int TILE_DMA = (TILE_SLOTS + 63) / 64;  // wave-level DMA instructions per tile
-  static constexpr int DMA_PER_WAVE = (TILE_DMA + 3) / 4;
+  static constexpr int DMA_PER_WAVE = (TILE_DMA + NW - 1) / NW;
 };
 
 template <typename T> struct Tr;
@@ -112,11 +115,12 @@ __device__ __forceinline__ f32x16 mma(const uint4& w, const uint4& x, f32x16 acc
 
 // GEN = false: only the plain-layout epilogue is compiled (every RRDBNet / SRVGG body layer);
 // GEN = true adds the stride-2 / PixelShuffle / NCHW / BSVD-residual / ReLU6 epilogues.
-template <typename T, int NB, int MB, int DBG, bool GEN>
-__global__ __launch_bounds__(NTHREADS, MB == 2 ? 2 : 1) void conv3x3_kernel(const ConvArgs a) {
+template <typename T, int NB, int MB, int NW, int DBG, bool GEN>
+__global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3_kernel(const ConvArgs a) {
   constexpr int CW = Tr<T>::CW;
-  constexpr int TH = Geo<MB>::TH, TILE_SLOTS = Geo<MB>::TILE_SLOTS, TILE_DMA = Geo<MB>::TILE_DMA;
-  constexpr int DMA_PER_WAVE = Geo<MB>::DMA_PER_WAVE;
+  using G = Geo<MB, NW>;
+  constexpr int TH = G::TH, TILE_SLOTS = G::TILE_SLOTS, TILE_DMA = G::TILE_DMA;
+  constexpr int DMA_PER_WAVE = G::DMA_PER_WAVE;
   constexpr int WSLOTS = 18 * NB * 64;  // weight slots per chunk
   constexpr int RV = (int)(16 * sizeof(T) / 16);  // uint4 per 16-channel group
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(NTHREADS, MB == 2 ? 2 : 1) void conv3x3_kernel(cons
   int plan[DMA_PER_WAVE];  // row | x << 8 | group*16 << 16 | valid << 31
 #pragma unroll
   for (int j = 0; j < DMA_PER_WAVE; ++j) {
-    const int s = (wave + 4 * j) * 64 + lane;
+    const int s = (wave + NW * j) * 64 + lane;
     const int p = s >> 2, gq = s & 3;
     const int row = p / IN_W, x = p - row * IN_W;
     plan[j] = (s < TILE_SLOTS) ? (row | (x << 8) | (((gq ^ ((x >> 2) & 3)) * 16) << 16)) : -1;
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(NTHREADS, MB == 2 ? 2 : 1) void conv3x3_kernel(cons
   // One K-chunk prefetch = NDMA wave-level DMA instructions per wave (halo tile, then weights).
   // They are not issued in a burst: dma_op(i) is called from slots spread through the MFMA stream
   // of the chunk being computed, so their issue cost hides under matrix-pipe time.
-  constexpr int NDMA_T = DMA_PER_WAVE, NDMA_W = (18 * NB + 3) / 4, NDMA = NDMA_T + NDMA_W;
+  constexpr int NDMA_T = DMA_PER_WAVE, NDMA_W = (18 * NB + NW - 1) / NW, NDMA = NDMA_T + NDMA_W;
   static_assert(NDMA <= 6 * MB, "not enough DMA slots in the MFMA stream");
   const char* pf_plane = nullptr; const char* pf_wsrc = nullptr;
   uint32_t pf_tdst = 0, pf_wdst = 0; bool pf_on = false;
@@ -196,14 +200,14 @@ __global__ __launch_bounds__(NTHREADS, MB == 2 ? 2 : 1) void conv3x3_kernel(cons
   auto dma_op = [&](int idx) {
     if (!pf_on) return;
     if (idx < NDMA_T) {
-      const int k = wave + 4 * idx;
+      const int k = wave + NW * idx;
       if (k < TILE_DMA && !(DBG & DBG_NO_TILE_DMA)) {
         const char* src = src_off[idx] != OOB ? pf_plane + src_off[idx] : a.zero_page + (lane & 3) * 16;
         const uint32_t dst = __builtin_amdgcn_readfirstlane(pf_tdst + k * 1024);
         if (plan[idx] >= 0) dma16(src, dst);  // lanes past the tile's last slot are masked off (EXEC)
       }
     } else if (idx < NDMA) {
-      const int k = wave + 4 * (idx - NDMA_T);
+      const int k = wave + NW * (idx - NDMA_T);
       if (k < 18 * NB && !(DBG & DBG_NO_W_DMA)) dma16(pf_wsrc + k * 1024, __builtin_amdgcn_readfirstlane(pf_wdst + k * 1024));
     }
   };
@@ -577,34 +581,32 @@ __global__ __launch_bounds__(NTHREADS, MB == 2 ? 2 : 1) void conv3x3_kernel(cons
   }
 }
 
-template <typename T, int NB, int MB, int DBG, bool GEN>
+template <typename T, int NB, int MB, int NW, int DBG, bool GEN>
 static void launch_t(ss4k_ctx* ctx, const ConvArgs& a0, int groups, hipStream_t st) {
-  constexpr size_t lds = (size_t)(2 * Geo<MB>::TILE_SLOTS + 2 * 18 * NB * 64) * 16 + NB * 32 * 2 * 4;
-  static_assert(lds <= (MB == 2 ? 80 : 160) * 1024, "LDS budget");
+  using G = Geo<MB, NW>;
+  constexpr size_t lds = (size_t)(2 * G::TILE_SLOTS + 2 * 18 * NB * 64) * 16 + NB * 32 * 2 * 4;
+  static_assert(lds <= ((MB == 2 && NW == 4) ? 80 : 160) * 1024, "LDS budget");
   ConvArgs a = a0;
-  a.tiles_y = (a.H + Geo<MB>::TH - 1) / Geo<MB>::TH;
+  a.tiles_y = (a.H + G::TH - 1) / G::TH;
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
   static bool attr_set = false;
   if (!attr_set) {
-    SS4K_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, NB, MB, DBG, GEN>),
+    SS4K_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, NB, MB, NW, DBG, GEN>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  const int per_cu = MB == 2 ? 2 : 1;
+  const int per_cu = (MB == 2 && NW == 4) ? 2 : 1;
   int gx = std::min(ntiles, std::max(1, ctx->num_cu * per_cu / groups));
-  hipLaunchKernelGGL((conv3x3_kernel<T, NB, MB, DBG, GEN>), dim3(gx, groups), dim3(NTHREADS), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_kernel<T, NB, MB, NW, DBG, GEN>), dim3(gx, groups), dim3(64 * NW), lds, st, a);
   SS4K_HIP(hipGetLastError());
 }
 
-template <int NB, int MB>
+template <int NB, int MB, int NW>
 static void launch_dbg(ss4k_ctx* ctx, const ConvArgs& a, int groups, hipStream_t st) {
-  switch (a.dbg & ~DBG_MB4) {  // ablation builds of the fp16 kernel for ss4k_bench_conv
-    case DBG_NO_EPILOGUE: launch_t<__half, NB, MB, DBG_NO_EPILOGUE, false>(ctx, a, groups, st); break;
-    case DBG_NO_TILE_DMA | DBG_NO_W_DMA | DBG_NO_EPILOGUE: launch_t<__half, NB, MB, DBG_NO_TILE_DMA | DBG_NO_W_DMA | DBG_NO_EPILOGUE, false>(ctx, a, groups, st); break;
-    case DBG_NO_MMA | DBG_NO_EPILOGUE: launch_t<__half, NB, MB, DBG_NO_MMA | DBG_NO_EPILOGUE, false>(ctx, a, groups, st); break;
-    case DBG_STAMP: launch_t<__half, NB, MB, DBG_STAMP, false>(ctx, a, groups, st); break;
-    case 0: launch_t<__half, NB, MB, 0, false>(ctx, a, groups, st); break;
-    default: throw Error(SS4K_EINVAL, "ss4k_bench_conv: unsupported ablation flags (0, 16, 28, 18, 32 [+64])");
+  switch (a.dbg & ~DBG_MB4) {  // instrumented builds of the fp16 kernel for ss4k_bench_conv
+    case DBG_STAMP: launch_t<__half, NB, MB, NW, DBG_STAMP, false>(ctx, a, groups, st); break;
+    case 0: launch_t<__half, NB, MB, NW, 0, false>(ctx, a, groups, st); break;
+    default: throw Error(SS4K_EINVAL, "ss4k_bench_conv: supported flags are 0 and 32 (phase stamps), optionally | 64 (4-wave 16-row tiles)");
   }
 }
 
@@ -624,21 +626,21 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
     else { SS4K_HIP(hipEventCreate(&pe.a)); SS4K_HIP(hipEventCreate(&pe.b)); }
     SS4K_HIP(hipEventRecord(pe.a, st));
   }
-  // 32-cout fp16 layers run the 8-row-tile build (two workgroups per CU); DBG_MB4 forces 16 rows
-  const bool mb2 = dtype == SS4K_F16 && nb == 1 && !(a.dbg & DBG_MB4);
+  // fp16: 32-cout layers run the 8-row-tile build (two workgroups per CU), 64-cout layers the
+  // 8-wave build (16-row tile, two waves per SIMD in one workgroup); DBG_MB4 forces 4 waves x 4 rows
+  const bool alt = dtype == SS4K_F16 && !(a.dbg & DBG_MB4);
   if (a.dbg) {
-    SS4K_REQUIRE(dtype == SS4K_F16, "ablation builds exist for fp16 only");
-    if (nb == 1) { if (mb2) launch_dbg<1, 2>(ctx, a, groups, st); else launch_dbg<1, 4>(ctx, a, groups, st); }
-    else launch_dbg<2, 4>(ctx, a, groups, st);
+    SS4K_REQUIRE(dtype == SS4K_F16, "instrumented builds exist for fp16 only");
+    if (nb == 1) { if (alt) launch_dbg<1, 2, 4>(ctx, a, groups, st); else launch_dbg<1, 4, 4>(ctx, a, groups, st); }
+    else { if (alt) launch_dbg<2, 2, 8>(ctx, a, groups, st); else launch_dbg<2, 4, 4>(ctx, a, groups, st); }
   } else {
     const bool gen = !(a.epi == EPI_NHWC && !a.bsvd_resid);
     if (dtype == SS4K_F16) {
-      if (mb2) { if (gen) launch_t<__half, 1, 2, 0, true>(ctx, a, groups, st); else launch_t<__half, 1, 2, 0, false>(ctx, a, groups, st); }
-      else if (nb == 1) { if (gen) launch_t<__half, 1, 4, 0, true>(ctx, a, groups, st); else launch_t<__half, 1, 4, 0, false>(ctx, a, groups, st); }
-      else { if (gen) launch_t<__half, 2, 4, 0, true>(ctx, a, groups, st); else launch_t<__half, 2, 4, 0, false>(ctx, a, groups, st); }
+      if (nb == 1) { if (gen) launch_t<__half, 1, 2, 4, 0, true>(ctx, a, groups, st); else launch_t<__half, 1, 2, 4, 0, false>(ctx, a, groups, st); }
+      else { if (gen) launch_t<__half, 2, 2, 8, 0, true>(ctx, a, groups, st); else launch_t<__half, 2, 2, 8, 0, false>(ctx, a, groups, st); }
     } else {
-      if (nb == 1) { if (gen) launch_t<float, 1, 4, 0, true>(ctx, a, groups, st); else launch_t<float, 1, 4, 0, false>(ctx, a, groups, st); }
-      else { if (gen) launch_t<float, 2, 4, 0, true>(ctx, a, groups, st); else launch_t<float, 2, 4, 0, false>(ctx, a, groups, st); }
+      if (nb == 1) { if (gen) launch_t<float, 1, 4, 4, 0, true>(ctx, a, groups, st); else launch_t<float, 1, 4, 4, 0, false>(ctx, a, groups, st); }
+      else { if (gen) launch_t<float, 2, 4, 4, 0, true>(ctx, a, groups, st); else launch_t<float, 2, 4, 4, 0, false>(ctx, a, groups, st); }
     }
   }
   if (ctx->prof) {

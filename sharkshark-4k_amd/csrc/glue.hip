@@ -234,30 +234,42 @@ void op_f32nchw_to_u8nhwc(const float* in, uint8_t* out, int n, int c, int h, in
 // NCHW fp32 -> "planes" T (conv_mfma.hip): channel k lives in plane k / CW at offset k % CW of the
 // pixel's 64-byte record; optional pixel-unshuffle(r) (RRDBNet x2/x1 front end, basicsr
 // pixel_unshuffle: channel = c*r*r + dy*r + dx); unused channels of the last plane are zeroed.
-template <typename T>
-__global__ void k_pack_input(const float* __restrict__ in, T* __restrict__ out, int n, int c, int h, int w, int r,
+template <typename T, int R>
+__global__ void k_pack_input(const float* __restrict__ in, T* __restrict__ out, int n, int c, int h, int w,
                              int nplanes) {
   constexpr int CW = 64 / sizeof(T);
-  const int oh = h / r, ow = w / r;
+  const int oh = h / R, ow = w / R;
   const size_t total = (size_t)n * oh * ow;
-  const int creal = c * r * r;
+  const int creal = c * R * R;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int ox = i % ow, oy = (i / ow) % oh;
     const size_t img = i / ((size_t)ow * oh);
-    for (int k = 0; k < nplanes * CW; ++k) {
-      float v = 0.f;
-      if (k < creal) {
-        const int ci = k / (r * r), rem = k - ci * r * r, dy = rem / r, dx = rem - dy * r;
-        v = in[((img * c + ci) * h + (size_t)oy * r + dy) * w + (size_t)ox * r + dx];
+    for (int p = 0; p < nplanes; ++p) {
+      T rec[CW];  // one 64-byte record, written with four 16-byte stores
+#pragma unroll
+      for (int q = 0; q < CW; ++q) {
+        const int k = p * CW + q;
+        float v = 0.f;
+        if (k < creal) {
+          const int ci = k / (R * R), rem = k % (R * R), dy = rem / R, dx = rem % R;
+          v = in[((img * c + ci) * h + (size_t)oy * R + dy) * w + (size_t)ox * R + dx];
+        }
+        rec[q] = (T)v;
       }
-      out[((size_t)(k / CW) * total + i) * CW + (k % CW)] = (T)v;
+      uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)p * total + i) * CW);
+      const uint4* src = reinterpret_cast<const uint4*>(rec);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dst[q] = src[q];
     }
   }
 }
 template <typename T>
 void op_pack_input(const float* in, T* out, int n, int c, int h, int w, int r, int nplanes, hipStream_t st) {
-  hipLaunchKernelGGL((k_pack_input<T>), grid1d((size_t)n * (h / r) * (w / r)), dim3(256), 0, st, in, out, n, c, h, w,
-                     r, nplanes);
+  const dim3 g = grid1d((size_t)n * (h / r) * (w / r));
+  if (r == 1) hipLaunchKernelGGL((k_pack_input<T, 1>), g, dim3(256), 0, st, in, out, n, c, h, w, nplanes);
+  else if (r == 2) hipLaunchKernelGGL((k_pack_input<T, 2>), g, dim3(256), 0, st, in, out, n, c, h, w, nplanes);
+  else if (r == 4) hipLaunchKernelGGL((k_pack_input<T, 4>), g, dim3(256), 0, st, in, out, n, c, h, w, nplanes);
+  else throw Error(SS4K_EINVAL, "pack_input: unshuffle factor must be 1, 2 or 4");
 }
 template void op_pack_input<float>(const float*, float*, int, int, int, int, int, int, hipStream_t);
 template void op_pack_input<__half>(const float*, __half*, int, int, int, int, int, int, hipStream_t);
