@@ -235,3 +235,45 @@ def test_rrdbnet_720p_fp16_vs_fp32_psnr(ctx):
     with torch.no_grad():
         want = onets.rrdbnet(xs, t2, 2, 2)
     assert_close(ms(xs.cuda()), want, what="rrdbnet crop")
+
+
+# ------------------------------------------------------------------------------ drop-in service, worker process on the GPU
+def test_hip_service_worker_process_roundtrip():
+    """HipUpscalerService behind the reference's queue API: start() spawns the worker, frames go in as
+    device tensors inside UpscalerQueueEntry, upscaled uint8 frames come back; checked against the oracle."""
+    from sharkshark4k_amd.upscale.hip_upscaler import HipUpscalerService
+    from sharkshark4k_amd.upscale.upscaler_base import UpscalerQueueEntry
+    from sharkshark4k_amd.util import Profiler
+    table = W.fsrcnn_table(seed=2)
+    svc = HipUpscalerService(device=0, denoising=False, upscaler_model="fsrcnn", scale=2, lr_shape=(36, 52),
+                             weights={"sr": table})
+    svc.start()
+    try:
+        frames = torch.from_numpy(smooth_u8(45, (2, 36, 52, 3)))
+        for step in (0, 1):
+            svc.push_job(UpscalerQueueEntry(frames=frames, step=step, profiler=Profiler()), timeout=60)
+        res = [svc.get_result(timeout=180) for _ in range(2)]
+        assert [r.step for r in res] == [0, 1]
+        got = res[0].frames.cpu()
+        assert got.shape == (2, 72, 104, 3) and got.dtype == torch.uint8
+        osv = osvc.OracleUpscaler(lambda x: onets.fsrcnn(x, table, 2), upscaler_model="fsrcnn", lr_shape=(36, 52))
+        assert_u8_close(got, osv.upscale(frames), what="service roundtrip")
+        assert "upscaler.upscale" in res[0].profiler.data and res[0].elapsed > 0
+    finally:
+        svc.stop()
+    assert not svc.proc.is_alive()
+
+
+def test_rrdbnet_x4_1080p_runs(ctx):
+    """BASELINE config 5 shape on one GPU: RRDBNet x4 (6 blocks to bound the time), 1080p -> 4320x7680,
+    bicubic to 2160x3840 through the batched service path; output statistics must be sane."""
+    table = W.rrdbnet_table(2, scale=4, num_block=6)
+    sr = factory.build_model_esrgan(ctx, "RealESRGAN_x4plus_anime_6B", weights=table, dtype="f16")
+    up = _capi.Upscaler(ctx, sr, (1080, 1920), (2160, 3840), True, False, None, 1.0)
+    frames = torch.from_numpy(smooth_u8(9, (1, 1080, 1920, 3))).cuda()
+    out = up(frames)
+    assert out.shape == (1, 2160, 3840, 3) and out.dtype == torch.uint8
+    # mean/std matching forces the output statistics onto the input's (fsrcnn_upscaler.py:188-199)
+    fi, fo = frames.float(), out.float()
+    assert abs(float(fi.mean()) - float(fo.mean())) < 2.0
+    assert abs(float(fi.std()) - float(fo.std())) < 6.0
