@@ -1,8 +1,9 @@
 // FSRCNN forward (reference src/upscale/model/fsrcnn/model.py:14-62) on fp32 planes.
 // Channel depths are 1 / 56 / 12, far too shallow for a dense MFMA contraction, so these are
 // direct convolutions on the vector ALUs: one thread per low-resolution pixel holds every output
-// channel in registers, weights are wave-uniform (scalar loads), activations are NHWC fp32 so a
-// pixel's channels are contiguous 16-byte loads.  Layers are fused where no halo is needed:
+// channel in registers, weights are wave-uniform (scalar loads), activations are stored as groups of
+// four channels, group-major ([C/4][pixel][4] fp32), so a wave's 16-byte loads/stores of one group are
+// one contiguous kilobyte whatever the channel count.  Layers are fused where no halo is needed:
 //   head  = conv5x5(1->56)+PReLU -> conv1x1(56->12)+PReLU        (56-wide map never leaves registers)
 //   map   = conv3x3(12->12)+PReLU                                 (x4)
 //   tail  = conv1x1(12->56)+PReLU                                 (NHWC 56 for the deconv gather)
@@ -47,11 +48,11 @@ __global__ __launch_bounds__(256) void k_fs_head(const float* __restrict__ in, f
   for (int c = 0; c < 56; ++c)
 #pragma unroll
     for (int j = 0; j < 12; ++j) s[j] = fmaf(ws[c * 12 + j], f[c], s[j]);
-  float4* dst = reinterpret_cast<float4*>(out + i * 12);
+  float4* dst = reinterpret_cast<float4*>(out);
 #pragma unroll
   for (int q = 0; q < 3; ++q)
-    dst[q] = make_float4(prelu(s[4 * q], as[4 * q]), prelu(s[4 * q + 1], as[4 * q + 1]),
-                         prelu(s[4 * q + 2], as[4 * q + 2]), prelu(s[4 * q + 3], as[4 * q + 3]));
+    dst[q * total + i] = make_float4(prelu(s[4 * q], as[4 * q]), prelu(s[4 * q + 1], as[4 * q + 1]),
+                                     prelu(s[4 * q + 2], as[4 * q + 2]), prelu(s[4 * q + 3], as[4 * q + 3]));
 }
 
 __global__ __launch_bounds__(256) void k_fs_map(const float* __restrict__ in, float* __restrict__ out,
@@ -72,20 +73,20 @@ __global__ __launch_bounds__(256) void k_fs_map(const float* __restrict__ in, fl
     for (int kx = 0; kx < 3; ++kx) {
       const int xx = x + kx - 1;
       if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
-      const float4* p = reinterpret_cast<const float4*>(in + (pbase + (size_t)yy * w + xx) * 12);
+      const float4* p = reinterpret_cast<const float4*>(in) + pbase + (size_t)yy * w + xx;
       float v[12];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) { const float4 t = p[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+      for (int q = 0; q < 3; ++q) { const float4 t = p[q * total]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
 #pragma unroll
       for (int c = 0; c < 12; ++c)
 #pragma unroll
         for (int j = 0; j < 12; ++j) s[j] = fmaf(wm[((ky * 3 + kx) * 12 + c) * 12 + j], v[c], s[j]);
     }
   }
-  float4* dst = reinterpret_cast<float4*>(out + i * 12);
+  float4* dst = reinterpret_cast<float4*>(out) + i;
 #pragma unroll
   for (int q = 0; q < 3; ++q)
-    dst[q] = make_float4(prelu(s[4 * q], am[4 * q]), prelu(s[4 * q + 1], am[4 * q + 1]),
+    dst[q * total] = make_float4(prelu(s[4 * q], am[4 * q]), prelu(s[4 * q + 1], am[4 * q + 1]),
                          prelu(s[4 * q + 2], am[4 * q + 2]), prelu(s[4 * q + 3], am[4 * q + 3]));
 }
 
@@ -94,11 +95,11 @@ __global__ __launch_bounds__(256) void k_fs_expand(const float* __restrict__ in,
                                                    const float* __restrict__ ae, size_t total) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const float4* p = reinterpret_cast<const float4*>(in + i * 12);
+  const float4* p = reinterpret_cast<const float4*>(in) + i;
   float v[12];
 #pragma unroll
-  for (int q = 0; q < 3; ++q) { const float4 t = p[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
-  float4* dst = reinterpret_cast<float4*>(out + i * 56);
+  for (int q = 0; q < 3; ++q) { const float4 t = p[q * total]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+  float4* dst = reinterpret_cast<float4*>(out) + i;
 #pragma unroll
   for (int q = 0; q < 14; ++q) {
     float o[4];
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void k_fs_expand(const float* __restrict__ in,
       for (int k = 0; k < 12; ++k) s = fmaf(we[k * 56 + c], v[k], s);
       o[e] = prelu(s, ae[c]);
     }
-    dst[q] = make_float4(o[0], o[1], o[2], o[3]);
+    dst[q * total] = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -118,6 +119,11 @@ template <int S>
 __global__ __launch_bounds__(256) void k_fs_deconv(const float* __restrict__ in, float* __restrict__ out,
                                                    const float* __restrict__ wd, float bias, int planes, int h,
                                                    int w) {
+  // the 81x56 taps (18 KB) overflow the 16 KB scalar cache when read as wave-uniform scalars (every
+  // s_load then misses to L2): keep them in LDS and read them as broadcasts instead
+  __shared__ float4 w_lds[81 * 14];
+  for (int k = threadIdx.x; k < 81 * 14; k += blockDim.x) w_lds[k] = reinterpret_cast<const float4*>(wd)[k];
+  __syncthreads();
   const size_t total = (size_t)planes * h * w;
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -138,10 +144,10 @@ __global__ __launch_bounds__(256) void k_fs_deconv(const float* __restrict__ in,
     for (int dx = -2; dx <= 2; ++dx) {
       const int xx = x + dx;
       if (xx < 0 || xx >= w) continue;
-      const float4* p = reinterpret_cast<const float4*>(in + (pbase + (size_t)yy * w + xx) * 56);
+      const float4* p = reinterpret_cast<const float4*>(in) + pbase + (size_t)yy * w + xx;
       float4 v[14];
 #pragma unroll
-      for (int q = 0; q < 14; ++q) v[q] = p[q];
+      for (int q = 0; q < 14; ++q) v[q] = p[q * total];
 #pragma unroll
       for (int py = 0; py < S; ++py) {
         const int ky = py + 4 - S * dy;
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(256) void k_fs_deconv(const float* __restrict__ in,
         for (int px = 0; px < S; ++px) {
           const int kx = px + 4 - S * dx;
           if (kx < 0 || kx > 8) continue;
-          const float4* wv = reinterpret_cast<const float4*>(wd + (ky * 9 + kx) * 56);
+          const float4* wv = w_lds + (ky * 9 + kx) * 14;
           float s = acc[py][px];
 #pragma unroll
           for (int q = 0; q < 14; ++q) {
