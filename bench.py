@@ -129,7 +129,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=4,
+                    help="frames per step per GPU; 4 = the reference's stream-mode job size, small_batch_size = "
+                         "min(4, fps) (src/sharkshark/pipeline.py:31,84), which is also what its README figure uses")
     ap.add_argument("--workload", default="rrdbnet", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
