@@ -138,8 +138,7 @@ struct Upscaler {
       const size_t plane = (size_t)lh * lw;
       lr4.ensure(plane * 4 * 4); den.ensure(plane * 3 * 4 * 2);
       SS4K_HIP(hipMemcpyAsync(lr4.ptr, lr_before, plane * 3 * 4, hipMemcpyDeviceToDevice, st));
-      std::vector<float> dummy;
-      // constant noise-map plane: write via a 1-tap "depthwise" would be overkill; use memset-like fill
+      // constant noise-map plane (fsrcnn_upscaler.py:262,269-271)
       fill_plane(lr4.as<float>() + plane * 3, plane, noise, st);
       float* den0 = den.as<float>(); float* den1 = den0 + plane * 3;
       dn->forward(lr4.as<float>(), den0, 1, lh, lw, st);

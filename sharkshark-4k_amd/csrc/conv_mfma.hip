@@ -246,6 +246,7 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
   dma_wait();
   __syncthreads();
   int buf = 0;
+  const unsigned long long st_pro = stamp() - st_begin;
 
   struct Frags { uint4 wf[3][NB]; uint4 af[MB + 2]; };
 
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
     if (tid == 0 && a.dbg_buf) {
       unsigned long long* o = a.dbg_buf + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;
       o[0] = st_end - st_begin; o[1] = st_dma; o[2] = st_mma; o[3] = st_epi; o[4] = st_bar; o[5] = kt + 1;
-      o[6] = __builtin_amdgcn_s_memrealtime(); o[7] = st_store;
+      o[6] = st_pro; o[7] = st_store;
     }
   }
 }

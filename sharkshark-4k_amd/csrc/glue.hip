@@ -28,8 +28,6 @@ void op_u8nhwc_to_f32nchw(const uint8_t* in, float* out, int n, int h, int w, in
 }
 
 // ------------------------------------------------------------------ area (adaptive average pool)
-struct Affine { const float* stats_hr; const float* stats_lr; int planes_per_img; };
-
 __device__ __forceinline__ int a_start(int i, int in, int out) { return (int)floorf((float)(i * in) / out); }
 __device__ __forceinline__ int a_end(int i, int in, int out) { return (int)ceilf((float)((i + 1) * in) / out); }
 

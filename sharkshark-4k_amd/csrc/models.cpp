@@ -269,6 +269,21 @@ void Model::pack_in(const float* in, const Tens& dst, int nplanes, int n, int c,
 void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_t st) {
   SS4K_REQUIRE(n > 0 && h > 0 && w > 0, "forward: empty input");
   const bool f16 = desc.dtype == SS4K_F16;
+  if (desc.kind != SS4K_FSRCNN) {
+    // the conv kernel addresses a plane with 32-bit byte offsets: split batches whose largest
+    // internal tensor (at output resolution) would exceed 4 GiB per plane (e.g. 4 frames at 4320x7680)
+    int oc, oh, ow; out_shape(1, h, w, &oc, &oh, &ow);
+    const double plane1 = (double)std::max(oh, h) * std::max(ow, w) * 64.0;
+    SS4K_REQUIRE(plane1 < 4294967296.0, "forward: a single frame exceeds the 4 GiB plane limit");
+    const int max_n = std::max(1, (int)(4294967295.0 / plane1));
+    if (n > max_n) {
+      for (int i = 0; i < n; i += max_n) {
+        const int nn = std::min(max_n, n - i);
+        forward(in + (size_t)i * in_channels() * h * w, out + (size_t)i * oc * oh * ow, nn, h, w, st);
+      }
+      return;
+    }
+  }
   if (desc.kind == SS4K_FSRCNN) {
     const size_t px = (size_t)n * h * w;
     if (acts.size() < 3) acts.resize(3);
@@ -404,10 +419,10 @@ double bench_conv_layer(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, 
   if (flags & DBG_STAMP) {  // print the phase breakdown of the last launch (wave 0 of every workgroup)
     std::vector<unsigned long long> h((size_t)1024 * 8);
     SS4K_HIP(hipMemcpy(h.data(), m.dbg_buf, h.size() * 8, hipMemcpyDeviceToHost));
-    double tot = 0, dma = 0, mma = 0, epi = 0, bar = 0, tiles = 0, sto = 0; int nwg = 0;
-    for (int i = 0; i < 1024; ++i) if (h[i * 8 + 5]) { tot += h[i*8]; dma += h[i*8+1]; mma += h[i*8+2]; epi += h[i*8+3]; bar += h[i*8+4]; tiles += h[i*8+5]; sto += h[i*8+7]; ++nwg; }
-    if (nwg) fprintf(stderr, "[stamp] %d WGs, avg tiles %.2f, cycles(100MHz ticks?) total %.0f  issue %.0f  mma %.0f  epilogue %.0f (stores %.0f)  barrier %.0f\n",
-                     nwg, tiles / nwg, tot / nwg, dma / nwg, mma / nwg, epi / nwg, sto / nwg, bar / nwg);
+    double tot = 0, dma = 0, mma = 0, epi = 0, bar = 0, tiles = 0, sto = 0, pro = 0; int nwg = 0;
+    for (int i = 0; i < 1024; ++i) if (h[i * 8 + 5]) { tot += h[i*8]; dma += h[i*8+1]; mma += h[i*8+2]; epi += h[i*8+3]; bar += h[i*8+4]; tiles += h[i*8+5]; sto += h[i*8+7]; pro += h[i*8+6]; ++nwg; }
+    if (nwg) fprintf(stderr, "[stamp] %d WGs, avg tiles %.2f, cycles(100MHz ticks?) total %.0f  issue %.0f  mma %.0f  epilogue %.0f (stores %.0f)  barrier %.0f  prologue %.0f\n",
+                     nwg, tiles / nwg, tot / nwg, dma / nwg, mma / nwg, epi / nwg, sto / nwg, bar / nwg, pro / nwg);
   }
   dbgb.release();
   return 1000.0 * ms / iters;

@@ -270,9 +270,11 @@ def test_rrdbnet_x4_1080p_runs(ctx):
     table = W.rrdbnet_table(2, scale=4, num_block=6)
     sr = factory.build_model_esrgan(ctx, "RealESRGAN_x4plus_anime_6B", weights=table, dtype="f16")
     up = _capi.Upscaler(ctx, sr, (1080, 1920), (2160, 3840), True, False, None, 1.0)
-    frames = torch.from_numpy(smooth_u8(9, (1, 1080, 1920, 3))).cuda()
+    # 3 frames: a 4320x7680 plane is 2.1 GB, so the library has to split this batch (2 + 1) internally
+    frames = torch.from_numpy(smooth_u8(9, (3, 1080, 1920, 3))).cuda()
     out = up(frames)
-    assert out.shape == (1, 2160, 3840, 3) and out.dtype == torch.uint8
+    assert out.shape == (3, 2160, 3840, 3) and out.dtype == torch.uint8
+    assert torch.equal(up(frames[2:3])[0], out[2])  # batch splitting does not change a frame's result
     # mean/std matching forces the output statistics onto the input's (fsrcnn_upscaler.py:188-199)
     fi, fo = frames.float(), out.float()
     assert abs(float(fi.mean()) - float(fo.mean())) < 2.0
