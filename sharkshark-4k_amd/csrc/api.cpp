@@ -59,15 +59,6 @@ struct Upscaler {
     SS4K_HIP(hipMemcpyAsync(tap[which].ptr, src, bytes, hipMemcpyDeviceToDevice, st));
     tap_dims[which][0] = n; tap_dims[which][1] = c; tap_dims[which][2] = h; tap_dims[which][3] = w;
   }
-  void append_tap(int which, const float* src, int idx, int n, int c, int h, int w, hipStream_t st) {
-    // single mode: frames are processed one by one; taps are stacked to (n,c,h,w)
-    if (!taps_on) return;
-    const size_t per = (size_t)c * h * w * 4;
-    if (idx == 0) tap[which].ensure(per * n);
-    SS4K_HIP(hipMemcpyAsync((char*)tap[which].ptr + per * idx, src, per, hipMemcpyDeviceToDevice, st));
-    tap_dims[which][0] = n; tap_dims[which][1] = c; tap_dims[which][2] = h; tap_dims[which][3] = w;
-  }
-
   void out_shape(int h, int w, int* oh, int* ow) const {
     int lh = h, lw = w;
     if (cfg.single_mode) { lh = cfg.lr_h; lw = cfg.lr_w; }
@@ -123,56 +114,60 @@ struct Upscaler {
     op_f32nchw_to_u8nhwc(fin, out, n, 3, FH, FW, st);
   }
 
-  // fsrcnn_upscaler.py:235-326, one frame
-  void single(const uint8_t* in, int idx, int n, int h, int w, uint8_t* out, hipStream_t st) {
-    const int lh = cfg.lr_h, lw = cfg.lr_w;
-    img.ensure((size_t)3 * h * w * 4);
-    op_u8nhwc_to_f32nchw(in, img.as<float>(), 1, h, w, 3, st);
-    lr.ensure((size_t)3 * lh * lw * 4);
-    op_area(img.as<float>(), lr.as<float>(), 3, h, w, lh, lw, st);  // unconditional in this path (:239-241)
+  // fsrcnn_upscaler.py:235-326.  The reference loops frame by frame in Python (:158-161); every
+  // frame is independent (BSVD sees F = 1, only the noise-map level differs for the very first frame
+  // of the stream), so the n frames of a job are pushed through each stage as one batch.
+  void single(const uint8_t* in, int n, int h, int w, uint8_t* out, hipStream_t st) {
+    const int lh = cfg.lr_h, lw = cfg.lr_w, P = 3 * n;
+    const size_t plane = (size_t)lh * lw;
+    img.ensure((size_t)P * h * w * 4);
+    op_u8nhwc_to_f32nchw(in, img.as<float>(), n, h, w, 3, st);
+    lr.ensure(plane * P * 4);
+    op_area(img.as<float>(), lr.as<float>(), P, h, w, lh, lw, st);  // unconditional in this path (:239-241)
     const float* lr_before = lr.as<float>();
     const float* lr_cur = lr_before;
     if (cfg.denoising) {
-      const float noise = first_frame ? 0.05f : (float)(0.1 * cfg.denoise_rate);  // :262, :269-271
-      first_frame = false;
-      const size_t plane = (size_t)lh * lw;
-      lr4.ensure(plane * 4 * 4); den.ensure(plane * 3 * 4 * 2);
-      SS4K_HIP(hipMemcpyAsync(lr4.ptr, lr_before, plane * 3 * 4, hipMemcpyDeviceToDevice, st));
-      // constant noise-map plane (fsrcnn_upscaler.py:262,269-271)
-      fill_plane(lr4.as<float>() + plane * 3, plane, noise, st);
-      float* den0 = den.as<float>(); float* den1 = den0 + plane * 3;
-      dn->forward(lr4.as<float>(), den0, 1, lh, lw, st);
+      lr4.ensure(plane * 4 * n * 4); den.ensure(plane * P * 4 * 2);
+      for (int i = 0; i < n; ++i) {
+        const float noise = first_frame ? 0.05f : (float)(0.1 * cfg.denoise_rate);  // :262, :269-271
+        first_frame = false;
+        float* dst = lr4.as<float>() + plane * 4 * i;
+        SS4K_HIP(hipMemcpyAsync(dst, lr_before + plane * 3 * i, plane * 3 * 4, hipMemcpyDeviceToDevice, st));
+        fill_plane(dst + plane * 3, plane, noise, st);  // constant noise-map plane
+      }
+      float* den0 = den.as<float>(); float* den1 = den0 + plane * P;
+      dn->forward(lr4.as<float>(), den0, n, lh, lw, st);
       // clamp(sharpen(den)) * 0.8 + 0.2 * lr   (:279-281)
-      op_depthwise_reflect(den0, den1, k_sharp.as<float>(), 3, lh, lw, 3, 1, lr_before, 0.8f, (float)(1 - 0.8), st);
+      op_depthwise_reflect(den0, den1, k_sharp.as<float>(), P, lh, lw, 3, 1, lr_before, 0.8f, (float)(1 - 0.8), st);
       lr_cur = den1;
     }
-    append_tap(0, lr_cur, idx, n, 3, lh, lw, st);
+    save_tap(0, lr_cur, n, 3, lh, lw, st);
     int oc, H, W; sr->out_shape(1, lh, lw, &oc, &H, &W);
-    hr.ensure((size_t)3 * H * W * 4 * 2);
+    hr.ensure((size_t)P * H * W * 4 * 2);
     float* hrp = hr.as<float>();
-    if (cfg.sr_is_realesrgan) sr->forward(lr_cur, hrp, 1, lh, lw, st);
-    else sr->forward(lr_cur, hrp, 3, lh, lw, st);  // FSRCNN on the three colour planes (:297)
+    if (cfg.sr_is_realesrgan) sr->forward(lr_cur, hrp, n, lh, lw, st);
+    else sr->forward(lr_cur, hrp, P, lh, lw, st);  // FSRCNN on the colour planes (:297)
     if (cfg.denoising) {
-      float* hs = hrp + (size_t)3 * H * W;
-      op_depthwise_reflect(hrp, hs, k_sharp_hr.as<float>(), 3, H, W, 3, 1, nullptr, 0, 0, st);  // :298-299
+      float* hs = hrp + (size_t)P * H * W;
+      op_depthwise_reflect(hrp, hs, k_sharp_hr.as<float>(), P, H, W, 3, 1, nullptr, 0, 0, st);  // :298-299
       hrp = hs;
     }
-    append_tap(1, hrp, idx, n, 3, H, W, st);
-    st_hr.ensure(3 * 8); st_lr.ensure(3 * 8);
-    op_plane_stats(ctx, hrp, st_hr.as<float>(), 3, H * W, st);
-    op_plane_stats(ctx, lr_before, st_lr.as<float>(), 3, lh * lw, st);
-    op_normalize(hrp, st_hr.as<float>(), st_lr.as<float>(), 3, H * W, st);
-    append_tap(2, hrp, idx, n, 3, H, W, st);
-    op_clamp01(hrp, (size_t)3 * H * W, st);
+    save_tap(1, hrp, n, 3, H, W, st);
+    st_hr.ensure(P * 8); st_lr.ensure(P * 8);
+    op_plane_stats(ctx, hrp, st_hr.as<float>(), P, H * W, st);
+    op_plane_stats(ctx, lr_before, st_lr.as<float>(), P, lh * lw, st);
+    op_normalize(hrp, st_hr.as<float>(), st_lr.as<float>(), P, H * W, st);
+    save_tap(2, hrp, n, 3, H, W, st);
+    op_clamp01(hrp, (size_t)P * H * W, st);
     const float* fin = hrp; int FH = H, FW = W;
     if (cfg.out_h > 0) {
       FH = cfg.out_h; FW = cfg.out_w;
-      hr2.ensure((size_t)3 * FH * FW * 4);
-      op_bicubic(hrp, hr2.as<float>(), 3, H, W, FH, FW, 1, st);
+      hr2.ensure((size_t)P * FH * FW * 4);
+      op_bicubic(hrp, hr2.as<float>(), P, H, W, FH, FW, 1, st);
       fin = hr2.as<float>();
     }
-    append_tap(4, fin, idx, n, 3, FH, FW, st);
-    op_f32nchw_to_u8nhwc(fin, out, 1, 3, FH, FW, st);
+    save_tap(4, fin, n, 3, FH, FW, st);
+    op_f32nchw_to_u8nhwc(fin, out, n, 3, FH, FW, st);
   }
 
   static void fill_plane(float* p, size_t n, float v, hipStream_t st) {
@@ -285,7 +280,7 @@ int ss4k_upscale_frames(ss4k_upscaler* up, const uint8_t* in, int n, int h, int 
     SS4K_REQUIRE(cap >= per * n, "ss4k_upscale_frames: output buffer too small");
     hipStream_t st = (hipStream_t)stream;
     if (up->u.cfg.single_mode) {
-      for (int i = 0; i < n; ++i) up->u.single(in + (size_t)i * h * w * 3, i, n, h, w, out + per * i, st);
+      up->u.single(in, n, h, w, out, st);
     } else {
       up->u.multi(in, n, h, w, out, st);
     }
