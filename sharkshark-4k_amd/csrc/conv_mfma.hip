@@ -300,6 +300,7 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
         // the 3*MB (input row, dy) pairs of one group; after every third MFMA (x NB) one DMA
         // instruction of the prefetch is issued
         int m = 0;
+        __builtin_amdgcn_s_setprio(1);  // keep this wave's MFMA burst together while its SIMD partner loads
 #pragma unroll
         for (int ir = 0; ir < MB + 2; ++ir)
 #pragma unroll
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
               ++m;
             }
           }
+        __builtin_amdgcn_s_setprio(0);
       };
       if constexpr ((DBG & DBG_NO_MMA) != 0) {
 #pragma unroll
