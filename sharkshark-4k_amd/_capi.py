@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libss4k_hip.so")
+LIB_PATH = os.environ.get("SS4K_LIB") or os.path.join(_HERE, "libss4k_hip.so")  # override = A/B builds
 
 FSRCNN, RRDBNET, SRVGG, BSVD = 1, 2, 3, 4
 F32, F16 = 0, 1
