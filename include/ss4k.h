@@ -56,7 +56,10 @@ typedef struct ss4k_model_desc {
   int32_t bsvd_chns[3];/* BSVD U-Net widths (32,64,128) */
   int32_t bsvd_mid_ch; /* 32 */
   int32_t bsvd_interm_ch; /* 30 */
-  int32_t reserved[5];
+  int32_t bsvd_stream; /* 0: every frame of a forward call is independent - how the service drives BSVD
+                          (F = 1, fsrcnn_upscaler.py:277); 1: the n frames of one ss4k_model_forward call are ONE
+                          stream run through the bidirectional buffers (BSVD.forward, bsvd/model.py:515-580) */
+  int32_t reserved[4];
 } ss4k_model_desc;
 
 int ss4k_abi_version(void);

@@ -97,23 +97,59 @@ def _bibuffer_conv_f1(x, w, name):
     return _conv(xm, w, name + ".op.conv")
 
 
-def _memcv(x, w, name):
-    x = F.relu6(_bibuffer_conv_f1(x, w, name + ".c1"))
-    return F.relu6(_bibuffer_conv_f1(x, w, name + ".c2"))
+def _bibuffer_conv_seq(x, w, name):
+    """A ``BiBufferConv`` over a whole stream ``x = (T, C, H, W)`` (one frame per step, in order).
+    Reference ``bsvd/model.py:42-53`` (ShiftConv: the conv input of step t is
+    ``cat(right[:, :fold], left_fold_2fold, center[:, 2*fold:])``) and ``:95-138`` (the buffers:
+    ``center`` = frame t, ``left_fold_2fold`` = channels ``[fold, 2*fold)`` of frame t-1 or zeros at
+    the start, ``right`` = frame t+1 or zeros in the end stage), ``fold = C // 8``.  Written as the
+    closed form of that pipeline: every frame of the stream in one batch."""
+    fold = x.shape[1] // 8
+    xs = x.clone()
+    xs[:-1, :fold] = x[1:, :fold]
+    xs[-1, :fold] = 0
+    xs[1:, fold:2 * fold] = x[:-1, fold:2 * fold]
+    xs[0, fold:2 * fold] = 0
+    return _conv_framewise(xs, w, name + ".op.conv")
 
 
-def _denblock(x, w, p):
-    """One ``DenBlock`` (reference ``bsvd/model.py:353-442``) on a single frame."""
+def _conv_framewise(x, w, name, stride=1):
+    """The streaming pipeline convolves one frame at a time (batch 1); do the same so fp32
+    rounding matches the reference bit for bit (oneDNN picks its kernel by shape)."""
+    return torch.cat([_conv(x[i:i + 1], w, name, stride=stride) for i in range(x.shape[0])], 0)
+
+
+def _memcv(x, w, name, conv=_bibuffer_conv_f1):
+    x = F.relu6(conv(x, w, name + ".c1"))
+    return F.relu6(conv(x, w, name + ".c2"))
+
+
+def _denblock(x, w, p, conv=_bibuffer_conv_f1, cv=None):
+    """One ``DenBlock`` (reference ``bsvd/model.py:353-442``); ``conv`` is the BiBufferConv form
+    (single independent frames, or one stream)."""
+    cv = cv or _conv
     skip1 = x[:, 0:3]
-    x0 = F.relu6(_conv(F.relu6(_conv(x, w, p + ".inc.convblock.0")), w, p + ".inc.convblock.3"))
-    x1 = _memcv(F.relu6(_conv(x0, w, p + ".downc0.convblock.0", stride=2)), w, p + ".downc0.memconv")
-    x2 = _memcv(F.relu6(_conv(x1, w, p + ".downc1.convblock.0", stride=2)), w, p + ".downc1.memconv")
-    x2 = F.pixel_shuffle(_conv(_memcv(x2, w, p + ".upc2.memconv"), w, p + ".upc2.convblock.0"), 2)
-    x1 = F.pixel_shuffle(_conv(_memcv(x2 + x1, w, p + ".upc1.memconv"), w, p + ".upc1.convblock.0"), 2)
-    y = _conv(F.relu6(_conv(x1 + x0, w, p + ".outc.convblock.0")), w, p + ".outc.convblock.3")
+    x0 = F.relu6(cv(F.relu6(cv(x, w, p + ".inc.convblock.0")), w, p + ".inc.convblock.3"))
+    x1 = _memcv(F.relu6(cv(x0, w, p + ".downc0.convblock.0", stride=2)), w, p + ".downc0.memconv", conv)
+    x2 = _memcv(F.relu6(cv(x1, w, p + ".downc1.convblock.0", stride=2)), w, p + ".downc1.memconv", conv)
+    x2 = F.pixel_shuffle(cv(_memcv(x2, w, p + ".upc2.memconv", conv), w, p + ".upc2.convblock.0"), 2)
+    x1 = F.pixel_shuffle(cv(_memcv(x2 + x1, w, p + ".upc1.memconv", conv), w, p + ".upc1.convblock.0"), 2)
+    y = cv(F.relu6(cv(x1 + x0, w, p + ".outc.convblock.0")), w, p + ".outc.convblock.3")
     y = y.clone()
     y[:, :3] = skip1 - y[:, :3]
     return y
+
+
+def bsvd_seq(x: torch.Tensor, w: Mapping) -> torch.Tensor:
+    """BSVD on a frame stream, ``(N,F,4,H,W) -> (N,F,3,H,W)``: the reference's ``BSVD.forward``
+    (``bsvd/model.py:515-525``) flattens N*F into ONE stream and runs the bidirectional-buffer
+    pipeline over it (``streaming_forward`` ``:527-580``: feed every frame, then ``None`` until
+    ``shift_num`` = 16 more outputs have drained, keep outputs ``[shift_num:]``).  The service never
+    uses F > 1 (``fsrcnn_upscaler.py:277``); this is SURVEY.md §8(f4)."""
+    n, f, c, h, ww = x.shape
+    y = _denblock(x.reshape(n * f, c, h, ww), w, "temp1", _bibuffer_conv_seq, _conv_framewise)
+    y = _denblock(y, w, "temp2", _bibuffer_conv_seq, _conv_framewise)
+    return y.reshape(n, f, y.shape[1], h, ww)
 
 
 def bsvd_f1(x: torch.Tensor, w: Mapping) -> torch.Tensor:

@@ -34,7 +34,8 @@ SYMBOLS = [
 class ModelDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("dtype", C.c_int32), ("scale", C.c_int32), ("num_feat", C.c_int32),
                 ("num_block", C.c_int32), ("num_grow_ch", C.c_int32), ("bsvd_chns", C.c_int32 * 3),
-                ("bsvd_mid_ch", C.c_int32), ("bsvd_interm_ch", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("bsvd_mid_ch", C.c_int32), ("bsvd_interm_ch", C.c_int32), ("bsvd_stream", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
 
 
 class UpscaleCfg(C.Structure):
@@ -198,11 +199,12 @@ class Context:
 
 def make_desc(kind: int, dtype: int = F32, scale: int = 2, num_feat: int = 64, num_block: int = 23,
               num_grow_ch: int = 32, bsvd_chns: Sequence[int] = (32, 64, 128), bsvd_mid_ch: int = 32,
-              bsvd_interm_ch: int = 30) -> ModelDesc:
+              bsvd_interm_ch: int = 30, bsvd_stream: bool = False) -> ModelDesc:
     d = ModelDesc()
     d.kind, d.dtype, d.scale, d.num_feat, d.num_block, d.num_grow_ch = kind, dtype, scale, num_feat, num_block, num_grow_ch
     d.bsvd_chns = (C.c_int32 * 3)(*bsvd_chns)
     d.bsvd_mid_ch, d.bsvd_interm_ch = bsvd_mid_ch, bsvd_interm_ch
+    d.bsvd_stream = 1 if bsvd_stream else 0
     return d
 
 
@@ -240,10 +242,15 @@ class Model:
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         squeeze_f = False
-        if x.ndim == 5:  # BSVD's (N, F=1, C, H, W)
-            assert x.shape[1] == 1, "BSVD is driven with one frame per call (fsrcnn_upscaler.py:277)"
-            x = x[:, 0]
-            squeeze_f = True
+        seq_shape = None
+        if x.ndim == 5:  # BSVD's (N, F, C, H, W)
+            if self.desc.bsvd_stream:  # BSVD.forward flattens N*F into one stream (bsvd/model.py:520-522)
+                seq_shape = x.shape[:2]
+                x = x.reshape((-1,) + tuple(x.shape[2:]))
+            else:
+                assert x.shape[1] == 1, "per-frame BSVD takes F = 1 (fsrcnn_upscaler.py:277); build it with stream=True for F > 1"
+                x = x[:, 0]
+                squeeze_f = True
         assert x.ndim == 4 and x.shape[1] == self.in_channels, f"expected (N,{self.in_channels},H,W), got {tuple(x.shape)}"
         x = x.to(device=self.ctx.device, dtype=torch.float32).contiguous()
         n, _, h, w = x.shape
@@ -251,6 +258,8 @@ class Model:
         out = torch.empty((n, oc, oh, ow), dtype=torch.float32, device=x.device)
         with torch.cuda.device(self.ctx.device):
             _check(lib().ss4k_model_forward(self._h, x.data_ptr(), out.data_ptr(), n, h, w, _stream()))
+        if seq_shape is not None:
+            return out.reshape(tuple(seq_shape) + tuple(out.shape[1:]))
         return out.unsqueeze(1) if squeeze_f else out
 
     forward = __call__

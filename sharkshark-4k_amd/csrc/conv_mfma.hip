@@ -202,13 +202,13 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
     if (idx < NDMA_T) {
       const int k = wave + NW * idx;
       if (k < TILE_DMA && !(DBG & DBG_NO_TILE_DMA)) {
-        const char* src = src_off[idx] != OOB ? pf_plane + src_off[idx] : a.zero_page + (lane & 3) * 16;
+        const char* src = (src_off[idx] != OOB && !(DBG & DBG_NO_MMA)) ? ((DBG & DBG_NO_STORE) ? a.in0 + (src_off[idx] & 0x1FFFFFu) : pf_plane + src_off[idx]) : a.zero_page + (lane & 3) * 16;
         const uint32_t dst = __builtin_amdgcn_readfirstlane(pf_tdst + k * 1024);
         if (plan[idx] >= 0) dma16(src, dst);  // lanes past the tile's last slot are masked off (EXEC)
       }
     } else if (idx < NDMA) {
       const int k = wave + NW * (idx - NDMA_T);
-      if (k < 18 * NB && !(DBG & DBG_NO_W_DMA)) dma16(pf_wsrc + k * 1024, __builtin_amdgcn_readfirstlane(pf_wdst + k * 1024));
+      if (k < 18 * NB && !(DBG & DBG_NO_W_DMA)) dma16(((DBG & DBG_NO_MMA) ? wbase + lane * 16 : pf_wsrc + k * 1024), __builtin_amdgcn_readfirstlane(pf_wdst + k * 1024));
     }
   };
 
@@ -221,7 +221,8 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
   }
 
   // DBG_STAMP build only: per-phase cycle totals of wave 0 (s_memtime), written once at the end
-  unsigned long long st_dma = 0, st_mma = 0, st_epi = 0, st_bar = 0, st_t = 0, st_store = 0;
+  unsigned long long st_dma = 0, st_mma = 0, st_epi = 0, st_bar = 0, st_t = 0, st_store = 0, st_wait = 0, st_rt0 = 0;
+  if constexpr ((DBG & DBG_STAMP) != 0) st_rt0 = __builtin_amdgcn_s_memrealtime();
   auto stamp = [&]() -> unsigned long long {
     if constexpr ((DBG & DBG_STAMP) != 0) {
       unsigned long long t;
@@ -319,11 +320,7 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
           }
         __builtin_amdgcn_s_setprio(0);
       };
-      if constexpr ((DBG & DBG_NO_MMA) != 0) {
-#pragma unroll
-        for (int i = 0; i < NDMA; ++i) dma_op(i);
-      }
-      if constexpr (!(DBG & DBG_NO_MMA)) {
+      {
         // software pipeline over the six (dx, k-step) groups: the LDS reads of group g+1 are in
         // flight while the 12*NB MFMAs of group g issue (one wave per SIMD: nobody else hides them)
         Frags fa, fb;
@@ -343,6 +340,7 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
       { const unsigned long long t = stamp(); st_mma += t - st_t; st_t = t; }
       if (c + 1 < nchunks) {
         dma_wait();       // next chunk has landed in the other buffer
+        { const unsigned long long t = stamp(); st_wait += t - st_t; st_t = t; }
         __syncthreads();  // and every wave is done reading this one
         buf ^= 1;
         { const unsigned long long t = stamp(); st_bar += t - st_t; st_t = t; }
@@ -570,16 +568,21 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
     if (next_tile < 0) break;
     tile = next_tile; ++kt;
     dma_wait();       // next tile's first chunk has landed
+    { const unsigned long long t = stamp(); st_wait += t - st_t; st_t = t; }
     __syncthreads();  // all waves are done with the last buffer
     buf ^= 1;
     { const unsigned long long t = stamp(); st_bar += t - st_t; st_t = t; }
   }
   if constexpr ((DBG & DBG_STAMP) != 0) {
     const unsigned long long st_end = stamp();
-    if (tid == 0 && a.dbg_buf) {
-      unsigned long long* o = a.dbg_buf + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;
-      o[0] = st_end - st_begin; o[1] = st_dma; o[2] = st_mma; o[3] = st_epi; o[4] = st_bar; o[5] = kt + 1;
-      o[6] = st_pro; o[7] = st_store;
+    if (lane == 0 && a.dbg_buf) {
+      unsigned long long* o = a.dbg_buf + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16;
+      if (wave == 0) {
+        o[0] = st_end - st_begin; o[1] = st_dma; o[2] = st_mma; o[3] = st_epi; o[4] = st_bar; o[5] = kt + 1;
+        o[6] = st_pro; o[7] = st_store; o[8] = st_wait; o[9] = __builtin_amdgcn_s_memrealtime() - st_rt0;
+        o[14] = st_rt0; o[15] = __builtin_amdgcn_s_memrealtime();
+      }
+      if (wave == NW - 1) { o[10] = st_mma; o[11] = st_bar; o[12] = st_wait; o[13] = st_epi; }
     }
   }
 }
@@ -608,6 +611,14 @@ template <int NB, int MB, int NW>
 static void launch_dbg(ss4k_ctx* ctx, const ConvArgs& a, int groups, hipStream_t st) {
   switch (a.dbg & ~DBG_MB4) {  // instrumented builds of the fp16 kernel for ss4k_bench_conv
     case DBG_STAMP: launch_t<__half, NB, MB, NW, DBG_STAMP, false>(ctx, a, groups, st); break;
+    // timing-only ablations (results are garbage): the chunk prefetch without its weight / halo-tile part
+    case DBG_STAMP | DBG_NO_W_DMA: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_W_DMA, false>(ctx, a, groups, st); break;
+    case DBG_STAMP | DBG_NO_TILE_DMA: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_TILE_DMA, false>(ctx, a, groups, st); break;
+    // same DMA instructions, but every source is one hot cache line (no memory traffic)
+    case DBG_STAMP | DBG_NO_MMA: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_MMA, false>(ctx, a, groups, st); break;
+    // halo tiles read from a 2 MB window (stays in L2): L2->LDS traffic as in production, no fabric traffic
+    case DBG_STAMP | DBG_NO_STORE: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_STORE, false>(ctx, a, groups, st); break;
+    case DBG_STAMP | DBG_NO_W_DMA | DBG_NO_TILE_DMA: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_W_DMA | DBG_NO_TILE_DMA, false>(ctx, a, groups, st); break;
     case 0: launch_t<__half, NB, MB, NW, 0, false>(ctx, a, groups, st); break;
     default: throw Error(SS4K_EINVAL, "ss4k_bench_conv: supported flags are 0 and 32 (phase stamps), optionally | 64 (4-wave 16-row tiles)");
   }
@@ -634,7 +645,7 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
   const bool alt = dtype == SS4K_F16 && !(a.dbg & DBG_MB4);
   if (a.dbg) {
     SS4K_REQUIRE(dtype == SS4K_F16, "instrumented builds exist for fp16 only");
-    if (nb == 1) { if (alt) launch_dbg<1, 2, 4>(ctx, a, groups, st); else launch_dbg<1, 4, 4>(ctx, a, groups, st); }
+    if (nb == 1) { if (alt) launch_dbg<1, 2, 4>(ctx, a, groups, st); else launch_dbg<1, 2, 8>(ctx, a, groups, st); }
     else { if (alt) launch_dbg<2, 2, 8>(ctx, a, groups, st); else launch_dbg<2, 4, 4>(ctx, a, groups, st); }
   } else {
     const bool gen = !(a.epi == EPI_NHWC && !a.bsvd_resid);

@@ -299,4 +299,31 @@ void op_ps_nchw_addbase(const T* src, float* out, const float* base, int n, int 
 template void op_ps_nchw_addbase<float>(const float*, float*, const float*, int, int, int, int, int, hipStream_t);
 template void op_ps_nchw_addbase<__half>(const __half*, float*, const float*, int, int, int, int, int, hipStream_t);
 
+// BSVD stream mode: the ShiftConv input of frame t (bsvd/model.py:42-53,95-138) takes channels
+// [0, fold) from frame t+1, [fold, 2*fold) from frame t-1 (zeros past either end of the stream) and
+// the rest from frame t.  Only the leading planes that hold channels < 2*fold are rebuilt here (the
+// conv reads the remaining planes from the tensor itself); one thread per 16-byte slot.
+__global__ void k_temporal_shift(const uint4* __restrict__ in, uint4* __restrict__ out, int nplanes, int frames,
+                                 size_t frame_px, int ch_per_slot, int ch_per_plane, int fold) {
+  const size_t slots_per_plane = (size_t)frames * frame_px * 4;
+  const size_t total = slots_per_plane * nplanes;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i / slots_per_plane);
+    const size_t r = i - (size_t)p * slots_per_plane;
+    const int t = (int)(r / (frame_px * 4));
+    const int ch0 = p * ch_per_plane + (int)(r & 3) * ch_per_slot;
+    const int ts = ch0 < fold ? t + 1 : (ch0 < 2 * fold ? t - 1 : t);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ts >= 0 && ts < frames) v = in[i + (ptrdiff_t)(ts - t) * (ptrdiff_t)(frame_px * 4)];
+    out[i] = v;
+  }
+}
+void op_temporal_shift(const void* in, void* out, int nplanes, int frames, size_t frame_px, int ch_per_slot,
+                       int ch_per_plane, int fold, hipStream_t st) {
+  if (fold % ch_per_slot != 0) throw Error(SS4K_EINVAL, "temporal shift: fold must be a multiple of the 16-byte channel group");
+  hipLaunchKernelGGL(k_temporal_shift, grid1d((size_t)nplanes * frames * frame_px * 4), dim3(256), 0, st,
+                     reinterpret_cast<const uint4*>(in), reinterpret_cast<uint4*>(out), nplanes, frames, frame_px,
+                     ch_per_slot, ch_per_plane, fold);
+}
+
 }  // namespace ss4k

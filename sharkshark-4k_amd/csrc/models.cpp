@@ -68,6 +68,7 @@ size_t model_param_count(const ss4k_model_desc& d) {
 
 static void validate_desc(const ss4k_model_desc& d) {
   SS4K_REQUIRE(d.dtype == SS4K_F32 || d.dtype == SS4K_F16, "desc.dtype must be SS4K_F32 or SS4K_F16");
+  SS4K_REQUIRE(d.bsvd_stream == 0 || (d.bsvd_stream == 1 && d.kind == SS4K_BSVD), "desc.bsvd_stream is 0 or 1 and only applies to BSVD");
   switch (d.kind) {
     case SS4K_FSRCNN:
       SS4K_REQUIRE(d.scale == 2 || d.scale == 4, "FSRCNN scale must be 2 or 4");
@@ -145,6 +146,16 @@ PackSpec Model::spec_masked(int c) const {
   return s;
 }
 
+// BiBufferConv inside a stream: every input channel is live; the leading planes (channels < c/4,
+// rounded up to whole planes) come from the time-shifted copy (segment 0), the rest from the tensor
+PackSpec Model::spec_shifted(int c) const {
+  PackSpec s{}; const int lead = shifted_planes(c);
+  s.nchunks0 = lead; s.nchunks1 = planes_for(c) - lead;
+  s.cin_map.assign((size_t)planes_for(c) * cw(), -1);
+  for (int j = 0; j < c; ++j) s.cin_map[j] = j;
+  return s;
+}
+
 void Model::build(const float* w, size_t n) {
   validate_desc(desc);
   SS4K_REQUIRE(n == model_param_count(desc), "weight blob size does not match the model description");
@@ -210,7 +221,7 @@ void Model::build(const float* w, size_t n) {
         const int cout = shapes[i].first, cin = shapes[i].second;
         const bool masked = (i == 3 || i == 4 || i == 6 || i == 7 || i == 8 || i == 9 || i == 11 || i == 12);
         const bool ps2 = (i == 10 || i == 13);
-        add_conv(pc, cout, cin, masked ? spec_masked(cin) : spec_plain(cin, ps2 ? 1 : 0), false);
+        add_conv(pc, cout, cin, masked ? (desc.bsvd_stream ? spec_shifted(cin) : spec_masked(cin)) : spec_plain(cin, ps2 ? 1 : 0), false);
       }
     }
   }
@@ -368,19 +379,30 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
     auto relu6 = [&](Tens outT) { ConvOpts o; o.act = ACT_RELU6; o.out = outT; return o; };
     // masked conv input: skip the planes that only hold dead channels (see spec_masked)
     auto masked = [&](const Tens& t, int c) { return Tens{t.p, t.plane_bytes, t.plane0 + (c / 4) / cw()}; };
+    // one BiBufferConv + ReLU6: independent frames read only the live planes; in a stream the
+    // leading planes are first rebuilt from the neighbouring frames (op_temporal_shift)
+    auto bibuf = [&](const Tens& t, int c, int N, int H, int W, const Tens& outT) {
+      if (!desc.bsvd_stream) { conv(li++, masked(t, c), nullptr, N, H, W, relu6(outT), st); return; }
+      const int lead = shifted_planes(c);
+      Tens S = act(14, (size_t)N * H * W, lead * cw());
+      op_temporal_shift(t.p + (size_t)t.plane0 * t.plane_bytes, S.p, lead, N, (size_t)H * W, 16 / (int)esz(desc.dtype), cw(),
+                        c / 8, st);
+      const Tens rest{t.p, t.plane_bytes, t.plane0 + lead};
+      conv(li++, S, planes_for(c) > lead ? &rest : nullptr, N, H, W, relu6(outT), st);
+    };
     conv(li++, IN, nullptr, n, h, w, relu6(I0), st);                                   // inc.convblock.0
     conv(li++, I0, nullptr, n, h, w, relu6(X0), st);                                   // inc.convblock.3
     { ConvOpts o = relu6(D0); o.epi = EPI_NHWC_SUB2; conv(li++, X0, nullptr, n, h, w, o, st); }   // downc0 stride 2
-    conv(li++, masked(D0, c1), nullptr, n, h2, w2, relu6(Ma), st);
-    conv(li++, masked(Ma, c1), nullptr, n, h2, w2, relu6(X1), st);
+    bibuf(D0, c1, n, h2, w2, Ma);
+    bibuf(Ma, c1, n, h2, w2, X1);
     { ConvOpts o = relu6(D1); o.epi = EPI_NHWC_SUB2; conv(li++, X1, nullptr, n, h2, w2, o, st); } // downc1 stride 2
-    conv(li++, masked(D1, c2), nullptr, n, h4, w4, relu6(Mb), st);
-    conv(li++, masked(Mb, c2), nullptr, n, h4, w4, relu6(X2), st);
-    conv(li++, masked(X2, c2), nullptr, n, h4, w4, relu6(Mc), st);                     // upc2.memconv
-    conv(li++, masked(Mc, c2), nullptr, n, h4, w4, relu6(Mb), st);
+    bibuf(D1, c2, n, h4, w4, Mb);
+    bibuf(Mb, c2, n, h4, w4, X2);
+    bibuf(X2, c2, n, h4, w4, Mc);                     // upc2.memconv
+    bibuf(Mc, c2, n, h4, w4, Mb);
     { ConvOpts o; o.epi = EPI_NHWC_PS2; o.res1 = &X1; o.out = S1; conv(li++, Mb, nullptr, n, h4, w4, o, st); }  // PixelShuffle + skip3
-    conv(li++, masked(S1, c1), nullptr, n, h2, w2, relu6(Ma), st);                     // upc1.memconv
-    conv(li++, masked(Ma, c1), nullptr, n, h2, w2, relu6(D0), st);
+    bibuf(S1, c1, n, h2, w2, Ma);                     // upc1.memconv
+    bibuf(Ma, c1, n, h2, w2, D0);
     { ConvOpts o; o.epi = EPI_NHWC_PS2; o.res1 = &X0; o.out = S0; conv(li++, D0, nullptr, n, h2, w2, o, st); }  // PixelShuffle + skip2
     conv(li++, S0, nullptr, n, h, w, relu6(O0), st);                                   // outc.convblock.0
     { ConvOpts o; o.res1 = &IN; o.bsvd_resid = 1;
@@ -403,11 +425,22 @@ double bench_conv_layer(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, 
   const int li = m.add_conv(pc, cout, cin, cin1 ? m.spec_concat(cin0, cin1) : m.spec_plain(cin0), false);
   const size_t px = (size_t)n * h * w;
   Tens X = m.act(0, px, cin0), G = m.act(1, px, std::max(cin1, 32)), O = m.act(2, px, cout);
-  SS4K_HIP(hipMemsetAsync(X.p, 0x11, (size_t)m.planes_for(cin0) * px * 64, st));
-  SS4K_HIP(hipMemsetAsync(G.p, 0x11, (size_t)m.planes_for(std::max(cin1, 32)) * px * 64, st));
+  {  // random operands: constant data lets the chip hold a higher clock than real frames do
+    auto fill = [&](Tens& t, int ch) {
+      const size_t bytes = (size_t)m.planes_for(ch) * px * 64;
+      std::vector<uint32_t> hbuf(bytes / 4);
+      for (auto& v : hbuf) {
+        s = s * 1664525u + 1013904223u;
+        v = dtype == SS4K_F16 ? ((s & 0x83FF83FFu) | 0x38003800u)    // two halves in +-[0.5,1)
+                              : ((s & 0x807FFFFFu) | 0x3F000000u);  // one float in +-[0.5,1)
+      }
+      SS4K_HIP(hipMemcpy(t.p, hbuf.data(), bytes, hipMemcpyHostToDevice));
+    };
+    fill(X, cin0); fill(G, std::max(cin1, 32));
+  }
   ConvOpts o; o.act = ACT_LRELU; o.slope = 0.2f; o.out = O;
   m.dbg = flags;
-  DevBuf dbgb; dbgb.ensure(1024 * 8 * 8); SS4K_HIP(hipMemsetAsync(dbgb.ptr, 0, 1024 * 8 * 8, st)); m.dbg_buf = dbgb.as<unsigned long long>();
+  DevBuf dbgb; dbgb.ensure(1024 * 16 * 8); SS4K_HIP(hipMemsetAsync(dbgb.ptr, 0, 1024 * 16 * 8, st)); m.dbg_buf = dbgb.as<unsigned long long>();
   for (int i = 0; i < 3; ++i) m.conv(li, X, cin1 ? &G : nullptr, n, h, w, o, st);
   hipEvent_t e0, e1; SS4K_HIP(hipEventCreate(&e0)); SS4K_HIP(hipEventCreate(&e1));
   SS4K_HIP(hipEventRecord(e0, st));
@@ -417,12 +450,23 @@ double bench_conv_layer(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, 
   float ms = 0; SS4K_HIP(hipEventElapsedTime(&ms, e0, e1));
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (flags & DBG_STAMP) {  // print the phase breakdown of the last launch (wave 0 of every workgroup)
-    std::vector<unsigned long long> h((size_t)1024 * 8);
+    std::vector<unsigned long long> h((size_t)1024 * 16);
     SS4K_HIP(hipMemcpy(h.data(), m.dbg_buf, h.size() * 8, hipMemcpyDeviceToHost));
-    double tot = 0, dma = 0, mma = 0, epi = 0, bar = 0, tiles = 0, sto = 0, pro = 0; int nwg = 0;
-    for (int i = 0; i < 1024; ++i) if (h[i * 8 + 5]) { tot += h[i*8]; dma += h[i*8+1]; mma += h[i*8+2]; epi += h[i*8+3]; bar += h[i*8+4]; tiles += h[i*8+5]; sto += h[i*8+7]; pro += h[i*8+6]; ++nwg; }
-    if (nwg) fprintf(stderr, "[stamp] %d WGs, avg tiles %.2f, cycles(100MHz ticks?) total %.0f  issue %.0f  mma %.0f  epilogue %.0f (stores %.0f)  barrier %.0f  prologue %.0f\n",
-                     nwg, tiles / nwg, tot / nwg, dma / nwg, mma / nwg, epi / nwg, sto / nwg, bar / nwg, pro / nwg);
+    double v[16] = {0}; int nwg = 0;
+    for (int i = 0; i < 1024; ++i) if (h[i * 16 + 5]) { for (int k = 0; k < 16; ++k) v[k] += (double)h[i * 16 + k]; ++nwg; }
+    if (nwg) {
+      unsigned long long b0 = ~0ull, b1 = 0, e0 = ~0ull, e1 = 0; double tmax = 0, tmin = 1e30; int tl_max = 0;
+      for (int i = 0; i < 1024; ++i) if (h[i * 16 + 5]) {
+        b0 = std::min(b0, h[i * 16 + 14]); b1 = std::max(b1, h[i * 16 + 14]);
+        e0 = std::min(e0, h[i * 16 + 15]); e1 = std::max(e1, h[i * 16 + 15]);
+        tmax = std::max(tmax, (double)h[i * 16]); tmin = std::min(tmin, (double)h[i * 16]); tl_max = std::max(tl_max, (int)h[i * 16 + 5]);
+      }
+      fprintf(stderr, "[stamp] kernel span %.1f us: workgroup starts spread over %.1f us, ends over %.1f us; per-WG cycles min %.0f max %.0f, max tiles %d\n",
+              (e1 - b0) / 100.0, (b1 - b0) / 100.0, (e1 - e0) / 100.0, tmin, tmax, tl_max);
+      for (double& x : v) x /= nwg;
+      fprintf(stderr, "[stamp] %d WGs, avg tiles %.2f, clock %.0f MHz; wave0 cycles: total %.0f  issue %.0f  mma %.0f  epilogue %.0f  dma-wait %.0f  barrier %.0f  prologue %.0f | last wave: mma %.0f  epilogue %.0f  dma-wait %.0f  barrier %.0f\n",
+              nwg, v[5], v[9] > 0 ? v[0] / v[9] * 100.0 : 0.0, v[0], v[1], v[2], v[3], v[8], v[4], v[6], v[10], v[13], v[12], v[11]);
+    }
   }
   dbgb.release();
   return 1000.0 * ms / iters;

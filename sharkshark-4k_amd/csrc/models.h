@@ -51,6 +51,9 @@ struct Model {
   PackSpec spec_plain(int cin_real, int ps2 = 0) const;
   PackSpec spec_concat(int c0, int c1) const;
   PackSpec spec_masked(int c) const;
+  PackSpec spec_shifted(int c) const;
+  // planes holding the time-shifted channels [0, c/4) of a BiBufferConv input (whole planes)
+  int shifted_planes(int c) const { return std::min(planes_for(c), (c / 4 + cw() - 1) / cw()); }
   int cw() const { return conv_cw(desc.dtype); }
   int planes_for(int channels) const { return (channels + cw() - 1) / cw(); }
   void conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, const ConvOpts& o, hipStream_t st);

@@ -65,7 +65,11 @@ def build_model_esrgan(ctx: _capi.Context, model_name: str = DEFAULT_REALESRGAN,
     return _capi.Model(ctx, desc, W.flatten(table, W.srvgg_keys(kw["num_conv"])))
 
 
-def build_denoise_model(ctx: _capi.Context, weights: Optional[Mapping] = None, dtype="f16", seed: int = 0):
+def build_denoise_model(ctx: _capi.Context, weights: Optional[Mapping] = None, dtype="f16", seed: int = 0,
+                        stream: bool = False):
+    """``stream=False``: the model the service calls, one independent frame per call (F = 1,
+    ``fsrcnn_upscaler.py:277``).  ``stream=True``: ``BSVD.forward`` on ``(N,F,4,H,W)`` clips, all N*F
+    frames run through the bidirectional buffers as one stream (``bsvd/model.py:515-580``)."""
     table = weights if weights is not None else W.bsvd_table(seed)
-    desc = _capi.make_desc(_capi.BSVD, _dtype(dtype), scale=1)
+    desc = _capi.make_desc(_capi.BSVD, _dtype(dtype), scale=1, bsvd_stream=stream)
     return _capi.Model(ctx, desc, W.flatten(table, W.bsvd_keys()))

@@ -172,6 +172,15 @@ def bsvd_cases():
             yo = onets.bsvd_f1(torch.from_numpy(x.copy()), table)
         assert maxdiff(y, y2) == 0.0
         save(name, {"oracle_maxdiff": maxdiff(y, yo), "weights": "bsvd_table(seed=21)"}, x=x, y=y.numpy())
+    # multi-frame streams through the bidirectional buffers (bsvd/model.py:515-580)
+    for name, n, f, h, w, seed in (("bsvd32_seq5_24x40", 1, 5, 24, 40, 24), ("bsvd32_seq3_16x24", 1, 3, 16, 24, 25),
+                                   ("bsvd32_seq2x2_16x24", 2, 2, 16, 24, 26)):
+        x = np.random.default_rng(seed).random((n, f, 4, h, w), dtype=np.float32)
+        x[:, :, 3] = 0.05
+        with torch.no_grad():
+            y = ref(torch.from_numpy(x.copy()))
+            yo = onets.bsvd_seq(torch.from_numpy(x.copy()), table)
+        save(name, {"oracle_maxdiff": maxdiff(y, yo), "weights": "bsvd_table(seed=21)", "stream": True}, x=x, y=y.numpy())
 
 
 # ------------------------------------------------------------------ service glue
