@@ -108,11 +108,12 @@ struct ConvArgs {
   int dbg;                              // selects an ablation build (ss4k_bench_conv only; 0 in production)
   unsigned long long* dbg_buf;          // DBG_STAMP: per-workgroup phase cycle counters
 };
-enum { DBG_NO_STORE = 1, DBG_NO_MMA = 2, DBG_NO_TILE_DMA = 4, DBG_NO_W_DMA = 8, DBG_NO_EPILOGUE = 16, DBG_STAMP = 32, DBG_MB4 = 64 };
+enum { DBG_NO_STORE = 1, DBG_NO_MMA = 2, DBG_NO_TILE_DMA = 4, DBG_NO_W_DMA = 8, DBG_NO_EPILOGUE = 16, DBG_STAMP = 32 };  // | tile-shape id << 8 (ss4k_bench_conv)
 
 // launchers (conv_mfma.hip)
 void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a, int dtype, hipStream_t st);
-int conv_cw(int dtype);  // channels per plane / K-chunk: 32 (f16) / 16 (f32)
+int conv_cw(int dtype);  // channels per plane / K-chunk: 16
+inline int conv_rec_bytes(int dtype) { return dtype == SS4K_F16 ? 32 : 64; }  // bytes of one pixel's record in a plane
 
 // weight packing (pack.cpp) --------------------------------------------------------------
 struct PackSpec {

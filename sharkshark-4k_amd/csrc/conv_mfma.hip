@@ -2,10 +2,11 @@
 //
 //   D[cout][pixel] += W[cout][k] * X[k][pixel],   k = (tap, cin)
 //
-// Data layout in HBM ("planes"): an activation tensor with C channels is stored as C/CW planes of
-// N*H*W 64-byte records (CW = 32 fp16 or 16 fp32 channels), so one K-chunk of one image row is a
-// contiguous run of bytes, the RRDB dense concat is just "more planes", and every load/store is a
-// whole 64-byte record.
+// Data layout in HBM ("planes"): an activation tensor with C channels is stored as C/16 planes of
+// N*H*W records of 16 channels (32 bytes fp16, 64 bytes fp32), so one K-chunk (= one plane) of one
+// image row is a contiguous run of bytes, the RRDB dense concat is just "more planes", and every
+// load/store is a whole record.  K-chunks of 16 channels keep a pipeline stage small (halo tile +
+// weights of a 16x32x64 tile: 38 KB), which is what lets the pixel tile per weight fetch be large.
 //
 // One workgroup = 4 waves = one wave per SIMD, ONE workgroup per CU (persistent over tiles):
 //   * output tile 16 rows x 32 pixels x (NB*32) output channels; wave w owns rows 4w..4w+3;
@@ -27,6 +28,10 @@
 // address modes of the DMA source / the epilogue store, not extra passes.
 #include "common.h"
 
+#ifndef SS4K_ROLL
+#define SS4K_ROLL(MB) ((MB) >= 4)
+#endif
+
 namespace ss4k {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -40,18 +45,29 @@ constexpr uint32_t OOB = 0xFFFFFFFFu;
 // NW waves per workgroup: 8 waves (two per SIMD inside ONE workgroup) are used for the 64-cout build,
 // whose LDS footprint allows only one workgroup per CU: the second wave of a SIMD fills the first
 // one's LDS-latency / DMA-issue bubbles and halves each wave's share of the epilogue.
-template <int MB, int NW> struct Geo {
+template <typename T> struct Tr;
+// E elements per 16-byte slot; a 16-channel record is SPR slots; one MFMA k-step eats two of them
+// (one per half-wave), so a K-chunk is KS k-steps per tap column
+template <> struct Tr<__half> { static constexpr int E = 8, KS = 1; };
+template <> struct Tr<float> { static constexpr int E = 4, KS = 2; };
+constexpr int CW = 16;  // channels per plane = per K-chunk, both dtypes
+
+template <typename T, int MB, int NW> struct Geo {
+  static constexpr int KS = Tr<T>::KS, SPR = 2 * KS, REC = 16 * SPR;
   static constexpr int TH = NW * MB, IN_H = TH + 2, IN_PIX = IN_W * IN_H;
-  static constexpr int TILE_SLOTS = IN_PIX * 4;            // 16-byte LDS slots per halo tile
+  static constexpr int TILE_SLOTS = IN_PIX * SPR;          // 16-byte LDS slots per halo tile
   static constexpr int TILE_DMA = (TILE_SLOTS + 63) / 64;  // wave-level DMA instructions per tile
   static constexpr int DMA_PER_WAVE = (TILE_DMA + NW - 1) / NW;
 };
+template <typename T, int NB, int MB, int NW> constexpr size_t lds_bytes() {
+  return (size_t)(2 * Geo<T, MB, NW>::TILE_SLOTS + 2 * 9 * Tr<T>::KS * NB * 64) * 16 + NB * 32 * 2 * 4;
+}
+// workgroups of one build that fit a CU (160 KB LDS, at most 3 so that 4-wave builds keep >= 168 VGPRs)
+template <typename T, int NB, int MB, int NW> constexpr int wgs_per_cu() {
+  return NW == 8 ? 1 : (lds_bytes<T, NB, MB, NW>() <= 53 * 1024 ? 3 : lds_bytes<T, NB, MB, NW>() <= 80 * 1024 ? 2 : 1);
+}
 
-template <typename T> struct Tr;
-template <> struct Tr<__half> { static constexpr int E = 8, CW = 32; };
-template <> struct Tr<float> { static constexpr int E = 4, CW = 16; };
-
-int conv_cw(int dtype) { return dtype == SS4K_F16 ? 32 : 16; }
+int conv_cw(int) { return CW; }
 
 // One wave-level LDS-DMA: every lane moves 16 bytes from ITS global address to LDS byte
 // lds_addr + 16*lane.  Written as inline asm so hipcc does not count it: the compiler would
@@ -116,12 +132,13 @@ __device__ __forceinline__ f32x16 mma(const uint4& w, const uint4& x, f32x16 acc
 // GEN = false: only the plain-layout epilogue is compiled (every RRDBNet / SRVGG body layer);
 // GEN = true adds the stride-2 / PixelShuffle / NCHW / BSVD-residual / ReLU6 epilogues.
 template <typename T, int NB, int MB, int NW, int DBG, bool GEN>
-__global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3_kernel(const ConvArgs a) {
-  constexpr int CW = Tr<T>::CW;
-  using G = Geo<MB, NW>;
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>())) void conv3x3_kernel(const ConvArgs a) {
+  using G = Geo<T, MB, NW>;
+  constexpr int KS = G::KS, SPR = G::SPR, REC = G::REC, NG = 3 * KS;
   constexpr int TH = G::TH, TILE_SLOTS = G::TILE_SLOTS, TILE_DMA = G::TILE_DMA;
   constexpr int DMA_PER_WAVE = G::DMA_PER_WAVE;
-  constexpr int WSLOTS = 18 * NB * 64;  // weight slots per chunk
+  constexpr int WSLOTS = 9 * KS * NB * 64;  // weight slots per chunk
+  constexpr bool ROLL = SS4K_ROLL(MB);       // one fragment set reloaded in place (see the chunk loop)
   constexpr int RV = (int)(16 * sizeof(T) / 16);  // uint4 per 16-channel group
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [tile buf 0][tile buf 1][weights buf 0][weights buf 1]
@@ -149,14 +166,17 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
     return (j < tpx && t < ntiles) ? t : -1;
   };
 
-  // per-lane operand read base (bytes): slot = pixel*4 + ((2ks+lh) ^ ((x>>2)&3)), x = lr+dx
-  int rd_base[3][2];
+  // bank swizzle of a pixel's 16-byte slots by its x: makes every ds_read_b128 operand read
+  // conflict-free for 64-byte (4 slots) and 32-byte (2 slots) pixels alike
+  auto swz = [](int x) { return SPR == 4 ? ((x >> 2) & 3) : ((x >> 3) & 1); };
+  // per-lane operand read base (bytes): slot = pixel*SPR + ((2ks+lh) ^ swz(x)), x = lr+dx
+  int rd_base[3][KS];
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const int x = lr + dx;
-      rd_base[dx][ks] = (((wave * MB) * IN_W + x) * 4 + ((2 * ks + lh) ^ ((x >> 2) & 3))) * 16;
+      rd_base[dx][ks] = (((wave * MB) * IN_W + x) * SPR + ((2 * ks + lh) ^ swz(x))) * 16;
     }
 
   // tile-independent part of the DMA plan: LDS slot s = 64k + lane holds pixel (row, x), source
@@ -165,9 +185,9 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
 #pragma unroll
   for (int j = 0; j < DMA_PER_WAVE; ++j) {
     const int s = (wave + NW * j) * 64 + lane;
-    const int p = s >> 2, gq = s & 3;
+    const int p = s / SPR, gq = s % SPR;
     const int row = p / IN_W, x = p - row * IN_W;
-    plan[j] = (s < TILE_SLOTS) ? (row | (x << 8) | (((gq ^ ((x >> 2) & 3)) * 16) << 16)) : -1;
+    plan[j] = (s < TILE_SLOTS) ? (row | (x << 8) | (((gq ^ swz(x)) * 16) << 16)) : -1;
   }
   uint32_t src_off[DMA_PER_WAVE];
   auto setup_tile = [&](int tile, int& n, int& y0, int& x0) {
@@ -179,14 +199,16 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
       const int iy = y0 - 1 + (plan[j] & 0xff), ix = x0 - 1 + ((plan[j] >> 8) & 0xff);
       const bool ok = plan[j] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
       const int sy = a.ups2 ? (iy >> 1) : iy, sx = a.ups2 ? (ix >> 1) : ix;
-      src_off[j] = ok ? (uint32_t)((n * Hs + sy) * Ws + sx) * 64u + (uint32_t)((plan[j] >> 16) & 0xff) : OOB;
+      src_off[j] = ok ? (uint32_t)((n * Hs + sy) * Ws + sx) * (uint32_t)REC + (uint32_t)((plan[j] >> 16) & 0xff) : OOB;
     }
   };
   // One K-chunk prefetch = NDMA wave-level DMA instructions per wave (halo tile, then weights).
   // They are not issued in a burst: dma_op(i) is called from slots spread through the MFMA stream
   // of the chunk being computed, so their issue cost hides under matrix-pipe time.
-  constexpr int NDMA_T = DMA_PER_WAVE, NDMA_W = (18 * NB + NW - 1) / NW, NDMA = NDMA_T + NDMA_W;
-  static_assert(NDMA <= 6 * MB, "not enough DMA slots in the MFMA stream");
+  constexpr int NDMA_T = DMA_PER_WAVE, NDMA_W = (9 * KS * NB + NW - 1) / NW, NDMA = NDMA_T + NDMA_W;
+  // one DMA slot after every SE-th (row, dy) MFMA pair of a group
+  constexpr int SE = NDMA <= NG * MB ? 3 : (2 * NDMA <= NG * 3 * MB ? 2 : 1);
+  static_assert((3 * MB) % SE == 0 && NDMA <= NG * 3 * MB / SE, "not enough DMA slots in the MFMA stream");
   const char* pf_plane = nullptr; const char* pf_wsrc = nullptr;
   uint32_t pf_tdst = 0, pf_wdst = 0; bool pf_on = false;
   auto prefetch_begin = [&](int c, int buf) {
@@ -208,7 +230,7 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
       }
     } else if (idx < NDMA) {
       const int k = wave + NW * (idx - NDMA_T);
-      if (k < 18 * NB && !(DBG & DBG_NO_W_DMA)) dma16(((DBG & DBG_NO_MMA) ? wbase + lane * 16 : pf_wsrc + k * 1024), __builtin_amdgcn_readfirstlane(pf_wdst + k * 1024));
+      if (k < 9 * KS * NB && !(DBG & DBG_NO_W_DMA)) dma16(((DBG & DBG_NO_MMA) ? wbase + lane * 16 : pf_wsrc + k * 1024), __builtin_amdgcn_readfirstlane(pf_wdst + k * 1024));
     }
   };
 
@@ -285,7 +307,7 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
       const char* tb = smem + buf * TILE_BYTES;
       const char* wb = smem + 2 * TILE_BYTES + buf * W_BYTES + lane * 16;
       auto load_group = [&](Frags& f, int g) {
-        const int dx = g >> 1, ks = g & 1;
+        const int dx = g / KS, ks = g % KS;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -293,7 +315,7 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
             f.wf[dy][nb] = *reinterpret_cast<const uint4*>(wb + (((g * 3 + dy) * NB + nb) * 64) * 16);
 #pragma unroll
         for (int ir = 0; ir < MB + 2; ++ir)
-          f.af[ir] = *reinterpret_cast<const uint4*>(tb + rd_base[dx][ks] + ir * IN_W * 64);
+          f.af[ir] = *reinterpret_cast<const uint4*>(tb + rd_base[dx][ks] + ir * IN_W * REC);
       };
       // the 12 (input row, dy) pairs of one group, in an order that never repeats an accumulator
       // back to back; after every third MFMA one DMA instruction of the prefetch is issued
@@ -310,9 +332,9 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
             if (mb >= 0 && mb < MB) {
 #pragma unroll
               for (int nb = 0; nb < NB; ++nb) acc[nb][mb] = mma<T>(f.wf[dy][nb], f.af[ir], acc[nb][mb]);
-              if (m % 3 == 1 && g * MB + m / 3 < NDMA) {
+              if (m % SE == SE / 2 && g * (3 * MB / SE) + m / SE < NDMA) {
                 __builtin_amdgcn_sched_barrier(0);
-                dma_op(g * MB + m / 3);
+                dma_op(g * (3 * MB / SE) + m / SE);
                 __builtin_amdgcn_sched_barrier(0);
               }
               ++m;
@@ -320,21 +342,62 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
           }
         __builtin_amdgcn_s_setprio(0);
       };
-      {
-        // software pipeline over the six (dx, k-step) groups: the LDS reads of group g+1 are in
-        // flight while the 12*NB MFMAs of group g issue (one wave per SIMD: nobody else hides them)
-        Frags fa, fb;
-        load_group(fa, 0);
+      if constexpr (!ROLL) {
+        // software pipeline over the NG (dx, k-step) groups: the LDS reads of group g+1 are in
+        // flight while the 3*MB*NB MFMAs of group g issue (two fragment sets)
+        Frags fr[2];
+        load_group(fr[0], 0);
 #pragma unroll
-        for (int g = 0; g < 6; g += 2) {
-          load_group(fb, g + 1);
+        for (int g = 0; g < NG; ++g) {
+          if (g + 1 < NG) load_group(fr[(g + 1) & 1], g + 1);
           __builtin_amdgcn_sched_barrier(0);
-          mma_group(fa, g);
+          mma_group(fr[g & 1], g);
           __builtin_amdgcn_sched_barrier(0);
-          if (g + 2 < 6) load_group(fa, g + 2);
+        }
+      } else {
+        // ONE fragment set, reloaded in place: as soon as the last MFMA that reads a register of
+        // group g has issued, that register is refilled with its group g+1 value (input row ir after
+        // its <= 3 MFMAs; the dy weights after rows MB-1, MB, MB+1).  Same latency cover as two
+        // sets for all but the last few MFMAs of a group, at half the registers - what lets the
+        // 4-rows-per-wave builds keep two waves per SIMD without scratch.
+        Frags f;
+        load_group(f, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const bool more = g + 1 < NG;
+          const int dxn = (g + 1) / KS, ksn = (g + 1) % KS;
+          int m = 0;
           __builtin_amdgcn_sched_barrier(0);
-          mma_group(fb, g + 1);
-          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int ir = 0; ir < MB + 2; ++ir) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+              const int mb = ir - dy;
+              if (mb >= 0 && mb < MB) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb][mb] = mma<T>(f.wf[dy][nb], f.af[ir], acc[nb][mb]);
+                if (m % SE == SE / 2 && g * (3 * MB / SE) + m / SE < NDMA) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  dma_op(g * (3 * MB / SE) + m / SE);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+                ++m;
+              }
+            }
+            if (more) {
+              __builtin_amdgcn_sched_barrier(0);
+              f.af[ir] = *reinterpret_cast<const uint4*>(tb + rd_base[dxn][ksn] + ir * IN_W * REC);
+              if (ir >= MB - 1) {
+                const int dy = ir - (MB - 1);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                  f.wf[dy][nb] = *reinterpret_cast<const uint4*>(wb + ((((g + 1) * 3 + dy) * NB + nb) * 64) * 16);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          __builtin_amdgcn_s_setprio(0);
         }
       }
       { const unsigned long long t = stamp(); st_mma += t - st_t; st_t = t; }
@@ -356,17 +419,22 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
     //   v = act(acc) * alpha + res1;  v = v * gamma + res2      (absent residuals are zeros,
     // absent activation is slope 1, so the same instruction stream serves every such layer)
     const bool fast_epi = !GEN || (a.epi == EPI_NHWC && !a.bsvd_resid);
+    // the epilogue's per-lane plane pointers depend only on kernel arguments: left alone, the
+    // compiler computes them once before the tile loop and carries ~16 registers through the MFMA
+    // loop (spilling in the 4-rows-per-wave builds).  Re-derive them per tile instead.
+    int lhe = lh;
+    asm volatile("" : "+v"(lhe));
     if constexpr (!(DBG & DBG_NO_EPILOGUE))
     if (fast_epi) {
       const float alpha = a.alpha, gamma = a.gamma;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const int vbase = (grp * NB + nb) * 32 + 16 * lh;
+        const int vbase = (grp * NB + nb) * 32 + 16 * lhe;
         if ((grp * NB + nb) * 32 >= a.cout_pad) continue;
         float slope_v[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 s4 = *reinterpret_cast<const float4*>(epi_lds + NB * 32 + nb * 32 + 16 * lh + 4 * q);
+          const float4 s4 = *reinterpret_cast<const float4*>(epi_lds + NB * 32 + nb * 32 + 16 * lhe + 4 * q);
           slope_v[4 * q] = s4.x; slope_v[4 * q + 1] = s4.y; slope_v[4 * q + 2] = s4.z; slope_v[4 * q + 3] = s4.w;
         }
         const int opl = vbase / CW;
@@ -401,41 +469,50 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
             }
             if (ok) {
               if constexpr ((DBG & DBG_NO_STORE) != 0) { if (v[0] == 12345.678f) a.out[0] = 1; }
-              else store16<T>(outp + (pix0 + (size_t)mb * a.W) * 64, v);
+              else store16<T>(outp + (pix0 + (size_t)mb * a.W) * REC, v);
             }
           }
         } else {
-          uint4 r1v[MB][RV], r2v[MB][RV];
+          // RB rows at a time: residual loads of those rows first, then the arithmetic (one memory
+          // round trip per batch, and the 4-rows-per-wave builds stay inside their register budget)
+          constexpr int RB = (NB * MB >= 8) ? 1 : 2;  // 128 accumulator registers leave room for one row only
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb) {
-            const bool ok = (cur_y0 + wave * MB + mb) < a.H && xo < a.W;
-            const size_t rec = (pix0 + (size_t)mb * a.W) * 64;
+          for (int mb0 = 0; mb0 < MB; mb0 += RB) {
+            uint4 r1v[RB][RV], r2v[RB][RV];
 #pragma unroll
-            for (int q = 0; q < RV; ++q) {
-              r1v[mb][q] = (r1p && ok) ? *reinterpret_cast<const uint4*>(r1p + rec + 16 * q) : make_uint4(0, 0, 0, 0);
-              r2v[mb][q] = (r2p && ok) ? *reinterpret_cast<const uint4*>(r2p + rec + 16 * q) : make_uint4(0, 0, 0, 0);
+            for (int j = 0; j < RB; ++j) {
+              const int mb = mb0 + j;
+              const bool ok = (cur_y0 + wave * MB + mb) < a.H && xo < a.W;
+              const size_t rec = (pix0 + (size_t)mb * a.W) * REC;
+#pragma unroll
+              for (int q = 0; q < RV; ++q) {
+                r1v[j][q] = (r1p && ok) ? *reinterpret_cast<const uint4*>(r1p + rec + 16 * q) : make_uint4(0, 0, 0, 0);
+                r2v[j][q] = (r2p && ok) ? *reinterpret_cast<const uint4*>(r2p + rec + 16 * q) : make_uint4(0, 0, 0, 0);
+              }
             }
-          }
-          __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb) {
-            const bool ok = (cur_y0 + wave * MB + mb) < a.H && xo < a.W;
-            float v[16], r1[16], r2[16];
-            load16<T>(reinterpret_cast<const char*>(&r1v[mb][0]), r1);
-            load16<T>(reinterpret_cast<const char*>(&r2v[mb][0]), r2);
+            for (int j = 0; j < RB; ++j) {
+              const int mb = mb0 + j;
+              const bool ok = (cur_y0 + wave * MB + mb) < a.H && xo < a.W;
+              float v[16], r1[16], r2[16];
+              load16<T>(reinterpret_cast<const char*>(&r1v[j][0]), r1);
+              load16<T>(reinterpret_cast<const char*>(&r2v[j][0]), r2);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              float t = acc[nb][mb][i];
-              const float neg = t * slope_v[i];
-              t = t >= 0.f ? t : neg;
-              if (a.act == ACT_RELU6) t = fminf(t, 6.f);  // slope is 0 for ReLU6: the select above is the ReLU
-              t = t * alpha + r1[i];
-              v[i] = t * gamma + r2[i];
+              for (int i = 0; i < 16; ++i) {
+                float t = acc[nb][mb][i];
+                const float neg = t * slope_v[i];
+                t = t >= 0.f ? t : neg;
+                if (a.act == ACT_RELU6) t = fminf(t, 6.f);  // slope is 0 for ReLU6: the select above is the ReLU
+                t = t * alpha + r1[i];
+                v[i] = t * gamma + r2[i];
+              }
+              if (ok) {
+                if constexpr ((DBG & DBG_NO_STORE) != 0) { if (v[0] == 12345.678f) a.out[0] = 1; }
+                else store16<T>(outp + (pix0 + (size_t)mb * a.W) * REC, v);
+              }
             }
-            if (ok) {
-              if constexpr ((DBG & DBG_NO_STORE) != 0) { if (v[0] == 12345.678f) a.out[0] = 1; }
-              else store16<T>(outp + (pix0 + (size_t)mb * a.W) * 64, v);
-            }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -443,13 +520,13 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
     } else if constexpr (GEN)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      const int vbase = (grp * NB + nb) * 32 + 16 * lh;
+      const int vbase = (grp * NB + nb) * 32 + 16 * lhe;
       if (vbase >= a.cout_pad) continue;
       float slope_v[16];
       if (a.act == ACT_PRELU) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 s4 = *reinterpret_cast<const float4*>(epi_lds + NB * 32 + nb * 32 + 16 * lh + 4 * q);
+          const float4 s4 = *reinterpret_cast<const float4*>(epi_lds + NB * 32 + nb * 32 + 16 * lhe + 4 * q);
           slope_v[4 * q] = s4.x; slope_v[4 * q + 1] = s4.y; slope_v[4 * q + 2] = s4.z; slope_v[4 * q + 3] = s4.w;
         }
       }
@@ -461,7 +538,7 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
           const int y = cur_y0 + wave * MB + mb;
           const bool ok = y < a.H && xo < a.W;
           const size_t ipix = ((size_t)cur_n * a.H + min(y, a.H - 1)) * a.W + min(xo, a.W - 1);
-          const size_t orec = ipix * 64 + (size_t)(vbase - opl * CW) * sizeof(T);
+          const size_t orec = ipix * REC + (size_t)(vbase - opl * CW) * sizeof(T);
 #pragma unroll
           for (int q = 0; q < RV; ++q) {
             r1v[mb][q] = (a.res1 && ok) ? *reinterpret_cast<const uint4*>(a.res1 + (size_t)(a.r1_plane0 + opl) * a.r1_plane_bytes + orec + 16 * q)
@@ -510,7 +587,7 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
               for (int i = 0; i < 16; ++i) v[i] *= a.alpha;
             }
             const int opl = oc / CW;
-            const size_t orec = opix * 64 + (size_t)(oc - opl * CW) * sizeof(T);
+            const size_t orec = opix * REC + (size_t)(oc - opl * CW) * sizeof(T);
             if (batch_res) {
               if (a.res1) {
                 float r[16];
@@ -527,7 +604,7 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
             } else {
               if (a.res1 && (!a.bsvd_resid || vbase == 0)) {
                 float r[16];
-                const size_t rrec = (a.epi <= EPI_NHWC_PS2) ? orec : ipix * 64;
+                const size_t rrec = (a.epi <= EPI_NHWC_PS2) ? orec : ipix * REC;
                 load16<T>(a.res1 + (size_t)(a.r1_plane0 + opl) * a.r1_plane_bytes + rrec, r);
                 if (a.bsvd_resid) {
 #pragma unroll
@@ -589,9 +666,10 @@ __global__ __launch_bounds__(64 * NW, (MB == 2 || NW == 8) ? 2 : 1) void conv3x3
 
 template <typename T, int NB, int MB, int NW, int DBG, bool GEN>
 static void launch_t(ss4k_ctx* ctx, const ConvArgs& a0, int groups, hipStream_t st) {
-  using G = Geo<MB, NW>;
-  constexpr size_t lds = (size_t)(2 * G::TILE_SLOTS + 2 * 18 * NB * 64) * 16 + NB * 32 * 2 * 4;
-  static_assert(lds <= ((MB == 2 && NW == 4) ? 80 : 160) * 1024, "LDS budget");
+  using G = Geo<T, MB, NW>;
+  constexpr size_t lds = lds_bytes<T, NB, MB, NW>();
+  constexpr int per_cu = wgs_per_cu<T, NB, MB, NW>();
+  static_assert(lds * per_cu <= 160 * 1024, "LDS budget");
   ConvArgs a = a0;
   a.tiles_y = (a.H + G::TH - 1) / G::TH;
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
@@ -601,26 +679,18 @@ static void launch_t(ss4k_ctx* ctx, const ConvArgs& a0, int groups, hipStream_t 
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  const int per_cu = (MB == 2 && NW == 4) ? 2 : 1;
   int gx = std::min(ntiles, std::max(1, ctx->num_cu * per_cu / groups));
   hipLaunchKernelGGL((conv3x3_kernel<T, NB, MB, NW, DBG, GEN>), dim3(gx, groups), dim3(64 * NW), lds, st, a);
   SS4K_HIP(hipGetLastError());
 }
 
+// ss4k_bench_conv only: instrumented (phase stamps) and alternative tile shapes of the fp16 kernel
 template <int NB, int MB, int NW>
 static void launch_dbg(ss4k_ctx* ctx, const ConvArgs& a, int groups, hipStream_t st) {
-  switch (a.dbg & ~DBG_MB4) {  // instrumented builds of the fp16 kernel for ss4k_bench_conv
+  switch (a.dbg & 0xff) {
     case DBG_STAMP: launch_t<__half, NB, MB, NW, DBG_STAMP, false>(ctx, a, groups, st); break;
-    // timing-only ablations (results are garbage): the chunk prefetch without its weight / halo-tile part
-    case DBG_STAMP | DBG_NO_W_DMA: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_W_DMA, false>(ctx, a, groups, st); break;
-    case DBG_STAMP | DBG_NO_TILE_DMA: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_TILE_DMA, false>(ctx, a, groups, st); break;
-    // same DMA instructions, but every source is one hot cache line (no memory traffic)
-    case DBG_STAMP | DBG_NO_MMA: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_MMA, false>(ctx, a, groups, st); break;
-    // halo tiles read from a 2 MB window (stays in L2): L2->LDS traffic as in production, no fabric traffic
-    case DBG_STAMP | DBG_NO_STORE: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_STORE, false>(ctx, a, groups, st); break;
-    case DBG_STAMP | DBG_NO_W_DMA | DBG_NO_TILE_DMA: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_W_DMA | DBG_NO_TILE_DMA, false>(ctx, a, groups, st); break;
     case 0: launch_t<__half, NB, MB, NW, 0, false>(ctx, a, groups, st); break;
-    default: throw Error(SS4K_EINVAL, "ss4k_bench_conv: supported flags are 0 and 32 (phase stamps), optionally | 64 (4-wave 16-row tiles)");
+    default: throw Error(SS4K_EINVAL, "ss4k_bench_conv: flags are 0 or 32 (phase stamps), | tile-shape id << 8");
   }
 }
 
@@ -633,25 +703,37 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
   SS4K_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0, "conv3x3: empty grid");
   SS4K_REQUIRE(a.act != ACT_LRELU || (a.slope >= 0.f && a.slope <= 1.f), "conv3x3: LeakyReLU slope must be in [0,1]");
   SS4K_REQUIRE(!a.ups2 || ((a.H % 2 == 0) && (a.W % 2 == 0)), "conv3x3: ups2 needs even grid");
-  SS4K_REQUIRE((double)a.N * a.H * a.W * 64.0 < 4294967296.0, "conv3x3: a plane must stay below 4 GiB");
+  SS4K_REQUIRE((double)a.N * a.H * a.W * (dtype == SS4K_F16 ? 32.0 : 64.0) < 4294967296.0, "conv3x3: a plane must stay below 4 GiB");
   ProfEvent pe{};
   if (ctx->prof) {
     if (!ctx->prof_pool.empty()) { pe = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); }
     else { SS4K_HIP(hipEventCreate(&pe.a)); SS4K_HIP(hipEventCreate(&pe.b)); }
     SS4K_HIP(hipEventRecord(pe.a, st));
   }
-  // fp16: 32-cout layers run the 8-row-tile build (two workgroups per CU), 64-cout layers the
-  // 8-wave build (16-row tile, two waves per SIMD in one workgroup); DBG_MB4 forces 4 waves x 4 rows
-  const bool alt = dtype == SS4K_F16 && !(a.dbg & DBG_MB4);
+  // fp16 tile shapes <couts/32, rows per wave, waves>; see DESIGN.md 4.1 for how they were chosen
   if (a.dbg) {
     SS4K_REQUIRE(dtype == SS4K_F16, "instrumented builds exist for fp16 only");
-    if (nb == 1) { if (alt) launch_dbg<1, 2, 4>(ctx, a, groups, st); else launch_dbg<1, 2, 8>(ctx, a, groups, st); }
-    else { if (alt) launch_dbg<2, 2, 8>(ctx, a, groups, st); else launch_dbg<2, 4, 4>(ctx, a, groups, st); }
+    const int shape = (a.dbg >> 8) & 7;
+    if (nb == 1) {
+      switch (shape) {
+        case 1: launch_dbg<1, 2, 4>(ctx, a, groups, st); break;
+        case 3: launch_dbg<1, 2, 8>(ctx, a, groups, st); break;
+        case 4: launch_dbg<1, 4, 8>(ctx, a, groups, st); break;
+        default: launch_dbg<1, 4, 4>(ctx, a, groups, st); break;
+      }
+    } else {
+      switch (shape) {
+        case 2: launch_dbg<2, 4, 4>(ctx, a, groups, st); break;
+        case 3: launch_dbg<2, 4, 8>(ctx, a, groups, st); break;
+        case 4: launch_dbg<2, 2, 4>(ctx, a, groups, st); break;
+        default: launch_dbg<2, 2, 8>(ctx, a, groups, st); break;
+      }
+    }
   } else {
     const bool gen = !(a.epi == EPI_NHWC && !a.bsvd_resid);
     if (dtype == SS4K_F16) {
-      if (nb == 1) { if (gen) launch_t<__half, 1, 2, 4, 0, true>(ctx, a, groups, st); else launch_t<__half, 1, 2, 4, 0, false>(ctx, a, groups, st); }
-      else { if (gen) launch_t<__half, 2, 2, 8, 0, true>(ctx, a, groups, st); else launch_t<__half, 2, 2, 8, 0, false>(ctx, a, groups, st); }
+      if (nb == 1) { if (gen) launch_t<__half, 1, 4, 4, 0, true>(ctx, a, groups, st); else launch_t<__half, 1, 4, 4, 0, false>(ctx, a, groups, st); }
+      else { if (gen) launch_t<__half, 2, 2, 8, 0, true>(ctx, a, groups, st); else launch_t<__half, 2, 4, 4, 0, false>(ctx, a, groups, st); }
     } else {
       if (nb == 1) { if (gen) launch_t<float, 1, 4, 4, 0, true>(ctx, a, groups, st); else launch_t<float, 1, 4, 4, 0, false>(ctx, a, groups, st); }
       else { if (gen) launch_t<float, 2, 4, 4, 0, true>(ctx, a, groups, st); else launch_t<float, 2, 4, 4, 0, false>(ctx, a, groups, st); }

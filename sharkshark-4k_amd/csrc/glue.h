@@ -21,7 +21,7 @@ void op_pack_input(const float* in, T* out, int n, int c, int h, int w, int r, i
 template <typename T>
 void op_ps_nchw_addbase(const T* src, float* out, const float* base, int n, int h, int w, int r, int cq, hipStream_t st);
 
-void op_temporal_shift(const void* in, void* out, int nplanes, int frames, size_t frame_px, int ch_per_slot,
+void op_temporal_shift(const void* in, void* out, int nplanes, int frames, size_t frame_px, int slots_per_record,
                        int ch_per_plane, int fold, hipStream_t st);
 
 // FSRCNN (fsrcnn.hip): whole-network forward on fp32 planes, weights in the device layout

@@ -235,7 +235,7 @@ void op_f32nchw_to_u8nhwc(const float* in, uint8_t* out, int n, int c, int h, in
 template <typename T, int R>
 __global__ void k_pack_input(const float* __restrict__ in, T* __restrict__ out, int n, int c, int h, int w,
                              int nplanes) {
-  constexpr int CW = 64 / sizeof(T);
+  constexpr int CW = 16, RV = CW * sizeof(T) / 16;  // 16-channel records of RV 16-byte slots
   const int oh = h / R, ow = w / R;
   const size_t total = (size_t)n * oh * ow;
   const int creal = c * R * R;
@@ -243,7 +243,7 @@ __global__ void k_pack_input(const float* __restrict__ in, T* __restrict__ out, 
     const int ox = i % ow, oy = (i / ow) % oh;
     const size_t img = i / ((size_t)ow * oh);
     for (int p = 0; p < nplanes; ++p) {
-      T rec[CW];  // one 64-byte record, written with four 16-byte stores
+      T rec[CW];  // one record, written with 16-byte stores
 #pragma unroll
       for (int q = 0; q < CW; ++q) {
         const int k = p * CW + q;
@@ -257,7 +257,7 @@ __global__ void k_pack_input(const float* __restrict__ in, T* __restrict__ out, 
       uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)p * total + i) * CW);
       const uint4* src = reinterpret_cast<const uint4*>(rec);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) dst[q] = src[q];
+      for (int q = 0; q < RV; ++q) dst[q] = src[q];
     }
   }
 }
@@ -277,7 +277,7 @@ template void op_pack_input<__half>(const float*, __half*, int, int, int, int, i
 template <typename T>
 __global__ void k_ps_nchw_addbase(const T* __restrict__ src, float* __restrict__ out, const float* __restrict__ base,
                                   int n, int h, int w, int r, int cq) {
-  constexpr int CW = 64 / sizeof(T);
+  constexpr int CW = 16;
   const int OH = h * r, OW = w * r;
   const size_t total = (size_t)n * cq * OH * OW, npix = (size_t)n * h * w;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -304,26 +304,28 @@ template void op_ps_nchw_addbase<__half>(const __half*, float*, const float*, in
 // the rest from frame t.  Only the leading planes that hold channels < 2*fold are rebuilt here (the
 // conv reads the remaining planes from the tensor itself); one thread per 16-byte slot.
 __global__ void k_temporal_shift(const uint4* __restrict__ in, uint4* __restrict__ out, int nplanes, int frames,
-                                 size_t frame_px, int ch_per_slot, int ch_per_plane, int fold) {
-  const size_t slots_per_plane = (size_t)frames * frame_px * 4;
+                                 size_t frame_px, int spr, int ch_per_plane, int fold) {
+  const int ch_per_slot = ch_per_plane / spr;
+  const size_t slots_per_plane = (size_t)frames * frame_px * spr;
   const size_t total = slots_per_plane * nplanes;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int p = (int)(i / slots_per_plane);
     const size_t r = i - (size_t)p * slots_per_plane;
-    const int t = (int)(r / (frame_px * 4));
-    const int ch0 = p * ch_per_plane + (int)(r & 3) * ch_per_slot;
+    const int t = (int)(r / (frame_px * spr));
+    const int ch0 = p * ch_per_plane + (int)(r % spr) * ch_per_slot;
     const int ts = ch0 < fold ? t + 1 : (ch0 < 2 * fold ? t - 1 : t);
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (ts >= 0 && ts < frames) v = in[i + (ptrdiff_t)(ts - t) * (ptrdiff_t)(frame_px * 4)];
+    if (ts >= 0 && ts < frames) v = in[i + (ptrdiff_t)(ts - t) * (ptrdiff_t)(frame_px * spr)];
     out[i] = v;
   }
 }
-void op_temporal_shift(const void* in, void* out, int nplanes, int frames, size_t frame_px, int ch_per_slot,
+void op_temporal_shift(const void* in, void* out, int nplanes, int frames, size_t frame_px, int slots_per_record,
                        int ch_per_plane, int fold, hipStream_t st) {
-  if (fold % ch_per_slot != 0) throw Error(SS4K_EINVAL, "temporal shift: fold must be a multiple of the 16-byte channel group");
-  hipLaunchKernelGGL(k_temporal_shift, grid1d((size_t)nplanes * frames * frame_px * 4), dim3(256), 0, st,
+  if (fold % (ch_per_plane / slots_per_record) != 0)
+    throw Error(SS4K_EINVAL, "temporal shift: fold must be a multiple of the 16-byte channel group");
+  hipLaunchKernelGGL(k_temporal_shift, grid1d((size_t)nplanes * frames * frame_px * slots_per_record), dim3(256), 0, st,
                      reinterpret_cast<const uint4*>(in), reinterpret_cast<uint4*>(out), nplanes, frames, frame_px,
-                     ch_per_slot, ch_per_plane, fold);
+                     slots_per_record, ch_per_plane, fold);
 }
 
 }  // namespace ss4k

@@ -254,9 +254,9 @@ Tens Model::act(int idx, size_t pixels, int channels) {
   if ((int)acts.size() <= idx) acts.resize(idx + 1);
   const int ch32 = (channels + 31) / 32 * 32;
   const int planes = planes_for(ch32);
-  SS4K_REQUIRE((double)pixels * 64.0 < 4294967296.0, "activation plane must stay below 4 GiB");
-  acts[idx].ensure((size_t)planes * pixels * 64);
-  return Tens{acts[idx].as<char>(), (uint32_t)(pixels * 64), 0};
+  SS4K_REQUIRE((double)pixels * rec() < 4294967296.0, "activation plane must stay below 4 GiB");
+  acts[idx].ensure((size_t)planes * pixels * rec());
+  return Tens{acts[idx].as<char>(), (uint32_t)(pixels * rec()), 0};
 }
 
 void Model::out_shape(int n, int h, int w, int* oc, int* oh, int* ow) const {
@@ -284,7 +284,7 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
     // the conv kernel addresses a plane with 32-bit byte offsets: split batches whose largest
     // internal tensor (at output resolution) would exceed 4 GiB per plane (e.g. 4 frames at 4320x7680)
     int oc, oh, ow; out_shape(1, h, w, &oc, &oh, &ow);
-    const double plane1 = (double)std::max(oh, h) * std::max(ow, w) * 64.0;
+    const double plane1 = (double)std::max(oh, h) * std::max(ow, w) * (double)rec();
     SS4K_REQUIRE(plane1 < 4294967296.0, "forward: a single frame exceeds the 4 GiB plane limit");
     const int max_n = std::max(1, (int)(4294967295.0 / plane1));
     if (n > max_n) {
@@ -385,8 +385,7 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
       if (!desc.bsvd_stream) { conv(li++, masked(t, c), nullptr, N, H, W, relu6(outT), st); return; }
       const int lead = shifted_planes(c);
       Tens S = act(14, (size_t)N * H * W, lead * cw());
-      op_temporal_shift(t.p + (size_t)t.plane0 * t.plane_bytes, S.p, lead, N, (size_t)H * W, 16 / (int)esz(desc.dtype), cw(),
-                        c / 8, st);
+      op_temporal_shift(t.p + (size_t)t.plane0 * t.plane_bytes, S.p, lead, N, (size_t)H * W, rec() / 16, cw(), c / 8, st);
       const Tens rest{t.p, t.plane_bytes, t.plane0 + lead};
       conv(li++, S, planes_for(c) > lead ? &rest : nullptr, N, H, W, relu6(outT), st);
     };
@@ -427,7 +426,7 @@ double bench_conv_layer(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, 
   Tens X = m.act(0, px, cin0), G = m.act(1, px, std::max(cin1, 32)), O = m.act(2, px, cout);
   {  // random operands: constant data lets the chip hold a higher clock than real frames do
     auto fill = [&](Tens& t, int ch) {
-      const size_t bytes = (size_t)m.planes_for(ch) * px * 64;
+      const size_t bytes = (size_t)m.planes_for(ch) * px * m.rec();
       std::vector<uint32_t> hbuf(bytes / 4);
       for (auto& v : hbuf) {
         s = s * 1664525u + 1013904223u;

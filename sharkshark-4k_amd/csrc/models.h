@@ -5,7 +5,7 @@
 
 namespace ss4k {
 
-// activation view in the "planes" layout (conv_mfma.hip): base, bytes per plane (N*H*W*64), first plane
+// activation view in the "planes" layout (conv_mfma.hip): base, bytes per plane (N*H*W*record), first plane
 struct Tens { char* p; uint32_t plane_bytes; int plane0; };
 
 struct ConvLayer {
@@ -55,6 +55,7 @@ struct Model {
   // planes holding the time-shifted channels [0, c/4) of a BiBufferConv input (whole planes)
   int shifted_planes(int c) const { return std::min(planes_for(c), (c / 4 + cw() - 1) / cw()); }
   int cw() const { return conv_cw(desc.dtype); }
+  int rec() const { return conv_rec_bytes(desc.dtype); }  // bytes per pixel record of a plane
   int planes_for(int channels) const { return (channels + cw() - 1) / cw(); }
   void conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, const ConvOpts& o, hipStream_t st);
   Tens act(int idx, size_t pixels, int channels);

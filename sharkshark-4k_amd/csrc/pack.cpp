@@ -1,7 +1,7 @@
 // Host-side repacking of PyTorch OIHW conv weights into the MFMA fragment order the conv kernel
 // DMAs straight into LDS (see conv_mfma.hip).  Pure host code: no HIP calls.
 //
-// Packed order: [group][chunk][dx(3) x ks(2)][dy(3)][nb][lane(64)][E]
+// Packed order: [group][chunk of 16 cin][dx(3) x ks(KS: 1 fp16, 2 fp32)][dy(3)][nb][lane(64)][E]
 //   lane l: MFMA row rho = l & 31 (-> output channel, permuted so a lane of the result holds 16
 //   contiguous channels), k half hk = l >> 5; element e: channel (2*ks + hk) * E + e of the chunk.
 #include "common.h"
@@ -42,7 +42,7 @@ int virt_to_real_cout(const PackSpec& s, int v) {
 }
 
 PackedConv pack_conv3x3(const PackSpec& s, const float* w, const float* bias, const float* prelu) {
-  const int E = s.dtype == SS4K_F16 ? 8 : 4, CW = 4 * E;
+  const int E = s.dtype == SS4K_F16 ? 8 : 4, CW = 16, KS = CW / (2 * E);  // k-steps per 16-channel chunk
   const int nchunks = s.nchunks0 + s.nchunks1;
   SS4K_REQUIRE((int)s.cin_map.size() == nchunks * CW, "pack_conv3x3: cin_map size");
   PackedConv p;
@@ -51,7 +51,7 @@ PackedConv pack_conv3x3(const PackSpec& s, const float* w, const float* bias, co
   p.cout_pad = (s.cout_real + gw - 1) / gw * gw;
   p.groups = p.cout_pad / gw;
   const size_t esz = s.dtype == SS4K_F16 ? 2 : 4;
-  const size_t nelem = (size_t)p.groups * nchunks * 18 * p.nb * 64 * E;
+  const size_t nelem = (size_t)p.groups * nchunks * 9 * KS * p.nb * 64 * E;
   p.w.assign(nelem * esz, 0);
   p.bias.assign(p.cout_pad, 0.f);
   p.prelu.assign(p.cout_pad, 0.f);
@@ -63,7 +63,7 @@ PackedConv pack_conv3x3(const PackSpec& s, const float* w, const float* bias, co
   for (int g = 0; g < p.groups; ++g)
     for (int c = 0; c < nchunks; ++c)
       for (int dx = 0; dx < 3; ++dx)
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
           for (int dy = 0; dy < 3; ++dy)
             for (int nb = 0; nb < p.nb; ++nb)
               for (int lane = 0; lane < 64; ++lane) {
