@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 #include <stdexcept>
@@ -62,6 +63,7 @@ struct ss4k_ctx {
   std::vector<ss4k::ProfEvent> prof_events;
   std::vector<ss4k::ProfEvent> prof_pool;
   int64_t prof_launches = 0;
+  std::set<const void*> lds_attr_set;  // kernels whose dynamic-LDS limit was raised on this device
   double prof_ms = 0, prof_flops = 0;
   const char* zero_page() {
     auto& b = scratch["zero_page"];

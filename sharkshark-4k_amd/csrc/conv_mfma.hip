@@ -673,12 +673,9 @@ static void launch_t(ss4k_ctx* ctx, const ConvArgs& a0, int groups, hipStream_t 
   ConvArgs a = a0;
   a.tiles_y = (a.H + G::TH - 1) / G::TH;
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SS4K_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, NB, MB, NW, DBG, GEN>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  const void* fn = reinterpret_cast<const void*>(&conv3x3_kernel<T, NB, MB, NW, DBG, GEN>);
+  if (ctx->lds_attr_set.insert(fn).second)  // per context = per device
+    SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int gx = std::min(ntiles, std::max(1, ctx->num_cu * per_cu / groups));
   hipLaunchKernelGGL((conv3x3_kernel<T, NB, MB, NW, DBG, GEN>), dim3(gx, groups), dim3(64 * NW), lds, st, a);
   SS4K_HIP(hipGetLastError());

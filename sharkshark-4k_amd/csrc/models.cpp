@@ -284,7 +284,10 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
     // the conv kernel addresses a plane with 32-bit byte offsets: split batches whose largest
     // internal tensor (at output resolution) would exceed 4 GiB per plane (e.g. 4 frames at 4320x7680)
     int oc, oh, ow; out_shape(1, h, w, &oc, &oh, &ow);
-    const double plane1 = (double)std::max(oh, h) * std::max(ow, w) * (double)rec();
+    // largest grid a "planes" tensor of this network lives on: RRDBNet's tail runs at the output
+    // resolution; SRVGG (PixelShuffle in the glue tail) and BSVD never leave the input resolution
+    const bool tail_at_out = desc.kind == SS4K_RRDBNET;
+    const double plane1 = (double)(tail_at_out ? std::max(oh, h) : h) * (tail_at_out ? std::max(ow, w) : w) * (double)rec();
     SS4K_REQUIRE(plane1 < 4294967296.0, "forward: a single frame exceeds the 4 GiB plane limit");
     const int max_n = std::max(1, (int)(4294967295.0 / plane1));
     if (n > max_n) {

@@ -218,6 +218,43 @@ def test_service_rejects_bad_input(ctx):
         _capi.Model(ctx, _capi.make_desc(_capi.FSRCNN, _capi.F32, scale=2), np.zeros(10, np.float32))
 
 
+# ------------------------------------------------------------------------------ image-server mode
+_IMG_MODE = {"sr": "srvgg", "seed": 41, "num_feat": 32, "num_conv": 2, "upscale": 4, "mode": "realesrgan",
+             "lr_shape": [360, 640], "output_shape": None, "lr_hr_resize": False, "denoising": False,
+             "denoise_rate": 0.2, "single_mode": None, "bsvd_seed": 21}
+
+
+@pytest.mark.parametrize("hw", [(61, 83), (129, 257), (203, 99)])
+def test_image_mode_any_shape_vs_oracle(ctx, hw):
+    """The HTTP image path's service configuration (image_pipeline.py:58-63: realesrgan, batch_size=1,
+    lr_hr_resize=False, denoising off) on one (1,H,W,3) frame of arbitrary, odd size
+    (image_pipeline.py:280-287): no resize to lr_shape, x4 network, stats + colour match, truncation."""
+    up, keep = _hip_service_from_manifest(ctx, _IMG_MODE)
+    frame = torch.from_numpy(smooth_u8(50 + hw[0], (1, hw[0], hw[1], 3)))
+    got = up(frame.cuda())
+    assert got.shape == (1, 4 * hw[0], 4 * hw[1], 3)
+    want = oracle_service_from_manifest(_IMG_MODE).upscale(frame)
+    assert_u8_close(got, want.numpy(), what=f"image mode {hw}")
+
+
+def test_image_mode_max_size_runs(ctx):
+    """Largest frame the image server admits (4096x2048 pixels, image_pipeline.py:265-271) through the
+    shipped default net (SRVGG x4, fp16): 16384x8192 out.  Size-independent checks: the channel
+    statistics match makes every output channel's mean equal the input's (within truncation), and
+    the call is deterministic."""
+    sr = factory.build_model_esrgan(ctx, "realesr-general-x4v3", dtype="f16", seed=3)
+    up = _capi.Upscaler(ctx, sr, (360, 640), None, False, False, None, 0.2)
+    frame = torch.from_numpy(smooth_u8(77, (1, 2048, 4096, 3))).cuda()
+    out = up(frame)
+    assert out.shape == (1, 8192, 16384, 3) and out.dtype == torch.uint8
+    m_in = frame.float().mean(dim=(0, 1, 2))
+    m_out = out[:, ::4, ::4].float().mean(dim=(0, 1, 2))
+    assert (m_in - m_out).abs().max() < 1.5, (m_in, m_out)
+    assert torch.equal(out[:, :64], up(frame)[:, :64])
+    del out
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------------------ full size (BASELINE configs), size-independent properties
 def test_fsrcnn_720p_properties(ctx):
     """C2 size: linearity in the deconv bias and per-plane independence, plus a sampled-window oracle check."""
