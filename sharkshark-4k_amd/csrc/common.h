@@ -106,6 +106,7 @@ struct ConvArgs {
   char* out; uint32_t out_plane_bytes; int out_plane0;
   int cout_real, cout_pad;
   int tiles_x, tiles_y;
+  int reverse;                          // walk the tiles back to front (placement only, never results)
   double flops;                         // algorithmic FLOPs of this layer (profiling only)
   int dbg;                              // selects an ablation build (ss4k_bench_conv only; 0 in production)
   unsigned long long* dbg_buf;          // DBG_STAMP: per-workgroup phase cycle counters

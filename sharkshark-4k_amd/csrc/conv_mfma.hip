@@ -159,11 +159,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
   // the same L2.  Placement only changes speed, never results.
   const bool banded = (gridDim.x % 8 == 0) && ntiles >= (int)gridDim.x;
   const int tpx = (ntiles + 7) / 8;
+  // a.reverse walks the same tiles back to front (inside each XCD's band, so the band -> XCD map
+  // stays): consecutive layers alternate direction, and a layer starts on the planes the previous
+  // one touched last - still in that XCD's L2 / the Infinity Cache
   auto tile_of = [&](int k) -> int {
-    if (!banded) { const int t = blockIdx.x + k * gridDim.x; return t < ntiles ? t : -1; }
+    if (!banded) {
+      const int t = blockIdx.x + k * gridDim.x;
+      return t < ntiles ? (a.reverse ? ntiles - 1 - t : t) : -1;
+    }
+    const int base = (blockIdx.x & 7) * tpx, len = min(tpx, ntiles - base);
     const int j = (blockIdx.x >> 3) + k * (gridDim.x >> 3);
-    const int t = (blockIdx.x & 7) * tpx + j;
-    return (j < tpx && t < ntiles) ? t : -1;
+    return j < len ? base + (a.reverse ? len - 1 - j : j) : -1;
   };
 
   // bank swizzle of a pixel's 16-byte slots by its x: makes every ds_read_b128 operand read

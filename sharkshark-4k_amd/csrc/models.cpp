@@ -4,6 +4,7 @@
 #include "models.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace ss4k {
 
@@ -158,6 +159,7 @@ PackSpec Model::spec_shifted(int c) const {
 
 void Model::build(const float* w, size_t n) {
   validate_desc(desc);
+  if (const char* e = std::getenv("SS4K_NO_FLIP")) flip_walk = !(e[0] == '1');  // A/B switch for the tile-walk direction
   SS4K_REQUIRE(n == model_param_count(desc), "weight blob size does not match the model description");
   ParamCursor pc{w, n};
   if (desc.kind == SS4K_FSRCNN) {
@@ -244,6 +246,7 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
   a.epi = o.epi; a.out = o.out.p; a.out_plane_bytes = o.out.plane_bytes; a.out_plane0 = o.out.plane0;
   a.cout_real = L.cout_real; a.cout_pad = L.cout_pad;
   a.dbg = dbg; a.dbg_buf = dbg_buf;
+  a.reverse = (flip_walk && (launch_parity ^= 1)) ? 1 : 0;
   a.flops = 2.0 * 9.0 * L.cin_real * L.cout_real * (double)N * H * W * (o.epi == EPI_NHWC_SUB2 ? 0.25 : 1.0);
   launch_conv3x3(ctx, a, desc.dtype, st);
 }

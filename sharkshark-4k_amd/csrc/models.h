@@ -34,6 +34,8 @@ struct Model {
   std::vector<DevBuf> acts;
   DevBuf fs_blob; FsrcnnWeights fsw{};
   size_t weight_bytes = 0;
+  bool flip_walk = true;   // consecutive conv launches walk their tiles in opposite directions (cache reuse)
+  int launch_parity = 0;
   int dbg = 0;  // ablation build selector forwarded to the conv kernel (bench only)
   unsigned long long* dbg_buf = nullptr;
 
