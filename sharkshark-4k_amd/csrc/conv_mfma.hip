@@ -115,6 +115,35 @@ template <> __device__ __forceinline__ void store16<float>(char* p, const float*
     *reinterpret_cast<float4*>(p + 16 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
+// one lane's 8-channel half record (16 bytes fp16, 32 bytes fp32)
+template <typename T> __device__ __forceinline__ void load8(const char* p, float* v);
+template <> __device__ __forceinline__ void load8<__half>(const char* p, float* v) {
+  const uint4 a = *reinterpret_cast<const uint4*>(p);
+  const __half* ha = reinterpret_cast<const __half*>(&a);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = __half2float(ha[i]);
+}
+template <> __device__ __forceinline__ void load8<float>(const char* p, float* v) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float4 a = *reinterpret_cast<const float4*>(p + 16 * q);
+    v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+  }
+}
+template <typename T> __device__ __forceinline__ void store8(char* p, const float* v);
+template <> __device__ __forceinline__ void store8<__half>(char* p, const float* v) {
+  uint4 a;
+  __half* ha = reinterpret_cast<__half*>(&a);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ha[i] = __float2half(v[i]);
+  *reinterpret_cast<uint4*>(p) = a;
+}
+template <> __device__ __forceinline__ void store8<float>(char* p, const float* v) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    *reinterpret_cast<float4*>(p + 16 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
 template <typename T>
 __device__ __forceinline__ f32x16 mma(const uint4& w, const uint4& x, f32x16 acc) {
   if constexpr (sizeof(T) == 2) {
@@ -230,7 +259,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
     if (idx < NDMA_T) {
       const int k = wave + NW * idx;
       if (k < TILE_DMA && !(DBG & DBG_NO_TILE_DMA)) {
-        const char* src = (src_off[idx] != OOB && !(DBG & DBG_NO_MMA)) ? ((DBG & DBG_NO_STORE) ? a.in0 + (src_off[idx] & 0x1FFFFFu) : pf_plane + src_off[idx]) : a.zero_page + (lane & 3) * 16;
+        const char* src = (src_off[idx] != OOB && !(DBG & DBG_NO_MMA)) ? ((((DBG & DBG_NO_STORE) != 0) != ((DBG & DBG_NO_EPILOGUE) != 0)) ? a.in0 + (src_off[idx] & 0x1FFFFFu) : pf_plane + src_off[idx]) : a.zero_page + (lane & 3) * 16;
         const uint32_t dst = __builtin_amdgcn_readfirstlane(pf_tdst + k * 1024);
         if (plan[idx] >= 0) dma16(src, dst);  // lanes past the tile's last slot are masked off (EXEC)
       }
@@ -286,7 +315,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
       float bias_v[16];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 b4 = *reinterpret_cast<const float4*>(epi_lds + nb * 32 + 16 * lh + 4 * q);
+        const float4 b4 = *reinterpret_cast<const float4*>(epi_lds + nb * 32 + 16 * (q >> 1) + 8 * lh + 4 * (q & 1));
         bias_v[4 * q] = b4.x; bias_v[4 * q + 1] = b4.y; bias_v[4 * q + 2] = b4.z; bias_v[4 * q + 3] = b4.w;
       }
 #pragma unroll
@@ -416,10 +445,28 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
       }
     }
 
+    // Hand the LDS buffers over to the next tile BEFORE the epilogue: vmcnt counts loads, stores and
+    // LDS-DMA together in issue order, so a wait placed after the epilogue would also sit out the
+    // round trip of this tile's output stores (measured: 18 % of the kernel).  Here only the DMA of
+    // the next tile's first chunk is outstanding; the stores then drain under that chunk's MFMAs,
+    // and the waves run their epilogues unsynchronised.  The epilogue touches no tile buffer.
+    if (next_tile >= 0) {
+      dma_wait();       // next tile's first chunk has landed
+      { const unsigned long long t = stamp(); st_wait += t - st_t; st_t = t; }
+      __syncthreads();  // all waves are done with the last buffer
+      buf ^= 1;
+      { const unsigned long long t = stamp(); st_bar += t - st_t; st_t = t; }
+    }
+
     // ---------------- epilogue: bias, activation, residuals, layout-aware store ----------------
     // The RRDB output is written in place over res2, so the compiler cannot hoist residual loads
     // past the stores: per 32-channel block issue every row's residual loads first, then consume
     // (one memory round trip per block instead of one per row).
+    // Lane (pixel p, half h) owns, per 32-cout block, channels 8h..8h+7 of its first plane
+    // (accumulator elements 0-7) and of its second plane (elements 8-15): one store instruction of
+    // the wave = plane X, 32 pixels x two 16-byte halves = one fully contiguous kilobyte.
+    constexpr int HB = 8 * (int)sizeof(T);  // bytes of an 8-channel half record
+    constexpr int RV8 = HB / 16;
     const bool batch_res = a.epi == EPI_NHWC && !a.bsvd_resid && (a.res1 || a.res2);
     // Fast path (every RRDBNet / SRVGG body layer): plain layout, branch-free arithmetic
     //   v = act(acc) * alpha + res1;  v = v * gamma + res2      (absent residuals are zeros,
@@ -430,21 +477,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
     // loop (spilling in the 4-rows-per-wave builds).  Re-derive them per tile instead.
     int lhe = lh;
     asm volatile("" : "+v"(lhe));
-    if constexpr (!(DBG & DBG_NO_EPILOGUE))
     if (fast_epi) {
       const float alpha = a.alpha, gamma = a.gamma;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const int vbase = (grp * NB + nb) * 32 + 16 * lhe;
-        if ((grp * NB + nb) * 32 >= a.cout_pad) continue;
+        const int vblock = (grp * NB + nb) * 32;
+        if (vblock >= a.cout_pad) continue;
         float slope_v[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 s4 = *reinterpret_cast<const float4*>(epi_lds + NB * 32 + nb * 32 + 16 * lhe + 4 * q);
+          const float4 s4 = *reinterpret_cast<const float4*>(epi_lds + NB * 32 + nb * 32 + 16 * (q >> 1) + 8 * lhe + 4 * (q & 1));
           slope_v[4 * q] = s4.x; slope_v[4 * q + 1] = s4.y; slope_v[4 * q + 2] = s4.z; slope_v[4 * q + 3] = s4.w;
         }
-        const int opl = vbase / CW;
-        const size_t sub = (size_t)(vbase - opl * CW) * sizeof(T);
+        const int opl = vblock / CW;  // first of this block's two planes
+        const size_t sub = (size_t)lhe * HB;
         const char* r1p = a.res1 ? a.res1 + (size_t)(a.r1_plane0 + opl) * a.r1_plane_bytes + sub : nullptr;
         const char* r2p = a.res2 ? a.res2 + (size_t)(a.r2_plane0 + opl) * a.r2_plane_bytes + sub : nullptr;
         char* outp = a.out + (size_t)(a.out_plane0 + opl) * a.out_plane_bytes + sub;
@@ -475,7 +521,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
             }
             if (ok) {
               if constexpr ((DBG & DBG_NO_STORE) != 0) { if (v[0] == 12345.678f) a.out[0] = 1; }
-              else store16<T>(outp + (pix0 + (size_t)mb * a.W) * REC, v);
+              else {
+                char* o = outp + (pix0 + (size_t)mb * a.W) * REC;
+                store8<T>(o, v);
+                store8<T>(o + a.out_plane_bytes, v + 8);
+              }
             }
           }
         } else {
@@ -484,17 +534,19 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
           constexpr int RB = (NB * MB >= 8) ? 1 : 2;  // 128 accumulator registers leave room for one row only
 #pragma unroll
           for (int mb0 = 0; mb0 < MB; mb0 += RB) {
-            uint4 r1v[RB][RV], r2v[RB][RV];
+            uint4 r1v[RB][2][RV8], r2v[RB][2][RV8];
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
               const int mb = mb0 + j;
               const bool ok = (cur_y0 + wave * MB + mb) < a.H && xo < a.W;
               const size_t rec = (pix0 + (size_t)mb * a.W) * REC;
 #pragma unroll
-              for (int q = 0; q < RV; ++q) {
-                r1v[j][q] = (r1p && ok) ? *reinterpret_cast<const uint4*>(r1p + rec + 16 * q) : make_uint4(0, 0, 0, 0);
-                r2v[j][q] = (r2p && ok) ? *reinterpret_cast<const uint4*>(r2p + rec + 16 * q) : make_uint4(0, 0, 0, 0);
-              }
+              for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+                for (int q = 0; q < RV8; ++q) {
+                  r1v[j][hq][q] = (r1p && ok) ? *reinterpret_cast<const uint4*>(r1p + hq * (size_t)a.r1_plane_bytes + rec + 16 * q) : make_uint4(0, 0, 0, 0);
+                  r2v[j][hq][q] = (r2p && ok) ? *reinterpret_cast<const uint4*>(r2p + hq * (size_t)a.r2_plane_bytes + rec + 16 * q) : make_uint4(0, 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -502,8 +554,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
               const int mb = mb0 + j;
               const bool ok = (cur_y0 + wave * MB + mb) < a.H && xo < a.W;
               float v[16], r1[16], r2[16];
-              load16<T>(reinterpret_cast<const char*>(&r1v[j][0]), r1);
-              load16<T>(reinterpret_cast<const char*>(&r2v[j][0]), r2);
+#pragma unroll
+              for (int hq = 0; hq < 2; ++hq) {
+                load8<T>(reinterpret_cast<const char*>(&r1v[j][hq][0]), r1 + 8 * hq);
+                load8<T>(reinterpret_cast<const char*>(&r2v[j][hq][0]), r2 + 8 * hq);
+              }
 #pragma unroll
               for (int i = 0; i < 16; ++i) {
                 float t = acc[nb][mb][i];
@@ -515,7 +570,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
               }
               if (ok) {
                 if constexpr ((DBG & DBG_NO_STORE) != 0) { if (v[0] == 12345.678f) a.out[0] = 1; }
-                else store16<T>(outp + (pix0 + (size_t)mb * a.W) * REC, v);
+                else {
+                  char* o = outp + (pix0 + (size_t)mb * a.W) * REC;
+                  store8<T>(o, v);
+                  store8<T>(o + a.out_plane_bytes, v + 8);
+                }
               }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -523,138 +582,135 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-    } else if constexpr (GEN)
+    } else if constexpr (GEN) {
+      // general epilogue, one 8-channel half (hq) of a 32-cout block at a time
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int vbase = (grp * NB + nb) * 32 + 16 * lhe;
-      if (vbase >= a.cout_pad) continue;
-      float slope_v[16];
-      if (a.act == ACT_PRELU) {
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 s4 = *reinterpret_cast<const float4*>(epi_lds + NB * 32 + nb * 32 + 16 * lhe + 4 * q);
-          slope_v[4 * q] = s4.x; slope_v[4 * q + 1] = s4.y; slope_v[4 * q + 2] = s4.z; slope_v[4 * q + 3] = s4.w;
+      for (int hq = 0; hq < 2; ++hq) {
+        const int vbase = (grp * NB + nb) * 32 + 16 * hq + 8 * lhe;  // first of this lane's 8 channels
+        if ((grp * NB + nb) * 32 >= a.cout_pad) continue;
+        float slope_v[8];
+        if (a.act == ACT_PRELU) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const float4 s4 = *reinterpret_cast<const float4*>(epi_lds + NB * 32 + nb * 32 + 16 * hq + 8 * lhe + 4 * q);
+            slope_v[4 * q] = s4.x; slope_v[4 * q + 1] = s4.y; slope_v[4 * q + 2] = s4.z; slope_v[4 * q + 3] = s4.w;
+          }
         }
-      }
-      uint4 r1v[MB][RV], r2v[MB][RV];
-      if (batch_res) {
-        const int opl = vbase / CW;
+        uint4 r1v[MB][RV8], r2v[MB][RV8];
+        if (batch_res) {
+          const int opl = vbase / CW;
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            const int y = cur_y0 + wave * MB + mb;
+            const bool ok = y < a.H && xo < a.W;
+            const size_t ipix = ((size_t)cur_n * a.H + min(y, a.H - 1)) * a.W + min(xo, a.W - 1);
+            const size_t orec = ipix * REC + (size_t)(vbase - opl * CW) * sizeof(T);
+#pragma unroll
+            for (int q = 0; q < RV8; ++q) {
+              r1v[mb][q] = (a.res1 && ok) ? *reinterpret_cast<const uint4*>(a.res1 + (size_t)(a.r1_plane0 + opl) * a.r1_plane_bytes + orec + 16 * q)
+                                          : make_uint4(0, 0, 0, 0);
+              r2v[mb][q] = (a.res2 && ok) ? *reinterpret_cast<const uint4*>(a.res2 + (size_t)(a.r2_plane0 + opl) * a.r2_plane_bytes + orec + 16 * q)
+                                          : make_uint4(0, 0, 0, 0);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
           const int y = cur_y0 + wave * MB + mb;
-          const bool ok = y < a.H && xo < a.W;
-          const size_t ipix = ((size_t)cur_n * a.H + min(y, a.H - 1)) * a.W + min(xo, a.W - 1);
-          const size_t orec = ipix * REC + (size_t)(vbase - opl * CW) * sizeof(T);
+          if (y < a.H && xo < a.W) {
+            const size_t ipix = ((size_t)cur_n * a.H + y) * a.W + xo;
+            float v[8];
 #pragma unroll
-          for (int q = 0; q < RV; ++q) {
-            r1v[mb][q] = (a.res1 && ok) ? *reinterpret_cast<const uint4*>(a.res1 + (size_t)(a.r1_plane0 + opl) * a.r1_plane_bytes + orec + 16 * q)
-                                        : make_uint4(0, 0, 0, 0);
-            r2v[mb][q] = (a.res2 && ok) ? *reinterpret_cast<const uint4*>(a.res2 + (size_t)(a.r2_plane0 + opl) * a.r2_plane_bytes + orec + 16 * q)
-                                        : make_uint4(0, 0, 0, 0);
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 8; ++i) v[i] = acc[nb][mb][8 * hq + i];
+            if (a.act == ACT_LRELU) {  // slope in [0,1] (checked on the host): max(v, slope*v)
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const int y = cur_y0 + wave * MB + mb;
-        if (y < a.H && xo < a.W) {
-          const size_t ipix = ((size_t)cur_n * a.H + y) * a.W + xo;
-          float v[16];
+              for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], v[i] * a.slope);
+            } else if (a.act == ACT_PRELU) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) v[i] = acc[nb][mb][i];
-          if (a.act == ACT_LRELU) {  // slope in [0,1] (checked on the host): max(v, slope*v)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], v[i] * a.slope);
-          } else if (a.act == ACT_PRELU) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const float neg = v[i] * slope_v[i];  // unconditional: a select, not a branch per element
-              v[i] = v[i] >= 0.f ? v[i] : neg;
-            }
-          } else if (a.act == ACT_RELU6) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = fminf(fmaxf(v[i], 0.f), 6.f);
-          }
-          // where this 16-channel group lands
-          size_t opix = ipix; int oc = vbase; bool keep = true;
-          if (a.epi == EPI_NHWC_SUB2) {
-            keep = !((y | xo) & 1);
-            opix = ((size_t)cur_n * ((a.H + 1) >> 1) + (y >> 1)) * ((a.W + 1) >> 1) + (xo >> 1);
-          } else if (a.epi == EPI_NHWC_PS2) {
-            const int cp = a.cout_real >> 2, sub = vbase / cp;
-            oc = vbase - sub * cp;
-            opix = ((size_t)cur_n * 2 * a.H + 2 * y + (sub >> 1)) * (2 * a.W) + 2 * xo + (sub & 1);
-            keep = vbase < a.cout_real;
-          }
-          if (keep) {
-            if (a.alpha != 1.f) {
-#pragma unroll
-              for (int i = 0; i < 16; ++i) v[i] *= a.alpha;
-            }
-            const int opl = oc / CW;
-            const size_t orec = opix * REC + (size_t)(oc - opl * CW) * sizeof(T);
-            if (batch_res) {
-              if (a.res1) {
-                float r[16];
-                load16<T>(reinterpret_cast<const char*>(&r1v[mb][0]), r);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] += r[i];
+              for (int i = 0; i < 8; ++i) {
+                const float neg = v[i] * slope_v[i];  // unconditional: a select, not a branch per element
+                v[i] = v[i] >= 0.f ? v[i] : neg;
               }
-              if (a.res2) {
-                float r[16];
-                load16<T>(reinterpret_cast<const char*>(&r2v[mb][0]), r);
+            } else if (a.act == ACT_RELU6) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = v[i] * a.gamma + r[i];
+              for (int i = 0; i < 8; ++i) v[i] = fminf(fmaxf(v[i], 0.f), 6.f);
+            }
+            // where this 8-channel group lands
+            size_t opix = ipix; int oc = vbase; bool keep = true;
+            if (a.epi == EPI_NHWC_SUB2) {
+              keep = !((y | xo) & 1);
+              opix = ((size_t)cur_n * ((a.H + 1) >> 1) + (y >> 1)) * ((a.W + 1) >> 1) + (xo >> 1);
+            } else if (a.epi == EPI_NHWC_PS2) {
+              const int cp = a.cout_real >> 2, sub = vbase / cp;
+              oc = vbase - sub * cp;
+              opix = ((size_t)cur_n * 2 * a.H + 2 * y + (sub >> 1)) * (2 * a.W) + 2 * xo + (sub & 1);
+              keep = vbase < a.cout_real;
+            }
+            if (keep) {
+              if (a.alpha != 1.f) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] *= a.alpha;
               }
-            } else {
-              if (a.res1 && (!a.bsvd_resid || vbase == 0)) {
-                float r[16];
-                const size_t rrec = (a.epi <= EPI_NHWC_PS2) ? orec : ipix * REC;
-                load16<T>(a.res1 + (size_t)(a.r1_plane0 + opl) * a.r1_plane_bytes + rrec, r);
-                if (a.bsvd_resid) {
+              const int opl = oc / CW;
+              const size_t orec = opix * REC + (size_t)(oc - opl * CW) * sizeof(T);
+              if (batch_res) {
+                if (a.res1) {
+                  float r[8];
+                  load8<T>(reinterpret_cast<const char*>(&r1v[mb][0]), r);
 #pragma unroll
-                  for (int i = 0; i < 3; ++i) v[i] = r[i] - v[i];
-                } else {
+                  for (int i = 0; i < 8; ++i) v[i] += r[i];
+                }
+                if (a.res2) {
+                  float r[8];
+                  load8<T>(reinterpret_cast<const char*>(&r2v[mb][0]), r);
 #pragma unroll
-                  for (int i = 0; i < 16; ++i) v[i] += r[i];
+                  for (int i = 0; i < 8; ++i) v[i] = v[i] * a.gamma + r[i];
+                }
+              } else {
+                if (a.res1 && (!a.bsvd_resid || vbase == 0)) {
+                  float r[8];
+                  const size_t rrec = (a.epi <= EPI_NHWC_PS2) ? orec : ipix * REC + (size_t)(vbase % CW) * sizeof(T);
+                  load8<T>(a.res1 + (size_t)(a.r1_plane0 + (a.epi <= EPI_NHWC_PS2 ? opl : vbase / CW)) * a.r1_plane_bytes + rrec, r);
+                  if (a.bsvd_resid) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) v[i] = r[i] - v[i];
+                  } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] += r[i];
+                  }
+                }
+                if (a.res2) {
+                  float r[8];
+                  load8<T>(a.res2 + (size_t)(a.r2_plane0 + opl) * a.r2_plane_bytes + orec, r);
+#pragma unroll
+                  for (int i = 0; i < 8; ++i) v[i] = v[i] * a.gamma + r[i];
                 }
               }
-              if (a.res2) {
-                float r[16];
-                load16<T>(a.res2 + (size_t)(a.r2_plane0 + opl) * a.r2_plane_bytes + orec, r);
+              if constexpr ((DBG & DBG_NO_STORE) != 0) {
+                if (v[0] == 12345.678f) a.out[0] = 1;  // keep the values live without storing
+              } else if (a.epi <= EPI_NHWC_PS2) {
+                store8<T>(a.out + (size_t)(a.out_plane0 + opl) * a.out_plane_bytes + orec, v);
+              } else {  // EPI_NCHW_F32
+                float* o = reinterpret_cast<float*>(a.out);
+                const size_t plane = (size_t)a.H * a.W;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = v[i] * a.gamma + r[i];
+                for (int i = 0; i < 8; ++i)
+                  if (vbase + i < a.cout_real)
+                    o[((size_t)cur_n * a.cout_real + vbase + i) * plane + (size_t)y * a.W + xo] = v[i];
               }
-            }
-            if constexpr ((DBG & DBG_NO_STORE) != 0) {
-              if (v[0] == 12345.678f) a.out[0] = 1;  // keep the values live without storing
-            } else if (a.epi <= EPI_NHWC_PS2) {
-              const unsigned long long ts0 = stamp();
-              store16<T>(a.out + (size_t)(a.out_plane0 + opl) * a.out_plane_bytes + orec, v);
-              st_store += stamp() - ts0;
-            } else {  // EPI_NCHW_F32
-              float* o = reinterpret_cast<float*>(a.out);
-              const size_t plane = (size_t)a.H * a.W;
-#pragma unroll
-              for (int i = 0; i < 16; ++i)
-                if (vbase + i < a.cout_real)
-                  o[((size_t)cur_n * a.cout_real + vbase + i) * plane + (size_t)y * a.W + xo] = v[i];
             }
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
 
     { const unsigned long long t = stamp(); st_epi += t - st_t; st_t = t; }
     if (next_tile < 0) break;
     tile = next_tile; ++kt;
-    dma_wait();       // next tile's first chunk has landed
-    { const unsigned long long t = stamp(); st_wait += t - st_t; st_t = t; }
-    __syncthreads();  // all waves are done with the last buffer
-    buf ^= 1;
-    { const unsigned long long t = stamp(); st_bar += t - st_t; st_t = t; }
   }
   if constexpr ((DBG & DBG_STAMP) != 0) {
     const unsigned long long st_end = stamp();
@@ -692,6 +748,15 @@ template <int NB, int MB, int NW>
 static void launch_dbg(ss4k_ctx* ctx, const ConvArgs& a, int groups, hipStream_t st) {
   switch (a.dbg & 0xff) {
     case DBG_STAMP: launch_t<__half, NB, MB, NW, DBG_STAMP, false>(ctx, a, groups, st); break;
+    // timing-only ablations of the memory traffic (results are garbage), see DESIGN.md 4.1:
+    //   33: halo tiles from a 2 MB L2-resident window, no output stores   (no fabric traffic)
+    //   49: real halo tiles, no output stores                             (no fabric writes)
+    //   48: halo tiles from the 2 MB window, real stores                  (no fabric reads)
+    //   34: every DMA instruction reads one hot cache line                (no L2 traffic either)
+    case DBG_STAMP | DBG_NO_STORE: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_STORE, false>(ctx, a, groups, st); break;
+    case DBG_STAMP | DBG_NO_STORE | DBG_NO_EPILOGUE: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_STORE | DBG_NO_EPILOGUE, false>(ctx, a, groups, st); break;
+    case DBG_STAMP | DBG_NO_EPILOGUE: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_EPILOGUE, false>(ctx, a, groups, st); break;
+    case DBG_STAMP | DBG_NO_MMA: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_MMA, false>(ctx, a, groups, st); break;
     case 0: launch_t<__half, NB, MB, NW, 0, false>(ctx, a, groups, st); break;
     default: throw Error(SS4K_EINVAL, "ss4k_bench_conv: flags are 0 or 32 (phase stamps), | tile-shape id << 8");
   }

@@ -2,8 +2,9 @@
 // DMAs straight into LDS (see conv_mfma.hip).  Pure host code: no HIP calls.
 //
 // Packed order: [group][chunk of 16 cin][dx(3) x ks(KS: 1 fp16, 2 fp32)][dy(3)][nb][lane(64)][E]
-//   lane l: MFMA row rho = l & 31 (-> output channel, permuted so a lane of the result holds 16
-//   contiguous channels), k half hk = l >> 5; element e: channel (2*ks + hk) * E + e of the chunk.
+//   lane l: MFMA row rho = l & 31 (-> output channel, permuted so that result lane (pixel, h) holds
+//   channels 8h..8h+7 of the block's first 16-channel plane in accumulator elements 0-7 and of its
+//   second plane in elements 8-15), k half hk = l >> 5; element e: channel (2*ks + hk) * E + e of the chunk.
 #include "common.h"
 #include <cmath>
 
@@ -68,7 +69,7 @@ PackedConv pack_conv3x3(const PackSpec& s, const float* w, const float* bias, co
             for (int nb = 0; nb < p.nb; ++nb)
               for (int lane = 0; lane < 64; ++lane) {
                 const int rho = lane & 31, hk = lane >> 5;
-                const int v = (g * p.nb + nb) * 32 + 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);
+                const int v = (g * p.nb + nb) * 32 + 16 * (rho >> 4) + 8 * ((rho >> 2) & 1) + (rho & 3) + 4 * ((rho >> 3) & 1);
                 const int co = virt_to_real_cout(s, v);
                 for (int e = 0; e < E; ++e, ++idx) {
                   const int ci = s.cin_map[(size_t)c * CW + (2 * ks + hk) * E + e];
