@@ -28,16 +28,17 @@ __global__ __launch_bounds__(256) void k_fs_head(const float* __restrict__ in, f
   float f[56];
 #pragma unroll
   for (int c = 0; c < 56; ++c) f[c] = bf[c];
+  // A real loop over the 25 taps (not unrolled): one tap's 56 scalar weights are live at a time.
+  // Fully unrolled, hipcc hoists all 1400 invariant scalar loads to the top of the kernel and spills
+  // the SGPRs into VGPR lanes (2 x 1340 v_writelane/v_readlane per thread, 4x the useful work).
+#pragma unroll 1
+  for (int t = 0; t < 25; ++t) {
+    const int ky = t / 5, kx = t - ky * 5;
+    const int yy = y + ky - 2, xx = x + kx - 2;
+    const float v = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? src[(size_t)yy * w + xx] : 0.f;
+    const float* wt = wf + t * 56;
 #pragma unroll
-  for (int ky = 0; ky < 5; ++ky) {
-    const int yy = y + ky - 2;
-#pragma unroll
-    for (int kx = 0; kx < 5; ++kx) {
-      const int xx = x + kx - 2;
-      const float v = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? src[(size_t)yy * w + xx] : 0.f;
-#pragma unroll
-      for (int c = 0; c < 56; ++c) f[c] = fmaf(wf[(ky * 5 + kx) * 56 + c], v, f[c]);
-    }
+    for (int c = 0; c < 56; ++c) f[c] = fmaf(wt[c], v, f[c]);
   }
 #pragma unroll
   for (int c = 0; c < 56; ++c) f[c] = prelu(f[c], af[c]);
