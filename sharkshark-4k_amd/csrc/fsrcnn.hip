@@ -6,8 +6,7 @@
 // one contiguous kilobyte whatever the channel count.  Layers are fused where no halo is needed:
 //   head  = conv5x5(1->56)+PReLU -> conv1x1(56->12)+PReLU        (56-wide map never leaves registers)
 //   map   = conv3x3(12->12)+PReLU                                 (x4)
-//   tail  = conv1x1(12->56)+PReLU                                 (NHWC 56 for the deconv gather)
-//   deconv= ConvTranspose 9x9 stride s as s*s sub-pixel phases, all phases of one LR pixel per thread
+//   tail  = conv1x1(12->56)+PReLU -> ConvTranspose 9x9 stride s   (fused, exact-fp32 MFMA: k_fs_tail)
 #include "common.h"
 #include "glue.h"
 
@@ -89,92 +88,6 @@ __global__ __launch_bounds__(256) void k_fs_map(const float* __restrict__ in, fl
   for (int q = 0; q < 3; ++q)
     dst[q * total] = make_float4(prelu(s[4 * q], am[4 * q]), prelu(s[4 * q + 1], am[4 * q + 1]),
                          prelu(s[4 * q + 2], am[4 * q + 2]), prelu(s[4 * q + 3], am[4 * q + 3]));
-}
-
-__global__ __launch_bounds__(256) void k_fs_expand(const float* __restrict__ in, float* __restrict__ out,
-                                                   const float* __restrict__ we, const float* __restrict__ be,
-                                                   const float* __restrict__ ae, size_t total) {
-  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const float4* p = reinterpret_cast<const float4*>(in) + i;
-  float v[12];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) { const float4 t = p[q * total]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
-  float4* dst = reinterpret_cast<float4*>(out) + i;
-#pragma unroll
-  for (int q = 0; q < 14; ++q) {
-    float o[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = 4 * q + e;
-      float s = be[c];
-#pragma unroll
-      for (int k = 0; k < 12; ++k) s = fmaf(we[k * 56 + c], v[k], s);
-      o[e] = prelu(s, ae[c]);
-    }
-    dst[q * total] = make_float4(o[0], o[1], o[2], o[3]);
-  }
-}
-
-template <int S>
-__global__ __launch_bounds__(256) void k_fs_deconv(const float* __restrict__ in, float* __restrict__ out,
-                                                   const float* __restrict__ wd, float bias, int planes, int h,
-                                                   int w) {
-  // the 81x56 taps (18 KB) overflow the 16 KB scalar cache when read as wave-uniform scalars (every
-  // s_load then misses to L2): keep them in LDS and read them as broadcasts instead
-  __shared__ float4 w_lds[81 * 14];
-  for (int k = threadIdx.x; k < 81 * 14; k += blockDim.x) w_lds[k] = reinterpret_cast<const float4*>(wd)[k];
-  __syncthreads();
-  const size_t total = (size_t)planes * h * w;
-  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int x = i % w, y = (i / w) % h;
-  const size_t pl = i / ((size_t)w * h);
-  const size_t pbase = pl * (size_t)h * w;
-  float acc[S][S];
-#pragma unroll
-  for (int a = 0; a < S; ++a)
-#pragma unroll
-    for (int b = 0; b < S; ++b) acc[a][b] = bias;
-  // out[s*y+py] gathers in[y+d] through tap ky = py + 4 - s*d  (stride s, padding 4, kernel 9)
-#pragma unroll
-  for (int dy = -2; dy <= 2; ++dy) {
-    const int yy = y + dy;
-    if (yy < 0 || yy >= h) continue;
-#pragma unroll
-    for (int dx = -2; dx <= 2; ++dx) {
-      const int xx = x + dx;
-      if (xx < 0 || xx >= w) continue;
-      const float4* p = reinterpret_cast<const float4*>(in) + pbase + (size_t)yy * w + xx;
-      float4 v[14];
-#pragma unroll
-      for (int q = 0; q < 14; ++q) v[q] = p[q * total];
-#pragma unroll
-      for (int py = 0; py < S; ++py) {
-        const int ky = py + 4 - S * dy;
-        if (ky < 0 || ky > 8) continue;
-#pragma unroll
-        for (int px = 0; px < S; ++px) {
-          const int kx = px + 4 - S * dx;
-          if (kx < 0 || kx > 8) continue;
-          const float4* wv = w_lds + (ky * 9 + kx) * 14;
-          float s = acc[py][px];
-#pragma unroll
-          for (int q = 0; q < 14; ++q) {
-            const float4 t = wv[q];
-            s = fmaf(t.x, v[q].x, s); s = fmaf(t.y, v[q].y, s); s = fmaf(t.z, v[q].z, s); s = fmaf(t.w, v[q].w, s);
-          }
-          acc[py][px] = s;
-        }
-      }
-    }
-  }
-  const size_t OW = (size_t)w * S;
-  float* dst = out + pl * (size_t)h * S * OW + (size_t)y * S * OW + (size_t)x * S;
-#pragma unroll
-  for (int py = 0; py < S; ++py)
-#pragma unroll
-    for (int px = 0; px < S; ++px) dst[py * OW + px] = acc[py][px];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -332,7 +245,7 @@ __global__ __launch_bounds__(256) void k_fs_tail(const float* __restrict__ in12,
 }
 
 void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const float* in, float* out, int planes, int h,
-                    int w, float* ws12a, float* ws12b, float* ws56, hipStream_t st) {
+                    int w, float* ws12a, float* ws12b, hipStream_t st) {
   const size_t total = (size_t)planes * h * w;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   hipLaunchKernelGGL(k_fs_head, grid, block, 0, st, in, ws12a, W.w_feat, W.b_feat, W.a_feat, W.w_shrink, W.b_shrink,
@@ -342,7 +255,6 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
     hipLaunchKernelGGL(k_fs_map, grid, block, 0, st, cur, nxt, W.w_map[l], W.b_map[l], W.a_map[l], planes, h, w);
     std::swap(cur, nxt);
   }
-  (void)ws56;
   const int strips = (w + FS_CI - 1) / FS_CI;
   // one round of workgroups at three per CU; every band re-does 4 halo rows
   const int bands = std::max(1, std::min((h + 15) / 16, 3 * ctx->num_cu / std::max(1, planes * strips)));

@@ -303,9 +303,9 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
   }
   if (desc.kind == SS4K_FSRCNN) {
     const size_t px = (size_t)n * h * w;
-    if (acts.size() < 3) acts.resize(3);
-    acts[0].ensure(px * 12 * 4); acts[1].ensure(px * 12 * 4); acts[2].ensure(px * 56 * 4);
-    fsrcnn_forward(ctx, fsw, desc.scale, in, out, n, h, w, acts[0].as<float>(), acts[1].as<float>(), acts[2].as<float>(), st);
+    if (acts.size() < 2) acts.resize(2);
+    acts[0].ensure(px * 12 * 4); acts[1].ensure(px * 12 * 4);
+    fsrcnn_forward(ctx, fsw, desc.scale, in, out, n, h, w, acts[0].as<float>(), acts[1].as<float>(), st);
     return;
   }
   // plane index of channel c inside a tensor
