@@ -219,7 +219,7 @@ def main():
                                   "kernel_time_share_of_step": (ms / psteps) / (1000.0 * elapsed / args.steps)}
         elif args.workload == "fsrcnn":
             ach = flops_per_frame * fps / world / 1e12
-            result["roofline"] = {"bound": "fp32 (vector = matrix rate)", "achieved": ach, "peak": F32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+            result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": F32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": ach / F32_VECTOR_PEAK_TFLOPS, "traffic": None,
                                   "kernel": "fsrcnn kernels, whole-step average (head/map on the fp32 vector ALUs, fused expand+deconv on exact-fp32 MFMA: both peak at 157.3)"}
     if rank == 0 and not args.no_also and args.workload == "rrdbnet":
