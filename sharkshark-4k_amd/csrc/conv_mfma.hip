@@ -8,21 +8,26 @@
 // load/store is a whole record.  K-chunks of 16 channels keep a pipeline stage small (halo tile +
 // weights of a 16x32x64 tile: 38 KB), which is what lets the pixel tile per weight fetch be large.
 //
-// One workgroup = 4 waves = one wave per SIMD, ONE workgroup per CU (persistent over tiles):
-//   * output tile 16 rows x 32 pixels x (NB*32) output channels; wave w owns rows 4w..4w+3;
-//   * per K-chunk the 18x34 halo tile (39 KB) and the chunk's weights (18/37 KB, pre-packed on the
-//     host in MFMA fragment order) are DMA'd global->LDS with global_load_lds_dwordx4 into the
-//     buffer the waves are NOT computing from (two LDS buffers, one barrier per chunk, the DMA of
-//     chunk c+1 - or of the next tile's first chunk - flies under the MFMAs of chunk c);
-//   * the tile image in LDS is pixel-major with the 16-byte channel groups XOR-swizzled by the
-//     pixel's x, applied on the DMA *source* address, so every ds_read_b128 operand read is
-//     bank-conflict free and all reads of a chunk hang off six per-lane base addresses;
-//   * loop nest per chunk: for (dx, k-step): 3 weight fragments (dy = 0..2) stay in registers while
-//     the wave walks its 6 input rows - each activation fragment is read ONCE and feeds up to three
-//     MFMAs (the three output rows it contributes to): 0.75 LDS reads per MFMA;
-//   * A operand = weights, B operand = activations, MFMA row -> cout map chosen so each lane ends
-//     up owning 16 contiguous output channels of one pixel: bias / activation / residual epilogue
-//     in registers, 32-byte vector stores.
+// A workgroup is NW waves, persistent over an XCD-banded walk of output tiles (production fp16
+// builds: 4 waves, TWO workgroups per CU so one's epilogue / barrier / DMA wait hides under the
+// other's MFMAs):
+//   * output tile (NW*MB) rows x 32 pixels x (NB*32) output channels; wave w owns rows MB*w...;
+//   * per K-chunk the halo tile ((NW*MB+2) x 34 records) and the chunk's weights (9*NB KB fp16,
+//     pre-packed on the host in MFMA fragment order) are DMA'd global->LDS with
+//     global_load_lds_dwordx4 into the buffer the waves are NOT computing from (two LDS buffers,
+//     one barrier per chunk; the DMA instructions of chunk c+1 - or of the next tile's first chunk
+//     - are issued from slots inside the MFMA stream of chunk c);
+//   * the tile image in LDS is pixel-major with a pixel's 16-byte slots XOR-swizzled by its x,
+//     applied on the DMA *source* address, so every ds_read_b128 operand read is bank-conflict free;
+//   * loop nest per chunk: per (dx, k-step) group 3 weight fragments (dy = 0..2) stay in registers
+//     while the wave walks its MB+2 input rows - each activation fragment is read ONCE and feeds up
+//     to three MFMAs; the MB = 4 builds keep one fragment set and refill registers in place;
+//   * A operand = weights, B operand = activations; the MFMA row -> cout map (host-side weight
+//     permutation) gives lane (pixel, half h) channels 8h..8h+7 of the block's two 16-channel
+//     planes: bias / activation / residual epilogue in registers, and every store instruction of a
+//     wave writes one contiguous kilobyte (non-temporal);
+//   * the LDS buffers are handed to the next tile BEFORE the epilogue, so output stores drain
+//     under the next chunk's MFMAs instead of in front of a vmcnt(0);
 //   * f16: v_mfma_f32_32x32x16_f16 (fp32 accumulate); f32: v_mfma_f32_32x32x2_f32 (exact fp32).
 // Nearest-x2 upsampled input, stride-2 subsampling, PixelShuffle(2) and the NCHW fp32 hand-off are
 // address modes of the DMA source / the epilogue store, not extra passes.
