@@ -218,6 +218,42 @@ def test_service_rejects_bad_input(ctx):
         _capi.Model(ctx, _capi.make_desc(_capi.FSRCNN, _capi.F32, scale=2), np.zeros(10, np.float32))
 
 
+# ------------------------------------------------------------------------------ ragged shapes
+@pytest.mark.parametrize("seed", [1, 2])
+def test_conv_networks_random_shapes(ctx, seed):
+    """Edge tiles of the conv kernel: random N, H, W (not multiples of the 16x32 tile, smaller than a
+    tile, several frames) through one-block RRDBNet x1/x2/x4, a small SRVGG and BSVD; fp32 path within
+    the parity tolerance of the CPU oracle, fp16 path by PSNR.  (tools/fuzz_shapes.py runs more.)"""
+    rng = np.random.default_rng(seed)
+    bs_tab = W.bsvd_table(seed=21)
+    sv_tab = W.srvgg_table(5, num_feat=32, num_conv=3, upscale=2)
+    for it in range(8):
+        kind = ("rrdb", "srvgg", "bsvd", "rrdb")[it % 4]
+        n = int(rng.integers(1, 4))
+        if kind == "rrdb":
+            sc = int(rng.choice([1, 2, 4])); r = {1: 4, 2: 2, 4: 1}[sc]
+            x = torch.rand(n, 3, int(rng.integers(1, 24)) * r, int(rng.integers(1, 44)) * r)
+            tab = W.rrdbnet_table(11 + sc, scale=sc, num_feat=64, num_block=1, num_grow_ch=32)
+            with torch.no_grad():
+                want = onets.rrdbnet(x, tab, sc, 1)
+            build = lambda d: factory.build_model_esrgan(ctx, "RealESRGAN_x2plus", weights=tab, dtype=d, scale=sc, num_block=1)
+        elif kind == "srvgg":
+            x = torch.rand(n, 3, int(rng.integers(1, 70)), int(rng.integers(1, 110)))
+            with torch.no_grad():
+                want = onets.srvgg(x, sv_tab, 3, 2)
+            build = lambda d: _capi.Model(ctx, _capi.make_desc(_capi.SRVGG, _capi.F32 if d == "f32" else _capi.F16, scale=2,
+                                                               num_feat=32, num_block=3), W.flatten(sv_tab, W.srvgg_keys(3)))
+        else:
+            x = torch.rand(n, 1, 4, int(rng.integers(1, 14)) * 4, int(rng.integers(1, 20)) * 4)
+            x[:, :, 3] = 0.05
+            with torch.no_grad():
+                want = onets.bsvd_f1(x, bs_tab)
+            build = lambda d: factory.build_denoise_model(ctx, weights=bs_tab, dtype=d)
+        what = f"{kind} {tuple(x.shape)}"
+        assert_close(build("f32")(x.cuda()), want, what=what)
+        assert psnr(build("f16")(x.cuda()), want) > 40.0, what
+
+
 # ------------------------------------------------------------------------------ image-server mode (SURVEY §8 f2)
 _IMG_MODE = {"sr": "srvgg", "seed": 41, "num_feat": 32, "num_conv": 2, "upscale": 4, "mode": "realesrgan",
              "lr_shape": [360, 640], "output_shape": None, "lr_hr_resize": False, "denoising": False,
