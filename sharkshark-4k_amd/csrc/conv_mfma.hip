@@ -812,7 +812,7 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
     const bool gen = !(a.epi == EPI_NHWC && !a.bsvd_resid);
     if (dtype == SS4K_F16) {
       if (nb == 1) { if (gen) launch_t<__half, 1, 4, 4, 0, true>(ctx, a, groups, st); else launch_t<__half, 1, 4, 4, 0, false>(ctx, a, groups, st); }
-      else { if (gen) launch_t<__half, 2, 2, 8, 0, true>(ctx, a, groups, st); else launch_t<__half, 2, 4, 4, 0, false>(ctx, a, groups, st); }
+      else { if (gen) launch_t<__half, 2, 4, 4, 0, true>(ctx, a, groups, st); else launch_t<__half, 2, 4, 4, 0, false>(ctx, a, groups, st); }
     } else {
       if (nb == 1) { if (gen) launch_t<float, 1, 4, 4, 0, true>(ctx, a, groups, st); else launch_t<float, 1, 4, 4, 0, false>(ctx, a, groups, st); }
       else { if (gen) launch_t<float, 2, 4, 4, 0, true>(ctx, a, groups, st); else launch_t<float, 2, 4, 4, 0, false>(ctx, a, groups, st); }
