@@ -55,39 +55,57 @@ __global__ __launch_bounds__(256) void k_fs_head(const float* __restrict__ in, f
                                      prelu(s[4 * q + 2], as[4 * q + 2]), prelu(s[4 * q + 3], as[4 * q + 3]));
 }
 
+// conv3x3 12->12 + PReLU.  Each thread computes R vertically adjacent pixels of one column (lanes stay
+// on consecutive x: every load is a coalesced kilobyte) and walks the R+2 input rows once: a loaded
+// 12-channel position feeds up to three output rows, so a pixel costs (R+2)*3/R position loads
+// instead of 9 (the one-pixel-per-thread form was bound by L1/L2 bandwidth, 432 B per pixel).
+template <int R>
 __global__ __launch_bounds__(256) void k_fs_map(const float* __restrict__ in, float* __restrict__ out,
                                                 const float* __restrict__ wm, const float* __restrict__ bm,
                                                 const float* __restrict__ am, int planes, int h, int w) {
-  const size_t total = (size_t)planes * h * w;
+  const int hb = (h + R - 1) / R;  // row blocks per plane
+  const size_t nthreads = (size_t)planes * hb * w, total = (size_t)planes * h * w;
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int x = i % w, y = (i / w) % h;
-  const size_t pbase = (i / ((size_t)w * h)) * (size_t)h * w;
-  float s[12];
+  if (i >= nthreads) return;
+  const int x = i % w, yb = (i / w) % hb, y0 = yb * R;
+  const size_t pbase = (i / ((size_t)w * hb)) * (size_t)h * w;
+  float s[R][12];
 #pragma unroll
-  for (int j = 0; j < 12; ++j) s[j] = bm[j];
+  for (int r = 0; r < R; ++r)
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int yy = y + ky - 1;
+    for (int j = 0; j < 12; ++j) s[r][j] = bm[j];
+#pragma unroll
+  for (int ir = 0; ir < R + 2; ++ir) {
+    const int yy = y0 + ir - 1;
+    if (yy < 0 || yy >= h) continue;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int xx = x + kx - 1;
-      if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+      if (xx < 0 || xx >= w) continue;
       const float4* p = reinterpret_cast<const float4*>(in) + pbase + (size_t)yy * w + xx;
       float v[12];
 #pragma unroll
       for (int q = 0; q < 3; ++q) { const float4 t = p[q * total]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
 #pragma unroll
-      for (int c = 0; c < 12; ++c)
+      for (int r = 0; r < R; ++r) {
+        const int ky = ir - r;  // input row ir is tap row ky of output row r
+        if (ky < 0 || ky > 2) continue;
 #pragma unroll
-        for (int j = 0; j < 12; ++j) s[j] = fmaf(wm[((ky * 3 + kx) * 12 + c) * 12 + j], v[c], s[j]);
+        for (int c = 0; c < 12; ++c)
+#pragma unroll
+          for (int j = 0; j < 12; ++j) s[r][j] = fmaf(wm[((ky * 3 + kx) * 12 + c) * 12 + j], v[c], s[r][j]);
+      }
     }
   }
-  float4* dst = reinterpret_cast<float4*>(out) + i;
 #pragma unroll
-  for (int q = 0; q < 3; ++q)
-    dst[q * total] = make_float4(prelu(s[4 * q], am[4 * q]), prelu(s[4 * q + 1], am[4 * q + 1]),
-                         prelu(s[4 * q + 2], am[4 * q + 2]), prelu(s[4 * q + 3], am[4 * q + 3]));
+  for (int r = 0; r < R; ++r) {
+    if (y0 + r >= h) break;
+    float4* dst = reinterpret_cast<float4*>(out) + pbase + (size_t)(y0 + r) * w + x;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      dst[q * total] = make_float4(prelu(s[r][4 * q], am[4 * q]), prelu(s[r][4 * q + 1], am[4 * q + 1]),
+                                   prelu(s[r][4 * q + 2], am[4 * q + 2]), prelu(s[r][4 * q + 3], am[4 * q + 3]));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -250,9 +268,11 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   hipLaunchKernelGGL(k_fs_head, grid, block, 0, st, in, ws12a, W.w_feat, W.b_feat, W.a_feat, W.w_shrink, W.b_shrink,
                      W.a_shrink, planes, h, w);
+  constexpr int FS_MAP_R = 4;
+  const dim3 mgrid((unsigned)(((size_t)planes * ((h + FS_MAP_R - 1) / FS_MAP_R) * w + 255) / 256));
   float* cur = ws12a; float* nxt = ws12b;
   for (int l = 0; l < 4; ++l) {
-    hipLaunchKernelGGL(k_fs_map, grid, block, 0, st, cur, nxt, W.w_map[l], W.b_map[l], W.a_map[l], planes, h, w);
+    hipLaunchKernelGGL(k_fs_map<FS_MAP_R>, mgrid, block, 0, st, cur, nxt, W.w_map[l], W.b_map[l], W.a_map[l], planes, h, w);
     std::swap(cur, nxt);
   }
   const int strips = (w + FS_CI - 1) / FS_CI;
