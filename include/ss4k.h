@@ -143,7 +143,7 @@ int ss4k_op_bicubic_resize(ss4k_ctx* ctx, const float* in_dev, float* out_dev, i
 int ss4k_op_bilinear_resize(ss4k_ctx* ctx, const float* in_dev, float* out_dev, int planes, int h, int w,
                             int oh, int ow, void* hip_stream);
 /* depthwise KxK conv with padding_mode='reflect' (blur_ker / sharpen_ker, :20-84); k2d_host = K*K
- * fp32 taps on the host, K odd <= 17 */
+ * fp32 taps on the host, K = 3 or 17 (the service's sharpen and blur kernels) */
 int ss4k_op_depthwise_reflect(ss4k_ctx* ctx, const float* in_dev, float* out_dev, int planes, int h, int w,
                               const float* k2d_host, int k, void* hip_stream);
 /* per-plane mean and unbiased std (:192-197): stats_dev[2*p] = mean, [2*p+1] = std */

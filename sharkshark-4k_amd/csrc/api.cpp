@@ -91,6 +91,7 @@ struct Upscaler {
     op_normalize(hrp, st_hr.as<float>(), st_lr.as<float>(), P, H * W, st);
     save_tap(2, hrp, n, 3, H, W, st);
     const int mh = H / 8, mw = W / 8;
+    bool clamped = false;
     if (mh > 8 && H > 64 && W > 64) {  // local colour match, :201-218
       const size_t sm = (size_t)P * mh * mw * 4;
       lb.ensure(sm); hb.ensure(sm); lbb.ensure(sm); hbb.ensure(sm);
@@ -99,10 +100,13 @@ struct Upscaler {
       op_depthwise_reflect(lb.as<float>(), lbb.as<float>(), k_blur17.as<float>(), P, mh, mw, 17, 0, nullptr, 0, 0, st);
       op_depthwise_reflect(hb.as<float>(), hbb.as<float>(), k_blur17.as<float>(), P, mh, mw, 17, 0, nullptr, 0, 0, st);
       op_sub(hbb.as<float>(), lbb.as<float>(), hb.as<float>(), (size_t)P * mh * mw, st);
-      op_bilinear(hb.as<float>(), hrp, P, mh, mw, H, W, /*subtract_from_out=*/1, 0, st);
+      // hr -= diff, then clamp(0,1) (:217,:220): one pass over the HR tensor unless the unclamped
+      // value is being tapped
+      clamped = !taps_on;
+      op_bilinear(hb.as<float>(), hrp, P, mh, mw, H, W, /*subtract_from_out=*/1, clamped ? 1 : 0, st);
     }
     save_tap(3, hrp, n, 3, H, W, st);
-    op_clamp01(hrp, (size_t)P * H * W, st);
+    if (!clamped) op_clamp01(hrp, (size_t)P * H * W, st);
     const float* fin = hrp; int FH = H, FW = W;
     if (cfg.out_h > 0 && cfg.lr_hr_resize) {  // always bicubic (quirk, :224-231)
       FH = cfg.out_h; FW = cfg.out_w;

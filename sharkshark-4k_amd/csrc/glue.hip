@@ -31,26 +31,29 @@ void op_u8nhwc_to_f32nchw(const uint8_t* in, float* out, int n, int h, int w, in
 __device__ __forceinline__ int a_start(int i, int in, int out) { return (int)floorf((float)(i * in) / out); }
 __device__ __forceinline__ int a_end(int i, int in, int out) { return (int)ceilf((float)((i + 1) * in) / out); }
 
+// one block row per output row (blockIdx.y = oy, blockIdx.z = plane): no per-element divisions
 __global__ void k_area(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int oh,
                        int ow) {
-  const size_t total = (size_t)planes * oh * ow;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int ox = i % ow, oy = (i / ow) % oh;
-    const size_t pl = i / ((size_t)ow * oh);
-    const int y0 = a_start(oy, h, oh), y1 = a_end(oy, h, oh), x0 = a_start(ox, w, ow), x1 = a_end(ox, w, ow);
-    const float* src = in + pl * (size_t)h * w;
+  const int oy = blockIdx.y, pl = blockIdx.z;
+  const int y0 = a_start(oy, h, oh), y1 = a_end(oy, h, oh);
+  const float* src = in + (size_t)pl * h * w;
+  float* dst = out + ((size_t)pl * oh + oy) * ow;
+  for (int ox = blockIdx.x * blockDim.x + threadIdx.x; ox < ow; ox += gridDim.x * blockDim.x) {
+    const int x0 = a_start(ox, w, ow), x1 = a_end(ox, w, ow);
     float sum = 0.f;
     for (int y = y0; y < y1; ++y)
       for (int x = x0; x < x1; ++x) sum += src[(size_t)y * w + x];
-    out[i] = sum / (float)(y1 - y0) / (float)(x1 - x0);
+    dst[ox] = sum / (float)(y1 - y0) / (float)(x1 - x0);
   }
 }
+static inline dim3 grid_rows(int ow, int oh, int planes) { return dim3((unsigned)std::min((ow + 255) / 256, 64), (unsigned)oh, (unsigned)planes); }
 void op_area(const float* in, float* out, int planes, int h, int w, int oh, int ow, hipStream_t st) {
   if (h == oh && w == ow) {
     (void)hipMemcpyAsync(out, in, (size_t)planes * h * w * sizeof(float), hipMemcpyDeviceToDevice, st);
     return;
   }
-  hipLaunchKernelGGL(k_area, grid1d((size_t)planes * oh * ow), dim3(256), 0, st, in, out, planes, h, w, oh, ow);
+  SS4K_REQUIRE(oh <= 65535 && planes <= 65535, "area: grid limits");
+  hipLaunchKernelGGL(k_area, grid_rows(ow, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow);
 }
 
 // ------------------------------------------------------------------ per-plane mean / unbiased std
@@ -111,54 +114,85 @@ void op_normalize(float* x, const float* st_hr, const float* st_lr, int planes, 
 // ------------------------------------------------------------------ depthwise KxK, reflect padding
 __device__ __forceinline__ int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
 
+template <int K>
 __global__ void k_depthwise_reflect(const float* __restrict__ in, float* __restrict__ out,
-                                    const float* __restrict__ taps, int planes, int h, int w, int k, int clamp01,
+                                    const float* __restrict__ taps, int planes, int h, int w, int clamp01,
                                     const float* __restrict__ blend_src, float blend_a, float blend_b) {
-  const size_t total = (size_t)planes * h * w;
-  const int r = k >> 1;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int x = i % w, y = (i / w) % h;
-    const float* src = in + (i / ((size_t)w * h)) * (size_t)h * w;
+  constexpr int r = K >> 1;
+  const int y = blockIdx.y, pl = blockIdx.z;
+  const float* src = in + (size_t)pl * h * w;
+  const size_t row = ((size_t)pl * h + y) * w;
+  for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) {
+    int xi[K];
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) xi[kx] = reflect(x + kx - r, w);
     float acc = 0.f;
-    for (int ky = 0; ky < k; ++ky) {
-      const int yy = reflect(y + ky - r, h);
-      for (int kx = 0; kx < k; ++kx) acc += taps[ky * k + kx] * src[(size_t)yy * w + reflect(x + kx - r, w)];
+#pragma unroll 1
+    for (int ky = 0; ky < K; ++ky) {
+      const float* sr = src + (size_t)reflect(y + ky - r, h) * w;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) acc += taps[ky * K + kx] * sr[xi[kx]];  // same summation order as the flat loop
     }
     if (clamp01) acc = fminf(fmaxf(acc, 0.f), 1.f);
-    if (blend_src) acc = acc * blend_a + blend_b * blend_src[i];
-    out[i] = acc;
+    if (blend_src) acc = acc * blend_a + blend_b * blend_src[row + x];
+    out[row + x] = acc;
   }
 }
 void op_depthwise_reflect(const float* in, float* out, const float* taps_dev, int planes, int h, int w, int k,
                           int clamp01, const float* blend_src, float blend_a, float blend_b, hipStream_t st) {
-  hipLaunchKernelGGL(k_depthwise_reflect, grid1d((size_t)planes * h * w), dim3(256), 0, st, in, out, taps_dev,
-                     planes, h, w, k, clamp01, blend_src, blend_a, blend_b);
+  SS4K_REQUIRE(h <= 65535 && planes <= 65535, "depthwise: grid limits");
+  SS4K_REQUIRE(k == 3 || k == 17, "depthwise: kernel size 3 or 17 (the service's sharpen / blur kernels)");
+  if (k == 3)
+    hipLaunchKernelGGL(k_depthwise_reflect<3>, grid_rows(w, h, planes), dim3(256), 0, st, in, out, taps_dev, planes, h, w,
+                       clamp01, blend_src, blend_a, blend_b);
+  else
+    hipLaunchKernelGGL(k_depthwise_reflect<17>, grid_rows(w, h, planes), dim3(256), 0, st, in, out, taps_dev, planes, h, w,
+                       clamp01, blend_src, blend_a, blend_b);
 }
 
 // ------------------------------------------------------------------ bilinear / bicubic (align_corners=False)
+// V consecutive outputs per thread (V = 4: 16-byte read-modify-write of the output row when ow % 4 == 0)
+template <int V>
 __global__ void k_bilinear(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int oh,
                            int ow, int subtract_from_out, int clamp01) {
-  const size_t total = (size_t)planes * oh * ow;
+  const int oy = blockIdx.y, pl = blockIdx.z;
   const float sy = (float)h / oh, sx = (float)w / ow;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int ox = i % ow, oy = (i / ow) % oh;
-    const float* src = in + (i / ((size_t)ow * oh)) * (size_t)h * w;
-    float fy = sy * (oy + 0.5f) - 0.5f; if (fy < 0) fy = 0;
-    float fx = sx * (ox + 0.5f) - 0.5f; if (fx < 0) fx = 0;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-    const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
-    const float v = hy * (hx * src[(size_t)y0 * w + x0] + lx * src[(size_t)y0 * w + x1]) +
-                    ly * (hx * src[(size_t)y1 * w + x0] + lx * src[(size_t)y1 * w + x1]);
-    float r = subtract_from_out ? out[i] - v : v;
-    if (clamp01) r = fminf(fmaxf(r, 0.f), 1.f);
-    out[i] = r;
+  const float* src = in + (size_t)pl * h * w;
+  float* dst = out + ((size_t)pl * oh + oy) * ow;
+  float fy = sy * (oy + 0.5f) - 0.5f; if (fy < 0) fy = 0;
+  const int y0 = (int)fy, y1 = y0 + (y0 < h - 1 ? 1 : 0);
+  const float ly = fy - y0, hy = 1.f - ly;
+  const float* r0 = src + (size_t)y0 * w; const float* r1 = src + (size_t)y1 * w;
+  for (int ob = (blockIdx.x * blockDim.x + threadIdx.x) * V; ob < ow; ob += gridDim.x * blockDim.x * V) {
+    float cur[V];
+    if (subtract_from_out) {
+      if constexpr (V == 4) { const float4 t = *reinterpret_cast<const float4*>(dst + ob); cur[0] = t.x; cur[1] = t.y; cur[2] = t.z; cur[3] = t.w; }
+      else cur[0] = dst[ob];
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const int ox = ob + e;
+      float fx = sx * (ox + 0.5f) - 0.5f; if (fx < 0) fx = 0;
+      const int x0 = (int)fx, x1 = x0 + (x0 < w - 1 ? 1 : 0);
+      const float lx = fx - x0, hx = 1.f - lx;
+      const float v = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
+      float r = subtract_from_out ? cur[e] - v : v;
+      if (clamp01) r = fminf(fmaxf(r, 0.f), 1.f);
+      cur[e] = r;
+    }
+    if constexpr (V == 4) *reinterpret_cast<float4*>(dst + ob) = make_float4(cur[0], cur[1], cur[2], cur[3]);
+    else dst[ob] = cur[0];
   }
 }
 void op_bilinear(const float* in, float* out, int planes, int h, int w, int oh, int ow, int subtract_from_out,
                  int clamp01, hipStream_t st) {
-  hipLaunchKernelGGL(k_bilinear, grid1d((size_t)planes * oh * ow), dim3(256), 0, st, in, out, planes, h, w, oh, ow,
-                     subtract_from_out, clamp01);
+  SS4K_REQUIRE(oh <= 65535 && planes <= 65535, "bilinear: grid limits");
+  if (ow % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+    hipLaunchKernelGGL(k_bilinear<4>, grid_rows(ow / 4, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow,
+                       subtract_from_out, clamp01);
+  else
+    hipLaunchKernelGGL(k_bilinear<1>, grid_rows(ow, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow,
+                       subtract_from_out, clamp01);
 }
 
 __device__ __forceinline__ float cc1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
@@ -169,32 +203,39 @@ __device__ __forceinline__ void cubic_coeffs(float t, float* c) {
 }
 __global__ void k_bicubic(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int oh,
                           int ow, int clamp01) {
-  const size_t total = (size_t)planes * oh * ow;
+  const int oy = blockIdx.y, pl = blockIdx.z;
   const float sy = (float)h / oh, sx = (float)w / ow;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int ox = i % ow, oy = (i / ow) % oh;
-    const float* src = in + (i / ((size_t)ow * oh)) * (size_t)h * w;
-    const float fy = sy * (oy + 0.5f) - 0.5f, fx = sx * (ox + 0.5f) - 0.5f;
-    const float fly = floorf(fy), flx = floorf(fx);
-    const int iy = (int)fly, ix = (int)flx;
-    float cy[4], cx[4];
-    cubic_coeffs(fy - fly, cy); cubic_coeffs(fx - flx, cx);
+  const float* src = in + (size_t)pl * h * w;
+  float* dst = out + ((size_t)pl * oh + oy) * ow;
+  const float fy = sy * (oy + 0.5f) - 0.5f, fly = floorf(fy);
+  const int iy = (int)fly;
+  float cy[4];
+  cubic_coeffs(fy - fly, cy);
+  const float* rows[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) rows[a] = src + (size_t)min(max(iy - 1 + a, 0), h - 1) * w;
+  for (int ox = blockIdx.x * blockDim.x + threadIdx.x; ox < ow; ox += gridDim.x * blockDim.x) {
+    const float fx = sx * (ox + 0.5f) - 0.5f, flx = floorf(fx);
+    const int ix = (int)flx;
+    float cx[4]; int xi[4];
+    cubic_coeffs(fx - flx, cx);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) xi[b] = min(max(ix - 1 + b, 0), w - 1);
     float acc = 0.f;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      const int yy = min(max(iy - 1 + a, 0), h - 1);
       float row = 0.f;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) row += cx[b] * src[(size_t)yy * w + min(max(ix - 1 + b, 0), w - 1)];
+      for (int b = 0; b < 4; ++b) row += cx[b] * rows[a][xi[b]];
       acc += cy[a] * row;
     }
     if (clamp01) acc = fminf(fmaxf(acc, 0.f), 1.f);
-    out[i] = acc;
+    dst[ox] = acc;
   }
 }
 void op_bicubic(const float* in, float* out, int planes, int h, int w, int oh, int ow, int clamp01, hipStream_t st) {
-  hipLaunchKernelGGL(k_bicubic, grid1d((size_t)planes * oh * ow), dim3(256), 0, st, in, out, planes, h, w, oh, ow,
-                     clamp01);
+  SS4K_REQUIRE(oh <= 65535 && planes <= 65535, "bicubic: grid limits");
+  hipLaunchKernelGGL(k_bicubic, grid_rows(ow, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow, clamp01);
 }
 
 // ------------------------------------------------------------------ elementwise helpers
@@ -274,27 +315,47 @@ template void op_pack_input<__half>(const float*, __half*, int, int, int, int, i
 
 // SRVGGNetCompact tail (realesrgan/factory.py:77-81): PixelShuffle(r) of a "planes" T tensor into
 // fp32 NCHW planes plus the nearest-upsampled network input.
-template <typename T>
+// One thread per LR pixel and colour: the r*r channels of that colour are one contiguous run of its
+// record(s), read with 16-byte loads, and leave as r rows of r floats (16-byte stores for r = 4).
+template <typename T, int R>
 __global__ void k_ps_nchw_addbase(const T* __restrict__ src, float* __restrict__ out, const float* __restrict__ base,
-                                  int n, int h, int w, int r, int cq) {
-  constexpr int CW = 16;
-  const int OH = h * r, OW = w * r;
-  const size_t total = (size_t)n * cq * OH * OW, npix = (size_t)n * h * w;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int ox = i % OW, oy = (i / OW) % OH;
-    const int c = (i / ((size_t)OW * OH)) % cq;
-    const size_t img = i / ((size_t)OW * OH * cq);
-    const int y = oy / r, x = ox / r, dy = oy - y * r, dx = ox - x * r;
-    const int ch = c * r * r + dy * r + dx;
-    const size_t pix = (img * h + y) * w + x;
-    const float v = (float)src[((size_t)(ch / CW) * npix + pix) * CW + (ch % CW)];
-    out[i] = v + base[((img * cq + c) * h + y) * w + x];
+                                  int n, int h, int w, int cq) {
+  constexpr int CW = 16, RR = R * R;
+  const int y = blockIdx.y, img = blockIdx.z;
+  const int OH = h * R, OW = w * R;
+  const size_t npix = (size_t)n * h * w;
+  for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) {
+    const size_t pix = ((size_t)img * h + y) * w + x;
+    for (int c = 0; c < cq; ++c) {
+      const int ch0 = c * RR;  // RR consecutive channels, never straddling a 16-channel record (RR | 16)
+      const T* rec = src + ((size_t)(ch0 / CW) * npix + pix) * CW + (ch0 % CW);
+      T v[RR];
+      if constexpr (RR * sizeof(T) >= 16) {
+#pragma unroll
+        for (int q = 0; q < (int)(RR * sizeof(T) / 16); ++q) reinterpret_cast<uint4*>(v)[q] = reinterpret_cast<const uint4*>(rec)[q];
+      } else {
+        *reinterpret_cast<uint2*>(v) = *reinterpret_cast<const uint2*>(rec);  // 4 fp16 channels
+      }
+      const float b = base[(((size_t)img * cq + c) * h + y) * w + x];
+      float* o = out + (((size_t)img * cq + c) * OH + (size_t)y * R) * OW + (size_t)x * R;
+#pragma unroll
+      for (int dy = 0; dy < R; ++dy) {
+        if constexpr (R == 4) {
+          *reinterpret_cast<float4*>(o + (size_t)dy * OW) = make_float4((float)v[dy * 4] + b, (float)v[dy * 4 + 1] + b,
+                                                                        (float)v[dy * 4 + 2] + b, (float)v[dy * 4 + 3] + b);
+        } else {
+          *reinterpret_cast<float2*>(o + (size_t)dy * OW) = make_float2((float)v[dy * 2] + b, (float)v[dy * 2 + 1] + b);
+        }
+      }
+    }
   }
 }
 template <typename T>
 void op_ps_nchw_addbase(const T* src, float* out, const float* base, int n, int h, int w, int r, int cq, hipStream_t st) {
-  hipLaunchKernelGGL((k_ps_nchw_addbase<T>), grid1d((size_t)n * cq * h * r * w * r), dim3(256), 0, st, src, out, base,
-                     n, h, w, r, cq);
+  SS4K_REQUIRE(h <= 65535 && n <= 65535, "pixel shuffle tail: grid limits");
+  if (r == 4) hipLaunchKernelGGL((k_ps_nchw_addbase<T, 4>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq);
+  else if (r == 2) hipLaunchKernelGGL((k_ps_nchw_addbase<T, 2>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq);
+  else throw Error(SS4K_EINVAL, "SRVGG: upscale must be 2 or 4");
 }
 template void op_ps_nchw_addbase<float>(const float*, float*, const float*, int, int, int, int, int, hipStream_t);
 template void op_ps_nchw_addbase<__half>(const __half*, float*, const float*, int, int, int, int, int, hipStream_t);
