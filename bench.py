@@ -202,13 +202,13 @@ def main():
         if launches > 0 and ms > 0:
             ach = flops / (ms * 1e-3) / 1e12
             traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01i_conv3x3_pmc_traffic.json")
+            pmc = os.path.join(ROOT, "profiles", "r01j_conv3x3_pmc_traffic.json")
             if args.workload == "rrdbnet" and os.path.exists(pmc):
                 # HBM-side bytes per launch cannot be read from inside the process: they come from the
                 # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
                 with open(pmc) as f:
                     pj = json.load(f)
-                traffic, traffic_src = pj["traffic_bytes_per_launch"], "profiles/r01i_conv3x3_pmc_traffic.json (" + pj["correction"] + ")"
+                traffic, traffic_src = pj["traffic_bytes_per_launch"], "profiles/r01j_conv3x3_pmc_traffic.json (" + pj["correction"] + ")"
             result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
                                   "unit": "TFLOP/s", "frac": ach / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": traffic,
                                   "traffic_unit": "bytes per launch (L2<->fabric, PMC)", "traffic_source": traffic_src,
