@@ -41,6 +41,10 @@ def test_struct_layout_matches_header():
     assert C.sizeof(_capi.ModelDesc) == 16 * 4
     assert C.sizeof(_capi.UpscaleCfg) == 8 * 4 + 4 + 4 + 8 + 6 * 4
     assert _capi.UpscaleCfg.denoise_rate.offset == 40
+    # bsvd_stream took the first reserved word of ss4k_model_desc (include/ss4k.h)
+    assert _capi.ModelDesc.bsvd_stream.offset == 11 * 4
+    d = _capi.make_desc(_capi.BSVD, bsvd_stream=True)
+    assert d.bsvd_stream == 1 and _capi.make_desc(_capi.BSVD).bsvd_stream == 0
 
 
 @pytest.mark.parametrize("desc,table", [

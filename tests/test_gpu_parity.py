@@ -216,6 +216,12 @@ def test_service_rejects_bad_input(ctx):
         _capi.Upscaler(ctx, sr, (16, 16), None, True, False, None, 1.0)  # batched path needs a 3-channel SR model
     with pytest.raises(_capi.Ss4kError):
         _capi.Model(ctx, _capi.make_desc(_capi.FSRCNN, _capi.F32, scale=2), np.zeros(10, np.float32))
+    with pytest.raises(_capi.Ss4kError):  # stream mode is a BSVD property
+        d = _capi.make_desc(_capi.SRVGG, _capi.F32, scale=2, num_feat=16, num_block=2, bsvd_stream=True)
+        _capi.Model(ctx, d, W.flatten(W.srvgg_table(0, num_feat=16, num_conv=2, upscale=2), W.srvgg_keys(2)))
+    with pytest.raises(_capi.Ss4kError):  # RRDBNet x2 needs even sizes (pixel_unshuffle raises in the reference too)
+        factory.build_model_esrgan(ctx, "RealESRGAN_x2plus", weights=rrdb_small_table(seed=7, scale=2, num_block=1),
+                                   dtype="f32", scale=2, num_block=1)(torch.rand(1, 3, 15, 16).cuda())
 
 
 # ------------------------------------------------------------------------------ ragged shapes
