@@ -86,7 +86,7 @@ static void validate_desc(const ss4k_model_desc& d) {
       break;
     case SS4K_BSVD:
       SS4K_REQUIRE(d.bsvd_chns[0] % 32 == 0 && d.bsvd_chns[1] % 64 == 0 && d.bsvd_chns[2] % 64 == 0 && d.bsvd_mid_ch % 32 == 0 &&
-                       d.bsvd_interm_ch > 0 && d.bsvd_interm_ch <= 32,
+                       d.bsvd_interm_ch > 0 && d.bsvd_interm_ch <= 256,
                    "BSVD: unsupported channel configuration");
       break;
     default:
@@ -378,7 +378,7 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
   int li = 0;
   for (int blk = 0; blk < 2; ++blk) {
     const Tens IN = blk == 0 ? IN0 : MID;
-    Tens I0 = act(2, px, 32), X0 = act(3, px, c0);
+    Tens I0 = act(2, px, desc.bsvd_interm_ch), X0 = act(3, px, c0);
     Tens D0 = act(4, px2, c1), Ma = act(5, px2, c1), X1 = act(6, px2, c1);
     Tens D1 = act(7, px4, c2), Mb = act(8, px4, c2), X2 = act(9, px4, c2), Mc = act(10, px4, c2);
     Tens S1 = act(11, px2, c1), S0 = act(12, px, c0), O0 = act(13, px, c0);

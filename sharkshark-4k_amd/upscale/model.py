@@ -65,11 +65,19 @@ def build_model_esrgan(ctx: _capi.Context, model_name: str = DEFAULT_REALESRGAN,
     return _capi.Model(ctx, desc, W.flatten(table, W.srvgg_keys(kw["num_conv"])))
 
 
+BSVD_VARIANTS = {  # bsvd/factory.py:31-36 (the one the service builds) and :94-98 / the commented-out block at :26-30
+    "bsvd-32": dict(chns=(32, 64, 128), mid_ch=32, interm_ch=30),
+    "bsvd-64": dict(chns=(64, 128, 256), mid_ch=64, interm_ch=64),
+}
+
+
 def build_denoise_model(ctx: _capi.Context, weights: Optional[Mapping] = None, dtype="f16", seed: int = 0,
-                        stream: bool = False):
+                        stream: bool = False, variant: str = "bsvd-32"):
     """``stream=False``: the model the service calls, one independent frame per call (F = 1,
     ``fsrcnn_upscaler.py:277``).  ``stream=True``: ``BSVD.forward`` on ``(N,F,4,H,W)`` clips, all N*F
     frames run through the bidirectional buffers as one stream (``bsvd/model.py:515-580``)."""
-    table = weights if weights is not None else W.bsvd_table(seed)
-    desc = _capi.make_desc(_capi.BSVD, _dtype(dtype), scale=1, bsvd_stream=stream)
-    return _capi.Model(ctx, desc, W.flatten(table, W.bsvd_keys()))
+    kw = BSVD_VARIANTS[variant]
+    table = weights if weights is not None else W.bsvd_table(seed, **kw)
+    desc = _capi.make_desc(_capi.BSVD, _dtype(dtype), scale=1, bsvd_stream=stream, bsvd_chns=kw["chns"],
+                           bsvd_mid_ch=kw["mid_ch"], bsvd_interm_ch=kw["interm_ch"])
+    return _capi.Model(ctx, desc, W.flatten(table, W.bsvd_keys(**kw)))

@@ -115,6 +115,22 @@ def test_bsvd_fp16_psnr(ctx, name):
     assert psnr(m(dev(g["x"])), g["y"]) > 45.0
 
 
+@pytest.mark.parametrize("stream", [False, True])
+def test_bsvd64_variant_vs_oracle(ctx, stream):
+    """The wider BSVD the reference's factory also knows (chns 64/128/256, mid 64, interm 64:
+    bsvd/factory.py:26-30,94-98), per frame and as a stream, fp32 against the oracle."""
+    kw = factory.BSVD_VARIANTS["bsvd-64"]
+    tab = W.bsvd_table(seed=33, **kw)
+    x = torch.rand(1, 3, 4, 24, 40) if stream else torch.rand(2, 1, 4, 24, 40)
+    x[:, :, 3] = 0.05
+    with torch.no_grad():
+        want = (onets.bsvd_seq if stream else onets.bsvd_f1)(x, tab)
+    m = factory.build_denoise_model(ctx, weights=tab, dtype="f32", stream=stream, variant="bsvd-64")
+    assert_close(m(x.cuda()), want, what=f"bsvd-64 stream={stream}")
+    m16 = factory.build_denoise_model(ctx, weights=tab, dtype="f16", stream=stream, variant="bsvd-64")
+    assert psnr(m16(x.cuda()), want) > 40.0
+
+
 def test_bsvd_stream_properties(ctx):
     """Size-independent checks of the stream mode at a larger frame: a one-frame stream equals the
     per-frame model; every frame of a stream depends on its neighbours (the temporal shift is live);
