@@ -381,6 +381,33 @@ def test_hip_service_worker_process_roundtrip():
     assert not svc.proc.is_alive()
 
 
+def test_stream_dispatcher_over_two_hip_services():
+    """SURVEY §8 f1 on the device: a recorder batch cut into 4-frame jobs, dealt round-robin over two
+    HipUpscalerService worker processes (both on GPU 0 here; one per GPU on a node), results re-ordered
+    by step and checked against the oracle service."""
+    from sharkshark4k_amd.stream import StreamDispatcher
+    from sharkshark4k_amd.upscale.hip_upscaler import HipUpscalerService
+    table = W.fsrcnn_table(seed=2)
+    svcs = [HipUpscalerService(device=0, denoising=False, upscaler_model="fsrcnn", scale=2, lr_shape=(36, 52),
+                               weights={"sr": table}) for _ in range(2)]
+    for s_ in svcs:
+        s_.start()
+    try:
+        d = StreamDispatcher(svcs, fps=24, frame_skips=False)
+        frames = torch.from_numpy(smooth_u8(91, (12, 36, 52, 3)))
+        steps = d.submit_batch(frames)
+        assert steps == [0, 1, 2]
+        out = d.drain(steps, timeout=240)
+        assert [e.step for e in out] == [0, 1, 2]
+        osv = osvc.OracleUpscaler(lambda x: onets.fsrcnn(x, table, 2), upscaler_model="fsrcnn", lr_shape=(36, 52))
+        for e in out:
+            assert_u8_close(e.frames.cpu(), osv.upscale(frames[4 * e.step:4 * e.step + 4]), what=f"stream job {e.step}")
+            assert "upscaler.upscale.per_frame_ms" in e.profiler.data
+    finally:
+        for s_ in svcs:
+            s_.stop()
+
+
 def test_rrdbnet_x4_1080p_runs(ctx):
     """BASELINE config 5 shape on one GPU: RRDBNet x4 (6 blocks to bound the time), 1080p -> 4320x7680,
     bicubic to 2160x3840 through the batched service path; output statistics must be sane."""
