@@ -444,7 +444,8 @@ double bench_conv_layer(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, 
     fill(X, cin0); fill(G, std::max(cin1, 32));
   }
   ConvOpts o; o.act = ACT_LRELU; o.slope = 0.2f; o.out = O;
-  m.dbg = flags;
+  if ((flags & 2048) && cout <= cin0) { o.act = ACT_NONE; o.alpha = 0.2f; o.res1 = &X; }  // conv5 of an RDB: x5 * 0.2 + x
+  m.dbg = flags & ~2048;
   DevBuf dbgb; dbgb.ensure(1024 * 16 * 8); SS4K_HIP(hipMemsetAsync(dbgb.ptr, 0, 1024 * 16 * 8, st)); m.dbg_buf = dbgb.as<unsigned long long>();
   for (int i = 0; i < 3; ++i) m.conv(li, X, cin1 ? &G : nullptr, n, h, w, o, st);
   hipEvent_t e0, e1; SS4K_HIP(hipEventCreate(&e0)); SS4K_HIP(hipEventCreate(&e1));
