@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sharkshark4k_amd
 from sharkshark4k_amd import _capi
 ctx = _capi.Context(0)
