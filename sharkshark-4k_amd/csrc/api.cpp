@@ -108,7 +108,9 @@ struct Upscaler {
     save_tap(3, hrp, n, 3, H, W, st);
     if (!clamped) op_clamp01(hrp, (size_t)P * H * W, st);
     const float* fin = hrp; int FH = H, FW = W;
-    if (cfg.out_h > 0 && cfg.lr_hr_resize) {  // always bicubic (quirk, :224-231)
+    // always bicubic (quirk, :224-231).  At equal size align_corners=False bicubic has taps (0,1,0,0):
+    // the identity on already clamped values, so that pass is skipped
+    if (cfg.out_h > 0 && cfg.lr_hr_resize && !(cfg.out_h == H && cfg.out_w == W)) {
       FH = cfg.out_h; FW = cfg.out_w;
       hr2.ensure((size_t)P * FH * FW * 4);
       op_bicubic(hrp, hr2.as<float>(), P, H, W, FH, FW, 1, st);
@@ -164,7 +166,7 @@ struct Upscaler {
     save_tap(2, hrp, n, 3, H, W, st);
     op_clamp01(hrp, (size_t)P * H * W, st);
     const float* fin = hrp; int FH = H, FW = W;
-    if (cfg.out_h > 0) {
+    if (cfg.out_h > 0 && !(cfg.out_h == H && cfg.out_w == W)) {  // equal size: identity, see multi()
       FH = cfg.out_h; FW = cfg.out_w;
       hr2.ensure((size_t)P * FH * FW * 4);
       op_bicubic(hrp, hr2.as<float>(), P, H, W, FH, FW, 1, st);
