@@ -1,108 +1,134 @@
-"""Worker-process service runtime: the boundary type the upscaler sits behind.
+"""Worker-process runtime behind every service of the boundary.
 
-Mirrors the reference's ``BaseService`` (``src/upscale/base_service.py:10-121``): three
-``torch.multiprocessing`` queues (jobs 32, results 32, commands 4096), one daemon worker process
-running ``proc_init`` then a poll loop that drains commands, takes one job, calls
-``proc_job_recieved`` and hands the result to ``on_queue`` or the result queue; the ``'exit'``
-command; ``ProcessDeadException`` / kill-process-group on errors when ``exit_on_error``.
+Contract kept from the reference's ``BaseService`` (``src/upscale/base_service.py:10-121``), because
+the pipelines drive it directly:
+
+* ``start()`` launches ONE daemon worker process; ``push_job(entry, timeout=10)`` /
+  ``push_job_nowait(entry)`` feed it, ``get_result(timeout=10)`` reads results (or the worker calls
+  ``on_queue(entry)`` instead, when set); ``wait_for_job_clear()``, ``stop()``, ``join(timeout=15)``;
+* queues ``job_queue`` / ``result_queue`` (32 deep) and ``cmd_queue`` (4096), the ``'exit'`` command;
+* worker hooks ``proc_init()``, ``proc_job_recieved(job) -> entry``, ``proc_cleanup()``;
+* failure policy: with ``exit_on_error`` a worker exception (or a dead worker noticed by the client,
+  ``ProcessDeadException``) prints the traceback and interrupts the whole process group; without it
+  the exception propagates and the worker dies; a full result queue drops the result with a warning;
+* the object itself is what gets pickled into the worker, minus its ``Process`` handle.
+
+Differences that matter on ROCm: the worker is spawned (a HIP context does not survive ``fork``), it
+blocks on the job queue instead of spinning, and on exit it flushes the result queue's feeder thread
+before it terminates so that the last results are not lost.
 """
 from __future__ import annotations
 
 import abc
 import os
+import queue
 import signal
 import time
 import traceback
-from queue import Empty, Full
 
 import torch.multiprocessing as mp
 
+_JOB_DEPTH = 32
+_RESULT_DEPTH = 32
+_COMMAND_DEPTH = 4096
+_EXIT = "exit"
+_IDLE_WAIT_S = 0.001
+
 
 class ProcessDeadException(Exception):
-    pass
+    """The worker process is gone (raised on the client side when ``exit_on_error`` is set)."""
 
 
-class BaseService(metaclass=abc.ABCMeta):
+def _interrupt_process_group(ex: BaseException) -> None:
+    traceback.print_exc()
+    print(ex)
+    os.killpg(os.getpgid(os.getpid()), signal.SIGINT)
+
+
+class BaseService(abc.ABC):
     on_queue = None
     exit_on_error = False
-    #: multiprocessing start method.  'spawn' is required once the parent has touched the GPU
-    #: (HIP contexts do not survive fork); the reference relies on the platform default.
+    #: multiprocessing start method ('spawn': the parent may already hold a HIP context)
     mp_start_method = "spawn"
 
     def __init__(self) -> None:
-        ctx = mp.get_context(self.mp_start_method)
-        self.job_queue = ctx.Queue(maxsize=32)
-        self.result_queue = ctx.Queue(maxsize=32)
-        self.cmd_queue = ctx.Queue(maxsize=4096)
-        self.proc = ctx.Process(target=self.proc_pre_main, daemon=True)
+        mpctx = mp.get_context(self.mp_start_method)
+        self.job_queue = mpctx.Queue(maxsize=_JOB_DEPTH)
+        self.result_queue = mpctx.Queue(maxsize=_RESULT_DEPTH)
+        self.cmd_queue = mpctx.Queue(maxsize=_COMMAND_DEPTH)
+        self.proc = mpctx.Process(target=self.proc_pre_main, daemon=True)
 
     def __getstate__(self):
-        state = self.__dict__.copy()
-        state.pop("proc", None)  # a Process handle cannot be pickled into its own child
-        return state
+        # the service object is the worker's target: everything travels except the process handle
+        return {k: v for k, v in self.__dict__.items() if k != "proc"}
 
-    def start(self):
-        self.proc.start()
+    # ---------------------------------------------------------------- worker side
+    def proc_init(self) -> None:
+        """Runs once in the worker before the first job (load models, create device contexts)."""
 
-    def proc_pre_main(self):
+    def proc_job_recieved(self, job):
+        """One job in, one result entry out."""
+        return job
+
+    def proc_cleanup(self) -> None:
+        """Runs once in the worker after the exit command."""
+
+    def proc_pre_main(self) -> None:
         self.proc_main()
 
-    def _drain_commands(self) -> bool:
-        want_exit = False
-        while True:
-            try:
-                if self.cmd_queue.get_nowait() == "exit":
-                    want_exit = True
-            except Empty:
-                return want_exit
+    def _exit_requested(self) -> bool:
+        asked = False
+        try:
+            while True:  # drain: later commands must not pile up behind an exit
+                asked |= self.cmd_queue.get_nowait() == _EXIT
+        except queue.Empty:
+            return asked
 
-    def proc_main(self):
+    def _deliver(self, entry) -> None:
+        if self.on_queue is not None:
+            self.on_queue(entry)
+            return
+        try:
+            self.result_queue.put_nowait(entry)
+        except queue.Full:
+            print(f"{type(self).__name__}: result queue is full, result of this job dropped (consumer too slow?)")
+
+    def proc_main(self) -> None:
         try:
             self.proc_init()
-            while not self._drain_commands():
+            while not self._exit_requested():
                 try:
-                    job = self.job_queue.get_nowait()
-                except Empty:
-                    time.sleep(0.001)
+                    job = self.job_queue.get(timeout=_IDLE_WAIT_S)
+                except queue.Empty:
                     continue
-                entry = self.proc_job_recieved(job)
-                try:
-                    if self.on_queue is not None:
-                        self.on_queue(entry)
-                    else:
-                        self.result_queue.put_nowait(entry)
-                except Full:
-                    print("BaseService.proc_main: result queue is full; is the consumer fast enough?")
+                self._deliver(self.proc_job_recieved(job))
             self.proc_cleanup()
-            print("BaseService.proc_main: exit requested")
-            # results still in the queue's feeder thread must reach the parent before we go
             self.result_queue.close()
-            self.result_queue.join_thread()
-            os.kill(os.getpid(), signal.SIGTERM)
-        except Exception as ex:
-            if self.exit_on_error:
-                traceback.print_exc()
-                print(ex)
-                os.killpg(os.getpgid(os.getpid()), signal.SIGINT)
-            else:
+            self.result_queue.join_thread()  # results still in the feeder thread reach the client first
+        except Exception as ex:  # noqa: BLE001 - the policy below decides
+            if not self.exit_on_error:
                 raise
-
-    def check_proc(self):
-        if not self.exit_on_error:
+            _interrupt_process_group(ex)
             return
-        if not self.proc.is_alive():
+        print(f"{type(self).__name__}: worker leaves on request")
+        os.kill(os.getpid(), signal.SIGTERM)  # daemon threads of the runtime must not keep it alive
+
+    # ---------------------------------------------------------------- client side
+    def start(self) -> None:
+        self.proc.start()
+
+    def check_proc(self) -> None:
+        if self.exit_on_error and not self.proc.is_alive():
             try:
                 raise ProcessDeadException("process is dead!")
-            except Exception as ex:
-                traceback.print_exc()
-                print(ex)
-                os.killpg(os.getpgid(os.getpid()), signal.SIGINT)
+            except ProcessDeadException as ex:
+                _interrupt_process_group(ex)
 
-    def push_job(self, entry, timeout=10):
+    def push_job(self, entry, timeout=10) -> None:
         self.check_proc()
         self.job_queue.put(entry, timeout=timeout)
 
-    def push_job_nowait(self, entry):
+    def push_job_nowait(self, entry) -> None:
         self.check_proc()
         self.job_queue.put_nowait(entry)
 
@@ -110,24 +136,14 @@ class BaseService(metaclass=abc.ABCMeta):
         self.check_proc()
         return self.result_queue.get(timeout=timeout)
 
+    def wait_for_job_clear(self) -> None:
+        while not self.job_queue.empty():
+            time.sleep(_IDLE_WAIT_S)
+
     def join(self, timeout=15):
         self.proc.join(timeout=timeout)
         return self.proc.exitcode
 
-    def wait_for_job_clear(self):
-        while not self.job_queue.empty():
-            time.sleep(0.001)
-
     def stop(self):
-        self.cmd_queue.put("exit")
-        self.join()
-
-    # hooks ---------------------------------------------------------------------------------
-    def proc_init(self):
-        pass
-
-    def proc_job_recieved(self, job):
-        pass
-
-    def proc_cleanup(self):
-        pass
+        self.cmd_queue.put(_EXIT)
+        return self.join()

@@ -1,14 +1,22 @@
-"""Queue entry type and the upscaler service contract.
+"""The job record and the upscaler-service contract of the drop-in boundary.
 
-Mirrors the reference's ``src/upscale/upscaler_base.py:17-63``: ``UpscalerQueueEntry`` fields and
-``BaseUpscalerService.proc_job_recieved`` (profiler spans ``'recoder.output'`` (end),
-``'upscaler.upscale'``, ``'upscaler.output'`` (start); result entry carries ``elapsed`` and
-``last_modified``).
+What callers of the reference depend on (``src/upscale/upscaler_base.py:17-63``, used from
+``src/sharkshark/pipeline.py:73-118`` and ``image_server/image_pipeline.py:280-351``):
+
+* ``UpscalerQueueEntry`` - the record that crosses the process boundary in both directions, with
+  exactly these field names: ``frames`` (uint8 NHWC tensor, on the device), ``audio_segment``
+  (passed through untouched), ``step`` (job ordinal), ``elapsed`` (seconds spent in the worker),
+  ``last_modified`` (wall time the result was produced) and ``profiler``;
+* ``BaseUpscalerService.proc_job_recieved(job) -> entry`` - closes the producer's
+  ``'recoder.output'`` span, times ``self.upscale(job.frames)`` as ``'upscaler.upscale'`` and opens
+  ``'upscaler.output'`` for the consumer to close;
+* class attributes ``lr_shape`` / ``output_shape`` / ``on_queue`` that the pipelines overwrite.
 """
 from __future__ import annotations
 
+import dataclasses
 import time
-from dataclasses import dataclass
+from typing import Any, Optional, Tuple
 
 import torch
 
@@ -16,36 +24,37 @@ from ..util.profiler import Profiler
 from .base_service import BaseService
 
 
-@dataclass
+@dataclasses.dataclass
 class UpscalerQueueEntry:
-    frames: torch.Tensor = None
-    audio_segment: torch.Tensor = None
+    frames: Optional[torch.Tensor] = None
+    audio_segment: Any = None
     step: int = 0
     elapsed: float = 0
     last_modified: float = 0
-    profiler: Profiler = None
+    profiler: Optional[Profiler] = None
+
+    def answered_by(self, frames: torch.Tensor, elapsed: float) -> "UpscalerQueueEntry":
+        """The result record of this job: same step / audio / profiler, new frames and timing."""
+        return dataclasses.replace(self, frames=frames, elapsed=elapsed, last_modified=time.time())
 
 
 class BaseUpscalerService(BaseService):
     profiler: Profiler
-    lr_shape = (720, 1280)
-    output_shape = (1440, 2560)
+    lr_shape: Tuple[int, int] = (720, 1280)
+    output_shape: Optional[Tuple[int, int]] = (1440, 2560)
     on_queue = None
 
-    def __init__(self) -> None:
-        super().__init__()
+    def upscale(self, frames: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError("an upscaler service implements upscale(uint8 NHWC) -> uint8 NHWC")
 
-    def proc_job_recieved(self, job: UpscalerQueueEntry):
-        self.profiler = job.profiler
-        began = time.time()
-        job.profiler.end("recoder.output")
-        job.profiler.start("upscaler.upscale")
-        frames_up = self.upscale(job.frames)
-        job.profiler.end("upscaler.upscale")
-        elapsed = time.time() - began
-        job.profiler.start("upscaler.output")
-        return UpscalerQueueEntry(frames=frames_up, step=job.step, audio_segment=job.audio_segment, elapsed=elapsed,
-                                  last_modified=time.time(), profiler=job.profiler)
-
-    def upscale(self, frames):
-        raise NotImplementedError
+    def proc_job_recieved(self, job: UpscalerQueueEntry) -> UpscalerQueueEntry:  # (sic) the reference's spelling
+        prof = job.profiler if job.profiler is not None else Profiler()
+        self.profiler = prof  # upscale() implementations add their own spans to the job's profiler
+        arrived = time.time()
+        prof.end("recoder.output")
+        with prof.span("upscaler.upscale"):
+            upscaled = self.upscale(job.frames)
+        result = job.answered_by(upscaled, elapsed=time.time() - arrived)
+        result.profiler = prof
+        prof.start("upscaler.output")
+        return result
