@@ -1,11 +1,4 @@
-from .profiler import Profiler  # noqa: F401
+"""Small host utilities shared by the service mirror (currently the span profiler that rides in every queue entry)."""
+from .profiler import Profiler
 
-
-def human_readable(v, step=1024, unit=("B", "KB", "MB", "GB", "TB")):
-    """Reference ``src/util/__init__.py:1-7``."""
-    assert step > 0
-    idx = 0
-    while v > step:
-        v /= step
-        idx += 1
-    return f"{v:.4f}{unit[min(idx, len(unit) - 1)]}"
+__all__ = ["Profiler"]
