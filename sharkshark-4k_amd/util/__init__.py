@@ -1,13 +1,11 @@
 """Small host utilities shared by the service mirror: the span profiler that rides in every queue
 entry and the byte formatter the reference's pipelines print queue/bitrate sizes with."""
-import math
 
 from .profiler import Profiler
 
 __all__ = ["Profiler", "human_readable"]
 
 _UNITS = ("B", "KB", "MB", "GB", "TB")
-
 
 def human_readable(v, step=1024, unit=_UNITS):
     """``'1.5000MB'``-style rendering of a byte count: four decimals, the largest unit for which the
