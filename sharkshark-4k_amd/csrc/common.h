@@ -89,8 +89,8 @@ enum Epi {
 
 // One 3x3 / pad 1 / stride 1 convolution over "planes" activations (see conv_mfma.hip) as an implicit GEMM.
 struct ConvArgs {
-  const char* in0; uint32_t in0_plane_bytes; int in0_plane0, nchunks0;  // segment 0: one plane per K-chunk
-  const char* in1; uint32_t in1_plane_bytes; int in1_plane0, nchunks1;  // optional segment 1 (dense concat is free)
+  const char* in0; size_t in0_plane_bytes; int in0_plane0, nchunks0;  // segment 0: one plane per K-chunk
+  const char* in1; size_t in1_plane_bytes; int in1_plane0, nchunks1;  // optional segment 1 (dense concat is free)
   const char* zero_page;                // >= 64 zero bytes: DMA source for the zero padding
   int N, H, W;                          // conv grid (== output grid before SUB2/PS2)
   int ups2;                             // input is the nearest-x2 upsampling of an (H/2, W/2) tensor
@@ -99,11 +99,11 @@ struct ConvArgs {
   const float* prelu;                   // [cout_pad] or null
   int act; float slope;
   float alpha, gamma;                   // v = (act(acc+bias)*alpha + res1)*gamma + res2
-  const char* res1; uint32_t r1_plane_bytes; int r1_plane0;
-  const char* res2; uint32_t r2_plane_bytes; int r2_plane0;
+  const char* res1; size_t r1_plane_bytes; int r1_plane0;
+  const char* res2; size_t r2_plane_bytes; int r2_plane0;
   int bsvd_resid;                       // channels < 3: v = res1 - v (bsvd/model.py:436-442)
   int epi;
-  char* out; uint32_t out_plane_bytes; int out_plane0;
+  char* out; size_t out_plane_bytes; int out_plane0;
   int cout_real, cout_pad;
   int tiles_x, tiles_y;
   int reverse;                          // walk the tiles back to front (placement only, never results)

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
       const int iy = y0 - 1 + (plan[j] & 0xff), ix = x0 - 1 + ((plan[j] >> 8) & 0xff);
       const bool ok = plan[j] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
       const int sy = a.ups2 ? (iy >> 1) : iy, sx = a.ups2 ? (ix >> 1) : ix;
-      src_off[j] = ok ? (uint32_t)((n * Hs + sy) * Ws + sx) * (uint32_t)REC + (uint32_t)((plan[j] >> 16) & 0xff) : OOB;
+      src_off[j] = ok ? (uint32_t)(n * Hs + sy) * (uint32_t)Ws + (uint32_t)sx : OOB;  // source pixel index inside a plane
     }
   };
   // One K-chunk prefetch = NDMA wave-level DMA instructions per wave (halo tile, then weights).
@@ -269,7 +269,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
     if (idx < NDMA_T) {
       const int k = wave + NW * idx;
       if (k < TILE_DMA && !(DBG & DBG_NO_TILE_DMA)) {
-        const char* src = (src_off[idx] != OOB && !(DBG & DBG_NO_MMA)) ? ((((DBG & DBG_NO_STORE) != 0) != ((DBG & DBG_NO_EPILOGUE) != 0)) ? a.in0 + (src_off[idx] & 0x1FFFFFu) : pf_plane + src_off[idx]) : a.zero_page + (lane & 3) * 16;
+        const size_t boff = (size_t)src_off[idx] * REC + (size_t)((plan[idx] >> 16) & 0xff);  // record + swizzled 16-byte slot
+        const char* src = (src_off[idx] != OOB && !(DBG & DBG_NO_MMA)) ? ((((DBG & DBG_NO_STORE) != 0) != ((DBG & DBG_NO_EPILOGUE) != 0)) ? a.in0 + (boff & 0x1FFFFFu) : pf_plane + boff) : a.zero_page + (lane & 3) * 16;
         const uint32_t dst = __builtin_amdgcn_readfirstlane(pf_tdst + k * 1024);
         if (plan[idx] >= 0) dma16(src, dst);  // lanes past the tile's last slot are masked off (EXEC)
       }
@@ -782,7 +783,7 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
   SS4K_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0, "conv3x3: empty grid");
   SS4K_REQUIRE(a.act != ACT_LRELU || (a.slope >= 0.f && a.slope <= 1.f), "conv3x3: LeakyReLU slope must be in [0,1]");
   SS4K_REQUIRE(!a.ups2 || ((a.H % 2 == 0) && (a.W % 2 == 0)), "conv3x3: ups2 needs even grid");
-  SS4K_REQUIRE((double)a.N * a.H * a.W * (dtype == SS4K_F16 ? 32.0 : 64.0) < 4294967296.0, "conv3x3: a plane must stay below 4 GiB");
+  SS4K_REQUIRE((double)a.N * a.H * a.W < 2147483648.0, "conv3x3: a plane holds at most 2^31 pixels");
   ProfEvent pe{};
   if (ctx->prof) {
     if (!ctx->prof_pool.empty()) { pe = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); }

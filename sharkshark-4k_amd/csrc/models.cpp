@@ -257,9 +257,9 @@ Tens Model::act(int idx, size_t pixels, int channels) {
   if ((int)acts.size() <= idx) acts.resize(idx + 1);
   const int ch32 = (channels + 31) / 32 * 32;
   const int planes = planes_for(ch32);
-  SS4K_REQUIRE((double)pixels * rec() < 4294967296.0, "activation plane must stay below 4 GiB");
+  SS4K_REQUIRE(pixels < 2147483648ull, "an activation plane holds at most 2^31 pixels");
   acts[idx].ensure((size_t)planes * pixels * rec());
-  return Tens{acts[idx].as<char>(), (uint32_t)(pixels * rec()), 0};
+  return Tens{acts[idx].as<char>(), pixels * (size_t)rec(), 0};
 }
 
 void Model::out_shape(int n, int h, int w, int* oc, int* oh, int* ow) const {
@@ -284,15 +284,15 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
   SS4K_REQUIRE(n > 0 && h > 0 && w > 0, "forward: empty input");
   const bool f16 = desc.dtype == SS4K_F16;
   if (desc.kind != SS4K_FSRCNN) {
-    // the conv kernel addresses a plane with 32-bit byte offsets: split batches whose largest
-    // internal tensor (at output resolution) would exceed 4 GiB per plane (e.g. 4 frames at 4320x7680)
+    // the conv kernel indexes the pixels of a plane with 32 bits: split batches whose largest internal
+    // tensor would exceed 2^31 pixels (none of the BASELINE shapes: 4 frames at 4320x7680 are 133 M)
     int oc, oh, ow; out_shape(1, h, w, &oc, &oh, &ow);
     // largest grid a "planes" tensor of this network lives on: RRDBNet's tail runs at the output
     // resolution; SRVGG (PixelShuffle in the glue tail) and BSVD never leave the input resolution
     const bool tail_at_out = desc.kind == SS4K_RRDBNET;
-    const double plane1 = (double)(tail_at_out ? std::max(oh, h) : h) * (tail_at_out ? std::max(ow, w) : w) * (double)rec();
-    SS4K_REQUIRE(plane1 < 4294967296.0, "forward: a single frame exceeds the 4 GiB plane limit");
-    const int max_n = std::max(1, (int)(4294967295.0 / plane1));
+    const double plane1 = (double)(tail_at_out ? std::max(oh, h) : h) * (tail_at_out ? std::max(ow, w) : w);
+    SS4K_REQUIRE(plane1 < 2147483648.0, "forward: a single frame exceeds 2^31 pixels");
+    const int max_n = std::max(1, (int)(2147483647.0 / plane1));
     if (n > max_n) {
       for (int i = 0; i < n; i += max_n) {
         const int nn = std::min(max_n, n - i);

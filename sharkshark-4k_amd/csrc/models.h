@@ -6,7 +6,7 @@
 namespace ss4k {
 
 // activation view in the "planes" layout (conv_mfma.hip): base, bytes per plane (N*H*W*record), first plane
-struct Tens { char* p; uint32_t plane_bytes; int plane0; };
+struct Tens { char* p; size_t plane_bytes; int plane0; };
 
 struct ConvLayer {
   DevBuf w, bias, prelu;

@@ -381,6 +381,27 @@ def test_hip_service_worker_process_roundtrip():
     assert not svc.proc.is_alive()
 
 
+def test_rrdbnet_x4_plane_beyond_4gib(ctx):
+    """RRDBNet x4 on the image server's largest frame (4096x2048, image_pipeline.py:265-271): the tail
+    runs on 16384x8192 = 134 M pixels, 4.29 GB per fp16 plane - past 32-bit byte offsets.  Checked by
+    shift invariance: far-corner crop of the big output == the net run on the matching input crop
+    (interior only, one RRDB block has a receptive field of ~25 LR pixels)."""
+    tab = W.rrdbnet_table(21, scale=4, num_feat=64, num_block=1, num_grow_ch=32)
+    m = factory.build_model_esrgan(ctx, "RealESRGAN_x4plus", weights=tab, dtype="f16", scale=4, num_block=1)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(1, 3, 2048, 4096, generator=g)
+    big = m(x.cuda())
+    assert big.shape == (1, 3, 8192, 16384)
+    y0, x0, sz, mg = 1760, 3808, 256, 40  # crop near the highest addresses; mg = margin in LR pixels
+    small = m(x[:, :, y0:y0 + sz, x0:x0 + sz].contiguous().cuda())
+    a = big[:, :, 4 * (y0 + mg):4 * (y0 + sz - mg), 4 * (x0 + mg):4 * (x0 + sz - mg)]
+    b = small[:, :, 4 * mg:4 * (sz - mg), 4 * mg:4 * (sz - mg)]
+    assert torch.isfinite(big[:, :, ::64, ::64]).all()
+    assert (a - b).abs().max().item() < 2e-3, (a - b).abs().max().item()
+    del big, small
+    torch.cuda.empty_cache()
+
+
 def test_stream_dispatcher_over_two_hip_services():
     """SURVEY §8 f1 on the device: a recorder batch cut into 4-frame jobs, dealt round-robin over two
     HipUpscalerService worker processes (both on GPU 0 here; one per GPU on a node), results re-ordered
