@@ -114,6 +114,11 @@ void ss4k_upscaler_destroy(ss4k_upscaler* up);
 /* forget `lr_prev` state: the next frame is a "first frame" again (noise map 0.05, :269-271) */
 int ss4k_upscaler_reset(ss4k_upscaler* up);
 int ss4k_upscaler_out_shape(const ss4k_upscaler* up, int n, int h, int w, int* out_h, int* out_w);
+/* Host milliseconds the last ss4k_upscale_frames spent ENQUEUEING the denoise stage and the SR model:
+ * exactly what the reference's 'fsrcnn.denoise' / 'fsrcnn.model' profiler spans measure (host
+ * time.time() around asynchronous launches, fsrcnn_upscaler.py:276-278,290-300; util/profiler.py:12-24).
+ * denoise_ms = 0 when the job did not denoise. */
+int ss4k_upscaler_last_enqueue_ms(const ss4k_upscaler* up, double* denoise_ms, double* model_ms);
 
 /* Replaces FsrcnnUpscalerService.upscale(frames) (fsrcnn_upscaler.py:144-326): uint8 NHWC
  * (n,h,w,3) device frames in, uint8 NHWC (n,out_h,out_w,3) device frames out. */

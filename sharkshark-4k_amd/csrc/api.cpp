@@ -1,5 +1,6 @@
 // C ABI (include/ss4k.h): context, models, the frame-in/frame-out upscaler and the granular ops.
 #include "models.h"
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <memory>
@@ -50,6 +51,11 @@ struct Upscaler {
   DevBuf img, lr, lr4, den, hr, hr2, lb, hb, lbb, hbb, st_hr, st_lr;
   bool first_frame = true;
   bool taps_on = false;
+  // host time spent enqueueing the last job's denoise / SR model stages: what the reference's
+  // 'fsrcnn.denoise' / 'fsrcnn.model' profiler spans measure on an asynchronous device queue
+  // (util/profiler.py:12-24 - no device sync)
+  double enq_denoise_ms = 0, enq_model_ms = 0;
+  static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
   DevBuf tap[5]; int tap_dims[5][4] = {};
 
   void save_tap(int which, const float* src, int n, int c, int h, int w, hipStream_t st) {
@@ -83,7 +89,9 @@ struct Upscaler {
     int oc, H, W; sr->out_shape(n, lh, lw, &oc, &H, &W);
     hr.ensure((size_t)P * H * W * 4);
     float* hrp = hr.as<float>();
+    const double tm0 = now_ms();
     sr->forward(lrp, hrp, n, lh, lw, st);
+    enq_model_ms = now_ms() - tm0; enq_denoise_ms = 0;
     save_tap(0, lrp, n, 3, lh, lw, st); save_tap(1, hrp, n, 3, H, W, st);
     st_hr.ensure(P * 8); st_lr.ensure(P * 8);
     op_plane_stats(ctx, hrp, st_hr.as<float>(), P, H * W, st);
@@ -142,7 +150,9 @@ struct Upscaler {
         fill_plane(dst + plane * 3, plane, noise, st);  // constant noise-map plane
       }
       float* den0 = den.as<float>(); float* den1 = den0 + plane * P;
+      const double t0 = now_ms();
       dn->forward(lr4.as<float>(), den0, n, lh, lw, st);
+      enq_denoise_ms = now_ms() - t0;
       // clamp(sharpen(den)) * 0.8 + 0.2 * lr   (:279-281)
       op_depthwise_reflect(den0, den1, k_sharp.as<float>(), P, lh, lw, 3, 1, lr_before, 0.8f, (float)(1 - 0.8), st);
       lr_cur = den1;
@@ -151,8 +161,10 @@ struct Upscaler {
     int oc, H, W; sr->out_shape(1, lh, lw, &oc, &H, &W);
     hr.ensure((size_t)P * H * W * 4 * 2);
     float* hrp = hr.as<float>();
+    const double tm0 = now_ms();
     if (cfg.sr_is_realesrgan) sr->forward(lr_cur, hrp, n, lh, lw, st);
     else sr->forward(lr_cur, hrp, P, lh, lw, st);  // FSRCNN on the colour planes (:297)
+    enq_model_ms = now_ms() - tm0;
     if (cfg.denoising) {
       float* hs = hrp + (size_t)P * H * W;
       op_depthwise_reflect(hrp, hs, k_sharp_hr.as<float>(), P, H, W, 3, 1, nullptr, 0, 0, st);  // :298-299
@@ -291,6 +303,11 @@ int ss4k_upscale_frames(ss4k_upscaler* up, const uint8_t* in, int n, int h, int 
       up->u.multi(in, n, h, w, out, st);
     }
   });
+}
+int ss4k_upscaler_last_enqueue_ms(const ss4k_upscaler* up, double* denoise_ms, double* model_ms) {
+  if (!up || !denoise_ms || !model_ms) return SS4K_EINVAL;
+  *denoise_ms = up->u.enq_denoise_ms; *model_ms = up->u.enq_model_ms;
+  return SS4K_OK;
 }
 int ss4k_upscaler_enable_taps(ss4k_upscaler* up, int en) { if (!up) return SS4K_EINVAL; up->u.taps_on = en != 0; return SS4K_OK; }
 int ss4k_upscaler_read_tap(ss4k_upscaler* up, int which, float* out, size_t cap, int dims[4], void* stream) {

@@ -99,10 +99,14 @@ class HipUpscalerService(BaseUpscalerService):
         if frames.ndim == 4:
             assert frames.shape[-1] == 3
             prof = getattr(self, "profiler", None)
+            up = self._get_upscaler()
+            out = up(frames)
             if prof is not None:
-                prof.start("fsrcnn.model")  # key kept for consumers of the reference's profiler JSON
-            out = self._get_upscaler()(frames)
-            if prof is not None:
-                prof.end("fsrcnn.model")
+                # the reference's span keys (fsrcnn_upscaler.py:276-278,290-300): host time around the
+                # asynchronous stage launches, measured inside the library
+                denoise_ms, model_ms = up.last_enqueue_ms()
+                if self.denoise_model is not None:
+                    prof.add("fsrcnn.denoise", denoise_ms / 1000.0)
+                prof.add("fsrcnn.model", model_ms / 1000.0)
             return out
         raise Exception(frames.shape)

@@ -55,6 +55,13 @@ class Profiler:
         return took
 
     # -- additions ------------------------------------------------------------------------------
+    def add(self, name: str, seconds: float) -> None:
+        """Record a span that was timed elsewhere (e.g. inside the native library)."""
+        acc = self._acc.setdefault(name, [0.0, 0])
+        acc[0] += seconds
+        acc[1] += 1
+        self.data[name] = acc[0] / acc[1]
+
     @contextlib.contextmanager
     def span(self, name: str) -> Iterator[None]:
         self.start(name)

@@ -402,6 +402,25 @@ def test_rrdbnet_x4_plane_beyond_4gib(ctx):
     torch.cuda.empty_cache()
 
 
+def test_service_profiler_keys_match_reference():
+    """The worker's result carries the reference's span keys for the same configuration
+    (MANIFEST profiler_keys recorded from the reference service): 'fsrcnn.denoise' only when the job
+    denoised, 'fsrcnn.model', 'upscaler.upscale'."""
+    from sharkshark4k_amd.upscale.hip_upscaler import HipUpscalerService
+    from sharkshark4k_amd.upscale.upscaler_base import UpscalerQueueEntry
+    from sharkshark4k_amd.util import Profiler
+    for name in ("svc_single_fsrcnn_x2_denoise", "svc_single_fsrcnn_x2"):
+        m = CASES[name]
+        svc = HipUpscalerService(device=0, denoising=m["denoising"], denoise_rate=m["denoise_rate"], upscaler_model="fsrcnn",
+                                 scale=m["factor"], lr_shape=tuple(m["lr_shape"]), dtype="f32",
+                                 weights={"sr": W.fsrcnn_table(seed=m["seed"]), "denoise": W.bsvd_table(seed=m["bsvd_seed"])})
+        svc.proc_init()  # in-process: the worker body without the process around it
+        g = load_golden(name)
+        res = svc.proc_job_recieved(UpscalerQueueEntry(frames=dev(g["frames"]), step=0, profiler=Profiler()))
+        assert_u8_close(res.frames, g["out1"], what=name)
+        assert sorted(k for k in res.profiler.data) == sorted(m["profiler_keys"]), (name, res.profiler.data)
+
+
 def test_stream_dispatcher_over_two_hip_services():
     """SURVEY §8 f1 on the device: a recorder batch cut into 4-frame jobs, dealt round-robin over two
     HipUpscalerService worker processes (both on GPU 0 here; one per GPU on a node), results re-ordered
