@@ -90,6 +90,10 @@ int ss4k_model_in_channels(const ss4k_model* m);
 /* Replaces `self.model(x)` (fsrcnn_upscaler.py:181,293-297) and `self.denoise_model(x)`
  * (:277): x is contiguous NCHW fp32 in [0,1] on the device; result contiguous NCHW fp32.
  * BSVD: in (n,4,h,w) = the reference's (n,1,4,h,w); out (n,3,h,w).  FSRCNN: (planes,1,h,w). */
+/* Device bytes of activation workspace the model holds after a forward of n frames of h x w (it grows
+ * to the largest shape seen and is reused); nothing is allocated or launched by this call.  The
+ * size query of SURVEY.md 8(b) (`ss4k_workspace_bytes`). */
+int ss4k_model_workspace_bytes(ss4k_model* m, int n, int h, int w, size_t* bytes);
 int ss4k_model_forward(ss4k_model* m, const float* in_nchw_dev, float* out_nchw_dev, int n, int h,
                        int w, void* hip_stream);
 

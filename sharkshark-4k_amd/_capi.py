@@ -24,7 +24,7 @@ SYMBOLS = [
     "ss4k_abi_version", "ss4k_last_error", "ss4k_ctx_create", "ss4k_ctx_destroy", "ss4k_ctx_device",
     "ss4k_model_param_count", "ss4k_model_create", "ss4k_model_destroy", "ss4k_model_out_shape",
     "ss4k_model_in_channels", "ss4k_model_forward", "ss4k_upscaler_create", "ss4k_upscaler_destroy",
-    "ss4k_upscaler_reset", "ss4k_upscaler_out_shape", "ss4k_upscaler_last_enqueue_ms", "ss4k_upscale_frames", "ss4k_upscaler_enable_taps",
+    "ss4k_upscaler_reset", "ss4k_upscaler_out_shape", "ss4k_upscaler_last_enqueue_ms", "ss4k_model_workspace_bytes", "ss4k_upscale_frames", "ss4k_upscaler_enable_taps",
     "ss4k_upscaler_read_tap", "ss4k_op_u8nhwc_to_f32nchw", "ss4k_op_area_resize", "ss4k_op_bicubic_resize",
     "ss4k_op_bilinear_resize", "ss4k_op_depthwise_reflect", "ss4k_op_plane_stats", "ss4k_op_f32nchw_to_u8nhwc",
     "ss4k_prof_enable", "ss4k_prof_reset", "ss4k_prof_read", "ss4k_bench_conv",
@@ -74,6 +74,7 @@ def lib() -> C.CDLL:
     L.ss4k_upscaler_create.argtypes = [vp, C.POINTER(UpscaleCfg), vp, vp, C.POINTER(vp)]
     L.ss4k_upscaler_destroy.argtypes = [vp]; L.ss4k_upscaler_destroy.restype = None
     L.ss4k_upscaler_reset.argtypes = [vp]
+    L.ss4k_model_workspace_bytes.argtypes = [vp, i, i, i, C.POINTER(C.c_size_t)]
     L.ss4k_upscaler_last_enqueue_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ss4k_upscaler_out_shape.argtypes = [vp, i, i, i, C.POINTER(i), C.POINTER(i)]
     L.ss4k_upscale_frames.argtypes = [vp, vp, i, i, i, vp, sz, vp]
@@ -235,6 +236,11 @@ class Model:
             self.close()
         except Exception:
             pass
+
+    def workspace_bytes(self, n, h, w) -> int:
+        b = C.c_size_t()
+        _check(lib().ss4k_model_workspace_bytes(self._h, n, h, w, C.byref(b)))
+        return int(b.value)
 
     def out_shape(self, n, h, w):
         oc, oh, ow = C.c_int(), C.c_int(), C.c_int()

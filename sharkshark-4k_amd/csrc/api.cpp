@@ -248,6 +248,12 @@ int ss4k_model_out_shape(const ss4k_model* m, int n, int h, int w, int* oc, int*
   return guard([&] { SS4K_REQUIRE(m && oc && oh && ow, "NULL argument"); m->m.out_shape(n, h, w, oc, oh, ow); });
 }
 int ss4k_model_in_channels(const ss4k_model* m) { return m ? m->m.in_channels() : SS4K_EINVAL; }
+int ss4k_model_workspace_bytes(ss4k_model* m, int n, int h, int w, size_t* bytes) {
+  return guard([&] {
+    SS4K_REQUIRE(m && bytes, "ss4k_model_workspace_bytes: NULL argument");
+    *bytes = m->m.workspace_bytes(n, h, w);
+  });
+}
 int ss4k_model_forward(ss4k_model* m, const float* in, float* out, int n, int h, int w, void* stream) {
   return guard([&] {
     SS4K_REQUIRE(m && in && out, "ss4k_model_forward: NULL argument");

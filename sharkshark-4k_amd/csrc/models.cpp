@@ -232,6 +232,7 @@ void Model::build(const float* w, size_t n) {
 
 // ------------------------------------------------------------------------------------------
 void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, const ConvOpts& o, hipStream_t st) {
+  if (plan_only) return;
   const ConvLayer& L = layers[li];
   ConvArgs a{};
   a.in0 = in0.p; a.in0_plane_bytes = in0.plane_bytes; a.in0_plane0 = in0.plane0; a.nchunks0 = L.nchunks0;
@@ -251,6 +252,15 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
   launch_conv3x3(ctx, a, desc.dtype, st);
 }
 
+size_t Model::workspace_bytes(int n, int h, int w) {
+  plan_only = true; plan_bytes.clear();
+  try { forward(nullptr, nullptr, n, h, w, nullptr); } catch (...) { plan_only = false; throw; }
+  plan_only = false;
+  size_t total = 0;
+  for (size_t b : plan_bytes) total += (b + 255) & ~size_t(255);
+  return total;
+}
+
 // activation buffer idx holding `channels` channels (rounded up to whole 32-cout groups of planes,
 // which is what a producing conv writes) for `pixels` pixels
 Tens Model::act(int idx, size_t pixels, int channels) {
@@ -258,7 +268,13 @@ Tens Model::act(int idx, size_t pixels, int channels) {
   const int ch32 = (channels + 31) / 32 * 32;
   const int planes = planes_for(ch32);
   SS4K_REQUIRE(pixels < 2147483648ull, "an activation plane holds at most 2^31 pixels");
-  acts[idx].ensure((size_t)planes * pixels * rec());
+  const size_t need = (size_t)planes * pixels * rec();
+  if (plan_only) {
+    if ((int)plan_bytes.size() <= idx) plan_bytes.resize(idx + 1, 0);
+    plan_bytes[idx] = std::max(plan_bytes[idx], need);
+    return Tens{nullptr, pixels * (size_t)rec(), 0};
+  }
+  acts[idx].ensure(need);
   return Tens{acts[idx].as<char>(), pixels * (size_t)rec(), 0};
 }
 
@@ -276,6 +292,7 @@ int Model::in_channels() const {
 }
 
 void Model::pack_in(const float* in, const Tens& dst, int nplanes, int n, int c, int h, int w, int r, hipStream_t st) {
+  if (plan_only) return;
   if (desc.dtype == SS4K_F16) op_pack_input<__half>(in, reinterpret_cast<__half*>(dst.p), n, c, h, w, r, nplanes, st);
   else op_pack_input<float>(in, reinterpret_cast<float*>(dst.p), n, c, h, w, r, nplanes, st);
 }
@@ -304,6 +321,7 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
   if (desc.kind == SS4K_FSRCNN) {
     const size_t px = (size_t)n * h * w;
     if (acts.size() < 2) acts.resize(2);
+    if (plan_only) { plan_bytes.assign(2, px * 12 * 4); return; }
     acts[0].ensure(px * 12 * 4); acts[1].ensure(px * 12 * 4);
     fsrcnn_forward(ctx, fsw, desc.scale, in, out, n, h, w, acts[0].as<float>(), acts[1].as<float>(), st);
     return;
@@ -364,6 +382,7 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
     }
     Tens Z = act(3, px, layers[li].cout_pad);
     { ConvOpts o; o.out = Z; conv(li++, cur, nullptr, n, h, w, o, st); }
+    if (plan_only) return;
     if (f16) op_ps_nchw_addbase<__half>(reinterpret_cast<const __half*>(Z.p), out, in, n, h, w, desc.scale, 3, st);
     else op_ps_nchw_addbase<float>(reinterpret_cast<const float*>(Z.p), out, in, n, h, w, desc.scale, 3, st);
     return;
@@ -391,7 +410,7 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
       if (!desc.bsvd_stream) { conv(li++, masked(t, c), nullptr, N, H, W, relu6(outT), st); return; }
       const int lead = shifted_planes(c);
       Tens S = act(14, (size_t)N * H * W, lead * cw());
-      op_temporal_shift(t.p + (size_t)t.plane0 * t.plane_bytes, S.p, lead, N, (size_t)H * W, rec() / 16, cw(), c / 8, st);
+      if (!plan_only) op_temporal_shift(t.p + (size_t)t.plane0 * t.plane_bytes, S.p, lead, N, (size_t)H * W, rec() / 16, cw(), c / 8, st);
       const Tens rest{t.p, t.plane_bytes, t.plane0 + lead};
       conv(li++, S, planes_for(c) > lead ? &rest : nullptr, N, H, W, relu6(outT), st);
     };

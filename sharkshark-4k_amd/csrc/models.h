@@ -36,6 +36,11 @@ struct Model {
   size_t weight_bytes = 0;
   bool flip_walk = true;   // consecutive conv launches walk their tiles in opposite directions (cache reuse)
   int launch_parity = 0;
+  // plan_only: forward() walks the network without touching the device and records the activation
+  // bytes each buffer slot would need (ss4k_model_workspace_bytes)
+  bool plan_only = false;
+  std::vector<size_t> plan_bytes;
+  size_t workspace_bytes(int n, int h, int w);
   int dbg = 0;  // ablation build selector forwarded to the conv kernel (bench only)
   unsigned long long* dbg_buf = nullptr;
 

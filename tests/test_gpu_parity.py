@@ -421,6 +421,25 @@ def test_service_profiler_keys_match_reference():
         assert sorted(k for k in res.profiler.data) == sorted(m["profiler_keys"]), (name, res.profiler.data)
 
 
+def test_model_workspace_query(ctx):
+    """ss4k_model_workspace_bytes: the activation bytes a forward of that shape will hold, computed
+    without touching the device; checked against what the forward then really allocates."""
+    m = factory.build_model_esrgan(ctx, "RealESRGAN_x2plus", weights=rrdb_small_table(seed=9, scale=2, num_block=1),
+                                   dtype="f16", scale=2, num_block=1)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    want = m.workspace_bytes(2, 360, 640)
+    assert torch.cuda.mem_get_info()[0] == free0  # the query allocates nothing
+    assert want > 0 and m.workspace_bytes(4, 360, 640) > want > m.workspace_bytes(1, 360, 640)
+    x = torch.rand(2, 3, 360, 640, device="cuda")
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    y = m(x)
+    torch.cuda.synchronize()
+    used = free1 - torch.cuda.mem_get_info()[0] - y.numel() * 4
+    assert abs(used - want) <= 64 * 2 ** 20, (used, want)  # allocator granularity (2 MiB pages per buffer)
+
+
 def test_stream_dispatcher_over_two_hip_services():
     """SURVEY §8 f1 on the device: a recorder batch cut into 4-frame jobs, dealt round-robin over two
     HipUpscalerService worker processes (both on GPU 0 here; one per GPU on a node), results re-ordered
