@@ -276,6 +276,44 @@ def test_conv_networks_random_shapes(ctx, seed):
         assert psnr(build("f16")(x.cuda()), want) > 40.0, what
 
 
+def test_service_random_configurations(ctx):
+    """ss4k_upscale_frames on random configurations (batched / per-frame, +-denoise, +-area pre-resize,
+    +-bicubic output, x2 / x4, odd frame sizes, first and later job) against the oracle service.
+    tools/fuzz_service.py runs the long version."""
+    rng = np.random.default_rng(17)
+    bs_tab = W.bsvd_table(seed=21)
+    dn = factory.build_denoise_model(ctx, weights=bs_tab, dtype="f32")
+    for it in range(10):
+        single = bool(it % 2)
+        n = int(rng.integers(1, 4))
+        lh, lw = int(rng.integers(6, 24)) * 4, int(rng.integers(6, 32)) * 4
+        h, w = (lh, lw) if rng.integers(0, 2) else (lh + int(rng.integers(0, 40)), lw + int(rng.integers(0, 60)))
+        lrhr = bool(rng.integers(0, 4) > 0)
+        f = int(rng.choice([2, 4]))
+        if single:
+            tab = W.fsrcnn_table(seed=3)
+            sr = factory.build_model_fsrcnn(ctx, factor=f, weights=tab)
+            net, mode = (lambda x, tab=tab, f=f: onets.fsrcnn(x, tab, f)), "fsrcnn"
+        else:
+            tab = W.srvgg_table(5, num_feat=16, num_conv=2, upscale=f)
+            sr = _capi.Model(ctx, _capi.make_desc(_capi.SRVGG, _capi.F32, scale=f, num_feat=16, num_block=2),
+                             W.flatten(tab, W.srvgg_keys(2)))
+            net, mode = (lambda x, tab=tab, f=f: onets.srvgg(x, tab, 2, f)), "realesrgan"
+            if not lrhr:
+                h, w = lh, lw
+        denoise = single and bool(rng.integers(0, 2))
+        out_shape = (int(rng.integers(lh, lh * f + 9)), int(rng.integers(lw, lw * f + 13))) if rng.integers(0, 2) else None
+        rate = float(rng.choice([0.3, 1.0]))
+        frames = torch.from_numpy(smooth_u8(200 + it, (n, h, w, 3)))
+        what = f"single={single} denoise={denoise} n={n} in={h}x{w} lr={lh}x{lw} x{f} out={out_shape} resize={lrhr}"
+        up = _capi.Upscaler(ctx, sr, (lh, lw), out_shape, lrhr, single, dn if denoise else None, rate)
+        osv = osvc.OracleUpscaler(net, denoising=denoise, denoise_rate=rate, upscaler_model=mode, lr_hr_resize=lrhr,
+                                  denoise_model=lambda x: onets.bsvd_f1(x, bs_tab), output_shape=out_shape,
+                                  single_mode=single, lr_shape=(lh, lw))
+        for job in range(2):
+            assert_u8_close(up(frames.cuda()), osv.upscale(frames), what=f"{what} job {job}")
+
+
 # ------------------------------------------------------------------------------ image-server mode (SURVEY §8 f2)
 _IMG_MODE = {"sr": "srvgg", "seed": 41, "num_feat": 32, "num_conv": 2, "upscale": 4, "mode": "realesrgan",
              "lr_shape": [360, 640], "output_shape": None, "lr_hr_resize": False, "denoising": False,
