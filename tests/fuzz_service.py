@@ -1,4 +1,4 @@
-"""Dev tool: random-configuration fuzz of the whole hot path (ss4k_upscale_frames, fp32 nets) against
+"""Test infrastructure (long-running, run by hand on a GPU box): random-configuration fuzz of the whole hot path (ss4k_upscale_frames, fp32 nets) against
 the oracle service: uint8 frames within 1 LSB on <= 2 % of the bytes."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

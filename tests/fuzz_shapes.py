@@ -1,4 +1,4 @@
-"""Dev tool: random-shape parity fuzz of the conv networks (fp32 HIP vs the CPU oracle, rtol 1e-3 / atol 1e-4)."""
+"""Test infrastructure (long-running, run by hand on a GPU box): random-shape parity fuzz of the conv networks (fp32 HIP vs the CPU oracle, rtol 1e-3 / atol 1e-4)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

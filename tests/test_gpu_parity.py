@@ -245,7 +245,7 @@ def test_service_rejects_bad_input(ctx):
 def test_conv_networks_random_shapes(ctx, seed):
     """Edge tiles of the conv kernel: random N, H, W (not multiples of the 16x32 tile, smaller than a
     tile, several frames) through one-block RRDBNet x1/x2/x4, a small SRVGG and BSVD; fp32 path within
-    the parity tolerance of the CPU oracle, fp16 path by PSNR.  (tools/fuzz_shapes.py runs more.)"""
+    the parity tolerance of the CPU oracle, fp16 path by PSNR.  (tests/fuzz_shapes.py runs more.)"""
     rng = np.random.default_rng(seed)
     bs_tab = W.bsvd_table(seed=21)
     sv_tab = W.srvgg_table(5, num_feat=32, num_conv=3, upscale=2)
@@ -279,7 +279,7 @@ def test_conv_networks_random_shapes(ctx, seed):
 def test_service_random_configurations(ctx):
     """ss4k_upscale_frames on random configurations (batched / per-frame, +-denoise, +-area pre-resize,
     +-bicubic output, x2 / x4, odd frame sizes, first and later job) against the oracle service.
-    tools/fuzz_service.py runs the long version."""
+    tests/fuzz_service.py runs the long version."""
     rng = np.random.default_rng(17)
     bs_tab = W.bsvd_table(seed=21)
     dn = factory.build_denoise_model(ctx, weights=bs_tab, dtype="f32")
