@@ -106,3 +106,64 @@ def test_param_counts():
     assert W.num_params(W.fsrcnn_table(0)) == 12_809
     assert W.num_params(W.srvgg_table(0)) == 1_213_296
     assert W.num_params(W.bsvd_table(0)) == 2_454_583
+
+
+class _ModuleRRDBNet(torch.nn.Module):
+    """A second, independent coding of the published BasicSR RRDBNet as an ``nn.Module`` whose
+    ``state_dict`` uses the upstream key names (``body.{i}.rdb{j}.conv{k}``, ``conv_first`` ...), i.e.
+    what a real RealESRGAN checkpoint loads into.  Cannot pin the oracle to the reference (BasicSR is
+    not in the image) but catches a slip in either coding and in the key map."""
+
+    class RDB(torch.nn.Module):
+        def __init__(self, nf, gc):
+            super().__init__()
+            for k in range(1, 6):
+                setattr(self, f"conv{k}", torch.nn.Conv2d(nf + (k - 1) * gc, gc if k < 5 else nf, 3, 1, 1))
+
+        def forward(self, x):
+            feats = [x]
+            for k in range(1, 5):
+                feats.append(torch.nn.functional.leaky_relu(getattr(self, f"conv{k}")(torch.cat(feats, 1)), 0.2))
+            return self.conv5(torch.cat(feats, 1)) * 0.2 + x
+
+    class RRDB(torch.nn.Module):
+        def __init__(self, nf, gc):
+            super().__init__()
+            self.rdb1, self.rdb2, self.rdb3 = (_ModuleRRDBNet.RDB(nf, gc) for _ in range(3))
+
+        def forward(self, x):
+            return self.rdb3(self.rdb2(self.rdb1(x))) * 0.2 + x
+
+    def __init__(self, scale, num_block, nf=64, gc=32):
+        super().__init__()
+        self.scale = scale
+        self.conv_first = torch.nn.Conv2d(3 * {1: 16, 2: 4, 4: 1}[scale], nf, 3, 1, 1)
+        self.body = torch.nn.Sequential(*[self.RRDB(nf, gc) for _ in range(num_block)])
+        for name in ("conv_body", "conv_up1", "conv_up2", "conv_hr"):
+            setattr(self, name, torch.nn.Conv2d(nf, nf, 3, 1, 1))
+        self.conv_last = torch.nn.Conv2d(nf, 3, 3, 1, 1)
+
+    def forward(self, x):
+        F_ = torch.nn.functional
+        if self.scale != 4:
+            x = F_.pixel_unshuffle(x, 2 if self.scale == 2 else 4)
+        feat = self.conv_first(x)
+        feat = feat + self.conv_body(self.body(feat))
+        feat = F_.leaky_relu(self.conv_up1(F_.interpolate(feat, scale_factor=2, mode="nearest")), 0.2)
+        feat = F_.leaky_relu(self.conv_up2(F_.interpolate(feat, scale_factor=2, mode="nearest")), 0.2)
+        return self.conv_last(F_.leaky_relu(self.conv_hr(feat), 0.2))
+
+
+@pytest.mark.parametrize("scale", [1, 2, 4])
+def test_rrdbnet_functional_oracle_matches_module_form(scale):
+    table = W.rrdbnet_table(31 + scale, scale=scale, num_block=2)
+    net = _ModuleRRDBNet(scale, 2).eval()
+    missing = net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in table.items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert list(net.state_dict().keys()) == W.rrdbnet_keys(2)  # upstream key order = flat blob order
+    x = torch.rand(1, 3, 16, 24)
+    with torch.no_grad():
+        a, b = net(x), onets.rrdbnet(x, table, scale, 2)
+    assert a.shape == b.shape == (1, 3, 16 * scale, 24 * scale)
+    assert torch.allclose(a, b, rtol=0, atol=1e-6)
+
