@@ -7,9 +7,12 @@ Default workload (BASELINE.json configs[2], the one the >=24 fps target is quote
 RealESRGAN RRDBNet x2 (23 blocks), fp16 storage / fp32 accumulate.  Other BASELINE configs via
 --workload {fsrcnn,rrdbnet,pipeline,srvgg}.
 
-Multi-GPU (launched by torchrun, one rank per GPU): frames are sharded one-per-GPU with no
-data-path collective (weak scaling: every rank runs the same per-GPU batch); the weight blob is
-broadcast once from rank 0 over RCCL.  Prints ONE JSON line on rank 0.
+Multi-GPU: one rank per GPU, frames sharded one-per-GPU with no data-path collective (weak scaling:
+every rank runs the same per-GPU batch); the weight blob is broadcast once from rank 0 over RCCL.
+Launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (ranks read
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or directly as ``python bench.py
+--gpus N``: with WORLD_SIZE unset the parent starts the N ranks itself as fresh child processes
+BEFORE it touches any GPU, waits for them and relays rank 0's JSON line.  Prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -30,6 +33,8 @@ from sharkshark4k_amd.upscale import model as factory  # noqa: E402
 
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16
 F32_VECTOR_PEAK_TFLOPS = 157.3
+PMC_TRAFFIC_FILE = "r01j_conv3x3_pmc_traffic.json"  # refreshed whenever the conv kernel changes (tools/pmc_traffic.py)
+CONV_KERNEL_NAME = "ss4k::conv3x3_kernel<__half,NB> (implicit-GEMM 3x3 conv, v_mfma_f32_32x32x16_f16)"
 
 WORKLOADS = {
     "rrdbnet": "RealESRGAN RRDBNet x2 (23 blocks) 720p->1440p fp16 [BASELINE configs[2]]",
@@ -125,10 +130,112 @@ def cpu_baseline(workload, gpu_ctx, seconds_budget=14.0):
     got = up(frames.cuda()).cpu()
     mse = torch.mean((got.double() - want.double()) ** 2).item()
     psnr = float("inf") if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+    ncpu, cpu_model = host_cpu()
     return {"value": frac / sec, "unit": "frames/s (720p-frame equivalents)", "cores": torch.get_num_threads(),
-            "kind": "port",
+            "host_cpu_count": ncpu, "host_cpu_model": cpu_model, "kind": "port",
             "sample": f"oracle (PyTorch CPU fp32, {torch.get_num_threads()} threads) on one {crop[0]}x{crop[1]} frame crop "
                       f"= {frac:.4f} of a 720p frame: {sec:.2f} s"}, psnr
+
+
+def spawn_ranks(n, argv):
+    """``python bench.py --gpus N`` without a launcher: start N fresh ranks (one per GPU) from a parent
+    that has not initialised the GPU (no HIP call, no ``torch.cuda.is_available()``), relay rank 0's
+    stdout and return the worst exit code.  Never re-execs a process that touched the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    chunks = []  # rank 0's stdout is drained while it runs (a full pipe would block it)
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc, alive = 0, set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0:
+                rc = rc or code
+                print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+        if rc and alive:  # one rank failed: the others would wait for it in the rendezvous / barrier
+            time.sleep(2.0)
+            for r in alive:
+                if procs[r].poll() is None:
+                    procs[r].kill()  # exactly the PIDs started above
+        time.sleep(0.05)
+    reader.join(timeout=30)
+    sys.stdout.write(b"".join(chunks).decode())
+    sys.stdout.flush()
+    return rc
+
+
+def run_timed(step, steps, warmup, world, sync, device):
+    """The timing contract: W untimed steps, then exactly K steps bracketed by device sync + barrier on
+    both sides; the reported time is the MAX over ranks (one all_reduce of a scalar, outside the timed
+    region).  ``sync`` is ``torch.cuda.synchronize`` on the GPU, a no-op in the CPU (gloo) test."""
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+    for _ in range(warmup):
+        step()
+    sync(); barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync(); barrier(); sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def world_seen(world_env):
+    """Ranks the process group really has (what ``n_gpus`` reports), checked against the launcher's claim."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        seen = torch.distributed.get_world_size()
+        assert seen == world_env, f"process group has {seen} ranks, WORLD_SIZE says {world_env}"
+        return seen
+    return 1
+
+
+def conv_roofline(ctx, up, frames, out, psteps=3):
+    """Dominant kernel timed live with HIP events on the launch stream (untimed extra steps)."""
+    ctx.prof_reset(); ctx.prof_enable(True)
+    for _ in range(psteps):
+        up(frames, out)
+    torch.cuda.synchronize()
+    launches, ms, flops = ctx.prof_read()
+    ctx.prof_enable(False)
+    if launches <= 0 or ms <= 0:
+        return None
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"achieved": ach, "frac": ach / MFMA_F16_DENSE_PEAK_TFLOPS, "launches_per_step": launches / psteps,
+            "avg_launch_us": 1000.0 * ms / launches, "algorithmic_gflop_per_launch": flops / launches / 1e9,
+            "conv_ms_per_step": ms / psteps}
+
+
+def host_cpu():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return os.cpu_count() or 1, model
 
 
 def main():
@@ -145,9 +252,15 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the short secondary-workload measurements")
     args = ap.parse_args()
 
-    rank, world, local = sharding.init_distributed()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: this process becomes the parent of N fresh ranks and never touches a GPU itself
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    rank, world_env, local = sharding.init_distributed()
+    assert world_env == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch one rank per GPU"
+    assert torch.cuda.is_available(), f"rank {rank}: bench.py needs a GPU (no CPU fallback exists)"
+    assert local < torch.cuda.device_count(), f"rank {rank}: no GPU {local} on this node ({torch.cuda.device_count()} visible)"
+    world = world_seen(world_env)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     ctx = _capi.Context(local)
@@ -159,22 +272,7 @@ def main():
     oh, ow = up.out_shape(args.batch, *in_shape)
     out = torch.empty((args.batch, oh, ow, 3), dtype=torch.uint8, device=device)
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-
-    for _ in range(args.warmup):
-        up(frames, out)
-    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        up(frames, out)
-    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = run_timed(lambda: up(frames, out), args.steps, args.warmup, world, torch.cuda.synchronize, device)
     total_frames = args.batch * args.steps * world
     fps = total_frames / elapsed
 
@@ -191,64 +289,71 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
-        # dominant kernel, timed live with HIP events on the launch stream (untimed extra steps)
-        ctx.prof_reset(); ctx.prof_enable(True)
-        psteps = 3
-        for _ in range(psteps):
-            up(frames, out)
-        torch.cuda.synchronize()
-        launches, ms, flops = ctx.prof_read()
-        ctx.prof_enable(False)
-        if launches > 0 and ms > 0:
-            ach = flops / (ms * 1e-3) / 1e12
+        rl = conv_roofline(ctx, up, frames, out)
+        if rl is not None:
             traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01j_conv3x3_pmc_traffic.json")
-            if args.workload == "rrdbnet" and os.path.exists(pmc):
+            pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
+            if args.workload == "rrdbnet" and args.batch == 4 and os.path.exists(pmc):
                 # HBM-side bytes per launch cannot be read from inside the process: they come from the
                 # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
                 with open(pmc) as f:
                     pj = json.load(f)
-                traffic, traffic_src = pj["traffic_bytes_per_launch"], "profiles/r01j_conv3x3_pmc_traffic.json (" + pj["correction"] + ")"
-            result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": ach / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": traffic,
+                traffic, traffic_src = pj["traffic_bytes_per_launch"], f"profiles/{PMC_TRAFFIC_FILE} (" + pj["correction"] + ")"
+            result["roofline"] = {"bound": "mfma", "achieved": rl["achieved"], "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": rl["frac"], "traffic": traffic,
                                   "traffic_unit": "bytes per launch (L2<->fabric, PMC)", "traffic_source": traffic_src,
-                                  "kernel": "ss4k::conv3x3_kernel<__half,NB> (implicit-GEMM 3x3 conv, v_mfma_f32_32x32x16_f16)",
-                                  "launches_per_step": launches / psteps, "frames_per_launch": args.batch,
-                                  "avg_launch_us": 1000.0 * ms / launches,
-                                  "algorithmic_gflop_per_launch": flops / launches / 1e9,
-                                  "kernel_time_share_of_step": (ms / psteps) / (1000.0 * elapsed / args.steps)}
+                                  "kernel": CONV_KERNEL_NAME,
+                                  "launches_per_step": rl["launches_per_step"], "frames_per_launch": args.batch,
+                                  "avg_launch_us": rl["avg_launch_us"],
+                                  "algorithmic_gflop_per_launch": rl["algorithmic_gflop_per_launch"],
+                                  "kernel_time_share_of_step": rl["conv_ms_per_step"] / (1000.0 * elapsed / args.steps)}
         elif args.workload == "fsrcnn":
             ach = flops_per_frame * fps / world / 1e12
             result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": F32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": ach / F32_VECTOR_PEAK_TFLOPS, "traffic": None,
-                                  "kernel": "fsrcnn kernels, whole-step average (head/map on the fp32 vector ALUs, fused expand+deconv on exact-fp32 MFMA: both peak at 157.3)"}
-    if rank == 0 and not args.no_also and args.workload == "rrdbnet":
-        # the other single-GPU BASELINE configs, measured the same way (short, outside the headline timing)
+                                  "kernel": "fsrcnn kernels, whole-step average (exact-fp32 MFMA and fp32 vector ALUs: both peak at 157.3)"}
+    if rank == 0 and world == 1 and not args.no_also and args.workload == "rrdbnet":
+        # the other single-GPU BASELINE configs and the 1-frame (image-server / latency) job, measured the
+        # same way (short, outside the headline timing); conv-based ones carry their own roofline fraction
         also = {}
-        for wl in ("fsrcnn", "pipeline", "srvgg"):
-            up2, keep2, _ = build_upscaler(ctx, wl, device) if world == 1 else (None, None, None)
-            if up2 is None:
-                break
-            nb = frames.shape[0]  # the same job size as the headline
-            o2h, o2w = up2.out_shape(nb, 720, 1280)
+        for name, wl, nb, shape, reps in (("fsrcnn", "fsrcnn", args.batch, (720, 1280), 10),
+                                          ("pipeline", "pipeline", args.batch, (720, 1280), 10),
+                                          ("srvgg", "srvgg", args.batch, (720, 1280), 10),
+                                          ("rrdbnet_n1", "rrdbnet", 1, (720, 1280), 20),
+                                          ("rrdbnet_x4", "rrdbnet_x4", 1, (1080, 1920), 5)):
+            up2, keep2, fpf = (up, keep, flops_per_frame) if name == "rrdbnet_n1" else build_upscaler(ctx, wl, device, lr_shape=shape)
+            fr2 = frames[:nb] if shape == in_shape else synthetic_frames(nb, shape, seed=77).to(device)
+            o2h, o2w = up2.out_shape(nb, *shape)
             out2 = torch.empty((nb, o2h, o2w, 3), dtype=torch.uint8, device=device)
             for _ in range(3):
-                up2(frames, out2)
+                up2(fr2, out2)
             torch.cuda.synchronize(); t1 = time.perf_counter()
-            for _ in range(10):
-                up2(frames, out2)
+            for _ in range(reps):
+                up2(fr2, out2)
             torch.cuda.synchronize()
-            also[wl] = {"workload": WORKLOADS[wl], "frames_per_step": nb, "fps": 10 * nb / (time.perf_counter() - t1)}
-            del up2, keep2
+            dt = time.perf_counter() - t1
+            also[name] = {"workload": WORKLOADS[wl], "frames_per_step": nb, "fps": reps * nb / dt,
+                          "net_tflops": fpf * reps * nb / dt / 1e12}
+            if wl != "fsrcnn":
+                rl = conv_roofline(ctx, up2, fr2, out2, psteps=2)
+                if rl is not None:
+                    also[name]["conv_tflops"] = rl["achieved"]; also[name]["conv_frac_of_peak"] = rl["frac"]
+                    also[name]["conv_launches_per_step"] = rl["launches_per_step"]
+            else:
+                also[name]["frac_of_fp32_peak"] = also[name]["net_tflops"] / F32_VECTOR_PEAK_TFLOPS
+            del out2, fr2
+            if name != "rrdbnet_n1":
+                del up2, keep2
+            torch.cuda.empty_cache()
         result["also"] = also
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, psnr = cpu_baseline(args.workload, ctx)
         result["cpu_baseline"] = cb
         result["psnr_db_vs_cpu_ref"] = psnr
     if world > 1:
-        barrier()
+        torch.distributed.barrier()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

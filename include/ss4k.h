@@ -12,6 +12,12 @@
  *     stream) with no hidden synchronisation, like the reference's eager torch calls.
  *   - one ss4k_ctx per device; a ctx and its children are not thread-safe (the reference's
  *     worker is a single-threaded process loop, base_service.py:33-60).
+ *   - a ctx and everything created from it (models, upscalers) is SINGLE-STREAM: a model reuses its
+ *     activation workspace and an upscaler its staging buffers on every call, and the granular
+ *     ss4k_op_* calls share small per-context scratch.  Calls that touch the same ctx must be
+ *     enqueued on one stream (or be serialised by the caller with events); two services that
+ *     should overlap on one GPU take one ctx each.  Matches the reference (one worker process,
+ *     default stream, fsrcnn_upscaler.py:118-166).
  *   - there is no CPU fallback: without a HIP device ss4k_ctx_create fails.
  */
 #ifndef SS4K_H
@@ -87,13 +93,13 @@ int ss4k_model_out_shape(const ss4k_model* m, int n, int h, int w, int* out_c, i
 /* Input channel count the model expects (FSRCNN 1, RRDBNet/SRVGG 3, BSVD 4). */
 int ss4k_model_in_channels(const ss4k_model* m);
 
-/* Replaces `self.model(x)` (fsrcnn_upscaler.py:181,293-297) and `self.denoise_model(x)`
- * (:277): x is contiguous NCHW fp32 in [0,1] on the device; result contiguous NCHW fp32.
- * BSVD: in (n,4,h,w) = the reference's (n,1,4,h,w); out (n,3,h,w).  FSRCNN: (planes,1,h,w). */
 /* Device bytes of activation workspace the model holds after a forward of n frames of h x w (it grows
  * to the largest shape seen and is reused); nothing is allocated or launched by this call.  The
  * size query of SURVEY.md 8(b) (`ss4k_workspace_bytes`). */
 int ss4k_model_workspace_bytes(ss4k_model* m, int n, int h, int w, size_t* bytes);
+/* Replaces `self.model(x)` (fsrcnn_upscaler.py:181,293-297) and `self.denoise_model(x)`
+ * (:277): x is contiguous NCHW fp32 in [0,1] on the device; result contiguous NCHW fp32.
+ * BSVD: in (n,4,h,w) = the reference's (n,1,4,h,w); out (n,3,h,w).  FSRCNN: (planes,1,h,w). */
 int ss4k_model_forward(ss4k_model* m, const float* in_nchw_dev, float* out_nchw_dev, int n, int h,
                        int w, void* hip_stream);
 
@@ -165,11 +171,6 @@ int ss4k_op_f32nchw_to_u8nhwc(ss4k_ctx* ctx, const float* in_dev, uint8_t* out_d
 /* ---- measurement hooks (bench.py: live per-kernel timing with HIP events on the launch stream) */
 /* When enabled, every launch of the dominant conv kernel is bracketed with hipEvents on the
  * stream it is launched on; ss4k_prof_read returns (#launches, total ms, algorithmic FLOPs). */
-/* Times ONE 3x3 conv layer (cin0 [+ cin1 concat] -> cout, LeakyReLU) in isolation on synthetic data:
- * avg microseconds per launch over `iters` launches.  flags = ablation bits (1 no store, 2 no MFMA,
- * 4 no activation DMA, 8 no weight DMA, 16 no epilogue); 0 = the production kernel. */
-int ss4k_bench_conv(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, int n, int h, int w, int flags,
-                    int iters, double* avg_us, void* hip_stream);
 int ss4k_prof_enable(ss4k_ctx* ctx, int enable);
 int ss4k_prof_reset(ss4k_ctx* ctx);
 int ss4k_prof_read(ss4k_ctx* ctx, int64_t* launches, double* total_ms, double* flops);

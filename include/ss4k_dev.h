@@ -1,0 +1,28 @@
+/*
+ * ss4k_dev.h - measurement-only entry points of libss4k_hip_dev.so (built with -DSS4K_DEV from the
+ * same sources as libss4k_hip.so; a superset of include/ss4k.h).  Not part of the product library:
+ * the instrumented / alternative-tile-shape instantiations of the conv kernel live only here.
+ * Used by tools/stamp4.py, tools/traffic_ablate.py, tools/conv_sweep.py.
+ */
+#ifndef SS4K_DEV_H
+#define SS4K_DEV_H
+#include "ss4k.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Times ONE 3x3 conv layer (cin0 [+ cin1 concat] -> cout) in isolation on random operands: average
+ * microseconds per launch over `iters` launches.
+ * flags: 0 = the production kernel for that shape;
+ *        32 (DBG_STAMP) = phase stamps (s_memtime per phase, printed to stderr), optionally combined with
+ *        the timing-only ablations 1 (no output stores), 2 (every DMA reads one hot line), 16 (with 1:
+ *        halo tiles from a 2 MB L2-resident window) - results are garbage in those builds;
+ *        | shape_id << 8 selects another compiled tile shape (conv_mfma.hip, launch_conv3x3);
+ *        | 2048 makes it conv5 of an RDB (no activation, out = conv * 0.2 + x). */
+int ss4k_bench_conv(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, int n, int h, int w, int flags,
+                    int iters, double* avg_us, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SS4K_DEV_H */

@@ -27,8 +27,9 @@ SYMBOLS = [
     "ss4k_upscaler_reset", "ss4k_upscaler_out_shape", "ss4k_upscaler_last_enqueue_ms", "ss4k_model_workspace_bytes", "ss4k_upscale_frames", "ss4k_upscaler_enable_taps",
     "ss4k_upscaler_read_tap", "ss4k_op_u8nhwc_to_f32nchw", "ss4k_op_area_resize", "ss4k_op_bicubic_resize",
     "ss4k_op_bilinear_resize", "ss4k_op_depthwise_reflect", "ss4k_op_plane_stats", "ss4k_op_f32nchw_to_u8nhwc",
-    "ss4k_prof_enable", "ss4k_prof_reset", "ss4k_prof_read", "ss4k_bench_conv",
+    "ss4k_prof_enable", "ss4k_prof_reset", "ss4k_prof_read",
 ]
+DEV_SYMBOLS = ["ss4k_bench_conv"]  # include/ss4k_dev.h: libss4k_hip_dev.so only (SS4K_LIB=.../libss4k_hip_dev.so)
 
 
 class ModelDesc(C.Structure):
@@ -86,7 +87,8 @@ def lib() -> C.CDLL:
     L.ss4k_op_depthwise_reflect.argtypes = [vp, vp, vp, i, i, i, vp, i, vp]
     L.ss4k_op_plane_stats.argtypes = [vp, vp, vp, i, i, vp]
     L.ss4k_op_f32nchw_to_u8nhwc.argtypes = [vp, vp, vp, i, i, i, i, vp]
-    L.ss4k_bench_conv.argtypes = [vp, i, i, i, i, i, i, i, i, i, C.POINTER(C.c_double), vp]
+    if hasattr(L, "ss4k_bench_conv"):  # dev library only
+        L.ss4k_bench_conv.argtypes = [vp, i, i, i, i, i, i, i, i, i, C.POINTER(C.c_double), vp]
     L.ss4k_prof_enable.argtypes = [vp, i]
     L.ss4k_prof_reset.argtypes = [vp]
     L.ss4k_prof_read.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -142,6 +144,8 @@ class Context:
         return n.value, ms.value, fl.value
 
     def bench_conv(self, dtype, cin0, cin1, cout, n, h, w, flags=0, iters=20) -> float:
+        if not hasattr(lib(), "ss4k_bench_conv"):
+            raise Ss4kError("ss4k_bench_conv lives in libss4k_hip_dev.so: run with SS4K_LIB=<package>/libss4k_hip_dev.so")
         us = C.c_double()
         _check(lib().ss4k_bench_conv(self._h, dtype, cin0, cin1, cout, n, h, w, flags, iters, C.byref(us), _stream()))
         return us.value

@@ -1,4 +1,8 @@
-"""Build libss4k_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build()."""
+"""Build libss4k_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build().
+
+``build(dev=True)`` builds libss4k_hip_dev.so from the same sources with -DSS4K_DEV: the product ABI plus
+``ss4k_bench_conv`` (include/ss4k_dev.h) and the instrumented / alternative-shape instantiations of the
+conv kernel that the measurement tools use.  The product library carries none of that."""
 from __future__ import annotations
 
 import os
@@ -9,6 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libss4k_hip.so")
+LIB_DEV = os.path.join(HERE, "libss4k_hip_dev.so")
 SOURCES = ["conv_mfma.hip", "glue.hip", "fsrcnn.hip", "pack.cpp", "models.cpp", "api.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-x", "hip", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable"]
@@ -25,13 +30,16 @@ def _needs_build(obj: str, src: str) -> bool:
     if not os.path.exists(obj):
         return True
     newest = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
-    newest = max(newest, os.path.getmtime(src), os.path.getmtime(os.path.join(HERE, "..", "include", "ss4k.h")))
+    newest = max(newest, os.path.getmtime(src), os.path.getmtime(os.path.join(HERE, "..", "include", "ss4k.h")),
+                 os.path.getmtime(os.path.join(HERE, "..", "include", "ss4k_dev.h")))
     return os.path.getmtime(obj) < newest
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
     hipcc = _hipcc()
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, "build_dev" if dev else "build")
+    lib = LIB_DEV if dev else LIB
+    flags = FLAGS + (["-DSS4K_DEV"] if dev else [])
     os.makedirs(objdir, exist_ok=True)
     jobs = []
     for s in SOURCES:
@@ -42,7 +50,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def run(job):
         src, obj = job
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *flags, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -54,15 +62,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(objdir, os.path.splitext(s)[0] + ".o") for s in SOURCES]
-    if jobs or not os.path.exists(LIB):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", LIB]
+    if jobs or not os.path.exists(lib):
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", lib]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, dev="--dev" in sys.argv))

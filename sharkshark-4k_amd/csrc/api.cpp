@@ -48,7 +48,7 @@ static std::vector<float> sharpen_taps(double strength) {  // sharpen_ker, fsrcn
 struct Upscaler {
   ss4k_ctx* ctx; ss4k_upscale_cfg cfg; Model* sr; Model* dn;
   DevBuf k_blur17, k_sharp, k_sharp_hr;
-  DevBuf img, lr, lr4, den, hr, hr2, lb, hb, lbb, hbb, st_hr, st_lr;
+  DevBuf img, lr, lr4, den, hr, hr2, lb, hb, lbb, hbb, st_hr, st_lr, st_acc;
   bool first_frame = true;
   bool taps_on = false;
   // host time spent enqueueing the last job's denoise / SR model stages: what the reference's
@@ -94,13 +94,18 @@ struct Upscaler {
     enq_model_ms = now_ms() - tm0; enq_denoise_ms = 0;
     save_tap(0, lrp, n, 3, lh, lw, st); save_tap(1, hrp, n, 3, H, W, st);
     st_hr.ensure(P * 8); st_lr.ensure(P * 8);
-    op_plane_stats(ctx, hrp, st_hr.as<float>(), P, H * W, st);
-    op_plane_stats(ctx, lrp, st_lr.as<float>(), P, lh * lw, st);
+    SS4K_REQUIRE(P <= STATS_MAX_PLANES, "too many frames in one job");
+    st_acc.ensure(sizeof(double) * 2 * P);
+    op_plane_stats(st_acc.as<double>(), hrp, st_hr.as<float>(), P, H * W, st);
+    op_plane_stats(st_acc.as<double>(), lrp, st_lr.as<float>(), P, lh * lw, st);
     op_normalize(hrp, st_hr.as<float>(), st_lr.as<float>(), P, H * W, st);
     save_tap(2, hrp, n, 3, H, W, st);
     const int mh = H / 8, mw = W / 8;
     bool clamped = false;
     if (mh > 8 && H > 64 && W > 64) {  // local colour match, :201-218
+      // the reference's guard looks at the height only; for HR widths of 65..71 its 17-tap reflect pad (8)
+      // reaches the 8-pixel-wide map and torch raises - so does this build
+      SS4K_REQUIRE(mw > 8, "local colour match: HR width / 8 must exceed the 17-tap blur's reflect padding (torch raises here too)");
       const size_t sm = (size_t)P * mh * mw * 4;
       lb.ensure(sm); hb.ensure(sm); lbb.ensure(sm); hbb.ensure(sm);
       op_area(lrp, lb.as<float>(), P, lh, lw, mh, mw, st);
@@ -172,8 +177,10 @@ struct Upscaler {
     }
     save_tap(1, hrp, n, 3, H, W, st);
     st_hr.ensure(P * 8); st_lr.ensure(P * 8);
-    op_plane_stats(ctx, hrp, st_hr.as<float>(), P, H * W, st);
-    op_plane_stats(ctx, lr_before, st_lr.as<float>(), P, lh * lw, st);
+    SS4K_REQUIRE(P <= STATS_MAX_PLANES, "too many frames in one job");
+    st_acc.ensure(sizeof(double) * 2 * P);
+    op_plane_stats(st_acc.as<double>(), hrp, st_hr.as<float>(), P, H * W, st);
+    op_plane_stats(st_acc.as<double>(), lr_before, st_lr.as<float>(), P, lh * lw, st);
     op_normalize(hrp, st_hr.as<float>(), st_lr.as<float>(), P, H * W, st);
     save_tap(2, hrp, n, 3, H, W, st);
     op_clamp01(hrp, (size_t)P * H * W, st);
@@ -285,7 +292,7 @@ void ss4k_upscaler_destroy(ss4k_upscaler* up) {
   if (!up) return;
   Upscaler& u = up->u;
   for (DevBuf* b : {&u.k_blur17, &u.k_sharp, &u.k_sharp_hr, &u.img, &u.lr, &u.lr4, &u.den, &u.hr, &u.hr2, &u.lb, &u.hb,
-                    &u.lbb, &u.hbb, &u.st_hr, &u.st_lr})
+                    &u.lbb, &u.hbb, &u.st_hr, &u.st_lr, &u.st_acc})
     b->release();
   for (auto& t : u.tap) t.release();
   delete up;
@@ -347,7 +354,6 @@ int ss4k_op_depthwise_reflect(ss4k_ctx* c, const float* in, float* out, int p, i
   return guard([&] {
     SS4K_REQUIRE(c && in && out && k2d, "NULL argument");
     SS4K_REQUIRE(k >= 1 && k <= 17 && (k & 1), "kernel size must be odd and <= 17");
-    SS4K_REQUIRE(h > k / 2 && w > k / 2, "reflect padding needs pad < size");
     float* taps = c->buf("dw_taps", 17 * 17 * 4).as<float>();
     SS4K_HIP(hipMemcpyAsync(taps, k2d, (size_t)k * k * 4, hipMemcpyHostToDevice, (hipStream_t)s));
     op_depthwise_reflect(in, out, taps, p, h, w, k, 0, nullptr, 0, 0, (hipStream_t)s);
@@ -355,12 +361,16 @@ int ss4k_op_depthwise_reflect(ss4k_ctx* c, const float* in, float* out, int p, i
   });
 }
 int ss4k_op_plane_stats(ss4k_ctx* c, const float* in, float* stats, int p, int hw, void* s) {
-  return guard([&] { SS4K_REQUIRE(c && in && stats, "NULL argument"); op_plane_stats(c, in, stats, p, hw, (hipStream_t)s); SS4K_HIP(hipGetLastError()); });
+  return guard([&] {
+    SS4K_REQUIRE(c && in && stats, "NULL argument");
+    op_plane_stats(c->buf("stats_acc", sizeof(double) * 2 * STATS_MAX_PLANES).as<double>(), in, stats, p, hw, (hipStream_t)s);
+  });
 }
 int ss4k_op_f32nchw_to_u8nhwc(ss4k_ctx* c, const float* in, uint8_t* out, int n, int ch, int h, int w, void* s) {
   return guard([&] { SS4K_REQUIRE(c && in && out, "NULL argument"); op_f32nchw_to_u8nhwc(in, out, n, ch, h, w, (hipStream_t)s); SS4K_HIP(hipGetLastError()); });
 }
 
+#ifdef SS4K_DEV
 int ss4k_bench_conv(ss4k_ctx* c, int dtype, int cin0, int cin1, int cout, int n, int h, int w, int flags, int iters,
                     double* avg_us, void* stream) {
   return guard([&] {
@@ -368,6 +378,7 @@ int ss4k_bench_conv(ss4k_ctx* c, int dtype, int cin0, int cin1, int cout, int n,
     *avg_us = bench_conv_layer(c, dtype, cin0, cin1, cout, n, h, w, flags, iters, (hipStream_t)stream);
   });
 }
+#endif  // SS4K_DEV
 
 // ---- profiling hooks --------------------------------------------------------------------------
 static void prof_collect(ss4k_ctx* c) {

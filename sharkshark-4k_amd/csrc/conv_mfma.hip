@@ -44,12 +44,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int TW = 32, IN_W = TW + 2;
 constexpr uint32_t OOB = 0xFFFFFFFFu;
-// Tile geometry for MB output rows per wave (4 waves): MB = 4 -> 16x32 tile, one workgroup per CU
-// (115/153 KB LDS); MB = 2 -> 8x32 tile, 80 KB LDS so TWO workgroups share a CU and one's epilogue /
-// barrier / DMA-wait time is covered by the other's MFMAs (used for the 32-cout layers).
-// NW waves per workgroup: 8 waves (two per SIMD inside ONE workgroup) are used for the 64-cout build,
-// whose LDS footprint allows only one workgroup per CU: the second wave of a SIMD fills the first
-// one's LDS-latency / DMA-issue bubbles and halves each wave's share of the epilogue.
+// Tile geometry: NW waves x MB output rows per wave x 32 pixels.  Production fp16 builds are
+// <NB=1,MB=4,NW=4> (32-cout layers, 58 KB LDS) and <NB=2,MB=4,NW=4> (64-cout layers, 76 KB LDS): a 16x32
+// pixel tile at TWO workgroups per CU, so one workgroup's epilogue / barrier / DMA wait is covered by the
+// other's MFMAs.  The other shapes (MB = 2: 8-row tiles at three workgroups per CU; NW = 8: 32-row
+// tiles, one workgroup per CU) are compiled only into the dev library (SS4K_DEV, ss4k_bench_conv).
 template <typename T> struct Tr;
 // E elements per 16-byte slot; a 16-channel record is SPR slots; one MFMA k-step eats two of them
 // (one per half-wave), so a K-chunk is KS k-steps per tap column
@@ -755,6 +754,7 @@ static void launch_t(ss4k_ctx* ctx, const ConvArgs& a0, int groups, hipStream_t 
   SS4K_HIP(hipGetLastError());
 }
 
+#ifdef SS4K_DEV
 // ss4k_bench_conv only: instrumented (phase stamps) and alternative tile shapes of the fp16 kernel
 template <int NB, int MB, int NW>
 static void launch_dbg(ss4k_ctx* ctx, const ConvArgs& a, int groups, hipStream_t st) {
@@ -774,6 +774,8 @@ static void launch_dbg(ss4k_ctx* ctx, const ConvArgs& a, int groups, hipStream_t
   }
 }
 
+#endif  // SS4K_DEV
+
 void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st) {
   ConvArgs a = a0;
   a.tiles_x = (a.W + TW - 1) / TW;
@@ -791,6 +793,7 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
     SS4K_HIP(hipEventRecord(pe.a, st));
   }
   // fp16 tile shapes <couts/32, rows per wave, waves>; see DESIGN.md 4.1 for how they were chosen
+#ifdef SS4K_DEV
   if (a.dbg) {
     SS4K_REQUIRE(dtype == SS4K_F16, "instrumented builds exist for fp16 only");
     const int shape = (a.dbg >> 8) & 7;
@@ -809,7 +812,10 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
         default: launch_dbg<2, 2, 8>(ctx, a, groups, st); break;
       }
     }
-  } else {
+  } else
+#endif
+  {
+    SS4K_REQUIRE(a.dbg == 0, "instrumented conv builds live in libss4k_hip_dev.so only");
     const bool gen = !(a.epi == EPI_NHWC && !a.bsvd_resid);
     if (dtype == SS4K_F16) {
       if (nb == 1) { if (gen) launch_t<__half, 1, 4, 4, 0, true>(ctx, a, groups, st); else launch_t<__half, 1, 4, 4, 0, false>(ctx, a, groups, st); }

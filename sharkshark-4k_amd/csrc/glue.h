@@ -6,7 +6,10 @@ namespace ss4k {
 
 void op_u8nhwc_to_f32nchw(const uint8_t* in, float* out, int n, int h, int w, int c, hipStream_t st);
 void op_area(const float* in, float* out, int planes, int h, int w, int oh, int ow, hipStream_t st);
-void op_plane_stats(ss4k_ctx* ctx, const float* in, float* stats, int planes, int hw, hipStream_t st);
+// acc: 2 * planes doubles of scratch owned by the caller (each upscaler owns its own, so two upscalers
+// of one context never share partial sums), planes <= STATS_MAX_PLANES
+constexpr int STATS_MAX_PLANES = 4096;
+void op_plane_stats(double* acc, const float* in, float* stats, int planes, int hw, hipStream_t st);
 void op_normalize(float* x, const float* st_hr, const float* st_lr, int planes, int hw, hipStream_t st);
 void op_depthwise_reflect(const float* in, float* out, const float* taps_dev, int planes, int h, int w, int k,
                           int clamp01, const float* blend_src, float blend_a, float blend_b, hipStream_t st);

@@ -7,6 +7,9 @@
 
 namespace ss4k {
 
+// every launcher checks its launch: a bad grid surfaces here, not at the next synchronisation
+#define SS4K_LAUNCH_OK() SS4K_HIP(hipGetLastError())
+
 static inline dim3 grid1d(size_t n, int block = 256) {
   size_t g = (n + block - 1) / block;
   if (g > 256 * 8 * 4) g = 256 * 8 * 4;  // grid-stride beyond a few waves per CU
@@ -24,7 +27,7 @@ __global__ void k_u8nhwc_to_f32nchw(const uint8_t* __restrict__ in, float* __res
 }
 void op_u8nhwc_to_f32nchw(const uint8_t* in, float* out, int n, int h, int w, int c, hipStream_t st) {
   const size_t total = (size_t)n * h * w;
-  hipLaunchKernelGGL(k_u8nhwc_to_f32nchw, grid1d(total), dim3(256), 0, st, in, out, n, h, w, c);
+  hipLaunchKernelGGL(k_u8nhwc_to_f32nchw, grid1d(total), dim3(256), 0, st, in, out, n, h, w, c); SS4K_LAUNCH_OK();
 }
 
 // ------------------------------------------------------------------ area (adaptive average pool)
@@ -53,7 +56,7 @@ void op_area(const float* in, float* out, int planes, int h, int w, int oh, int 
     return;
   }
   SS4K_REQUIRE(oh <= 65535 && planes <= 65535, "area: grid limits");
-  hipLaunchKernelGGL(k_area, grid_rows(ow, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow);
+  hipLaunchKernelGGL(k_area, grid_rows(ow, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow); SS4K_LAUNCH_OK();
 }
 
 // ------------------------------------------------------------------ per-plane mean / unbiased std
@@ -87,14 +90,13 @@ __global__ void k_stats_final(const double* __restrict__ acc, float* __restrict_
   stats[2 * p] = (float)mean;
   stats[2 * p + 1] = (float)sqrt(var);
 }
-void op_plane_stats(ss4k_ctx* ctx, const float* in, float* stats, int planes, int hw, hipStream_t st) {
-  double* acc = ctx->buf("stats_acc", sizeof(double) * 2 * 4096).as<double>();
-  SS4K_REQUIRE(planes <= 4096, "plane_stats: too many planes");
+void op_plane_stats(double* acc, const float* in, float* stats, int planes, int hw, hipStream_t st) {
+  SS4K_REQUIRE(planes <= STATS_MAX_PLANES, "plane_stats: too many planes");
   SS4K_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 2 * planes, st));
   int gx = (hw + 256 * 16 - 1) / (256 * 16);
   gx = std::max(1, std::min(gx, 512));
-  hipLaunchKernelGGL(k_stats_partial, dim3(gx, planes), dim3(256), 0, st, in, acc, hw);
-  hipLaunchKernelGGL(k_stats_final, dim3((planes + 63) / 64), dim3(64), 0, st, acc, stats, planes, hw);
+  hipLaunchKernelGGL(k_stats_partial, dim3(gx, planes), dim3(256), 0, st, in, acc, hw); SS4K_LAUNCH_OK();
+  hipLaunchKernelGGL(k_stats_final, dim3((planes + 63) / 64), dim3(64), 0, st, acc, stats, planes, hw); SS4K_LAUNCH_OK();
 }
 
 // hr = (hr - mean_hr) / (std_hr + 1e-8) * std_lr + mean_lr   (fsrcnn_upscaler.py:198-199, :312-313)
@@ -108,7 +110,7 @@ __global__ void k_normalize(float* __restrict__ x, const float* __restrict__ st_
 }
 void op_normalize(float* x, const float* st_hr, const float* st_lr, int planes, int hw, hipStream_t st) {
   int gx = std::max(1, std::min((hw + 255) / 256, 1024));
-  hipLaunchKernelGGL(k_normalize, dim3(gx, planes), dim3(256), 0, st, x, st_hr, st_lr, planes, hw);
+  hipLaunchKernelGGL(k_normalize, dim3(gx, planes), dim3(256), 0, st, x, st_hr, st_lr, planes, hw); SS4K_LAUNCH_OK();
 }
 
 // ------------------------------------------------------------------ depthwise KxK, reflect padding
@@ -142,12 +144,16 @@ void op_depthwise_reflect(const float* in, float* out, const float* taps_dev, in
                           int clamp01, const float* blend_src, float blend_a, float blend_b, hipStream_t st) {
   SS4K_REQUIRE(h <= 65535 && planes <= 65535, "depthwise: grid limits");
   SS4K_REQUIRE(k == 3 || k == 17, "depthwise: kernel size 3 or 17 (the service's sharpen / blur kernels)");
-  if (k == 3)
+  // torch's reflect padding requires pad < size and raises otherwise (fsrcnn_upscaler.py:20-84 kernels)
+  SS4K_REQUIRE(h > k / 2 && w > k / 2, "depthwise reflect: padding (k/2) must be smaller than the plane, as torch requires");
+  if (k == 3) {
     hipLaunchKernelGGL(k_depthwise_reflect<3>, grid_rows(w, h, planes), dim3(256), 0, st, in, out, taps_dev, planes, h, w,
                        clamp01, blend_src, blend_a, blend_b);
-  else
+  } else {
     hipLaunchKernelGGL(k_depthwise_reflect<17>, grid_rows(w, h, planes), dim3(256), 0, st, in, out, taps_dev, planes, h, w,
                        clamp01, blend_src, blend_a, blend_b);
+  }
+  SS4K_LAUNCH_OK();
 }
 
 // ------------------------------------------------------------------ bilinear / bicubic (align_corners=False)
@@ -187,12 +193,14 @@ __global__ void k_bilinear(const float* __restrict__ in, float* __restrict__ out
 void op_bilinear(const float* in, float* out, int planes, int h, int w, int oh, int ow, int subtract_from_out,
                  int clamp01, hipStream_t st) {
   SS4K_REQUIRE(oh <= 65535 && planes <= 65535, "bilinear: grid limits");
-  if (ow % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+  if (ow % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
     hipLaunchKernelGGL(k_bilinear<4>, grid_rows(ow / 4, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow,
                        subtract_from_out, clamp01);
-  else
+  } else {
     hipLaunchKernelGGL(k_bilinear<1>, grid_rows(ow, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow,
                        subtract_from_out, clamp01);
+  }
+  SS4K_LAUNCH_OK();
 }
 
 __device__ __forceinline__ float cc1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
@@ -235,7 +243,7 @@ __global__ void k_bicubic(const float* __restrict__ in, float* __restrict__ out,
 }
 void op_bicubic(const float* in, float* out, int planes, int h, int w, int oh, int ow, int clamp01, hipStream_t st) {
   SS4K_REQUIRE(oh <= 65535 && planes <= 65535, "bicubic: grid limits");
-  hipLaunchKernelGGL(k_bicubic, grid_rows(ow, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow, clamp01);
+  hipLaunchKernelGGL(k_bicubic, grid_rows(ow, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow, clamp01); SS4K_LAUNCH_OK();
 }
 
 // ------------------------------------------------------------------ elementwise helpers
@@ -244,13 +252,13 @@ __global__ void k_sub(const float* __restrict__ a, const float* __restrict__ b, 
     out[i] = a[i] - b[i];
 }
 void op_sub(const float* a, const float* b, float* out, size_t n, hipStream_t st) {
-  hipLaunchKernelGGL(k_sub, grid1d(n), dim3(256), 0, st, a, b, out, n);
+  hipLaunchKernelGGL(k_sub, grid1d(n), dim3(256), 0, st, a, b, out, n); SS4K_LAUNCH_OK();
 }
 __global__ void k_clamp01(float* __restrict__ x, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     x[i] = fminf(fmaxf(x[i], 0.f), 1.f);
 }
-void op_clamp01(float* x, size_t n, hipStream_t st) { hipLaunchKernelGGL(k_clamp01, grid1d(n), dim3(256), 0, st, x, n); }
+void op_clamp01(float* x, size_t n, hipStream_t st) { hipLaunchKernelGGL(k_clamp01, grid1d(n), dim3(256), 0, st, x, n); SS4K_LAUNCH_OK(); }
 
 // (clamp(x,0,1)*255) -> uint8 by truncation, NCHW -> NHWC   (fsrcnn_upscaler.py:232-233, :325-326)
 __global__ void k_f32nchw_to_u8nhwc(const float* __restrict__ in, uint8_t* __restrict__ out, int n, int c, int h,
@@ -266,7 +274,7 @@ __global__ void k_f32nchw_to_u8nhwc(const float* __restrict__ in, uint8_t* __res
   }
 }
 void op_f32nchw_to_u8nhwc(const float* in, uint8_t* out, int n, int c, int h, int w, hipStream_t st) {
-  hipLaunchKernelGGL(k_f32nchw_to_u8nhwc, grid1d((size_t)n * h * w), dim3(256), 0, st, in, out, n, c, h, w);
+  hipLaunchKernelGGL(k_f32nchw_to_u8nhwc, grid1d((size_t)n * h * w), dim3(256), 0, st, in, out, n, c, h, w); SS4K_LAUNCH_OK();
 }
 
 // ------------------------------------------------------------------ network input / output layout converters
@@ -305,10 +313,11 @@ __global__ void k_pack_input(const float* __restrict__ in, T* __restrict__ out, 
 template <typename T>
 void op_pack_input(const float* in, T* out, int n, int c, int h, int w, int r, int nplanes, hipStream_t st) {
   const dim3 g = grid1d((size_t)n * (h / r) * (w / r));
-  if (r == 1) hipLaunchKernelGGL((k_pack_input<T, 1>), g, dim3(256), 0, st, in, out, n, c, h, w, nplanes);
-  else if (r == 2) hipLaunchKernelGGL((k_pack_input<T, 2>), g, dim3(256), 0, st, in, out, n, c, h, w, nplanes);
-  else if (r == 4) hipLaunchKernelGGL((k_pack_input<T, 4>), g, dim3(256), 0, st, in, out, n, c, h, w, nplanes);
+  if (r == 1) { hipLaunchKernelGGL((k_pack_input<T, 1>), g, dim3(256), 0, st, in, out, n, c, h, w, nplanes); }
+  else if (r == 2) { hipLaunchKernelGGL((k_pack_input<T, 2>), g, dim3(256), 0, st, in, out, n, c, h, w, nplanes); }
+  else if (r == 4) { hipLaunchKernelGGL((k_pack_input<T, 4>), g, dim3(256), 0, st, in, out, n, c, h, w, nplanes); }
   else throw Error(SS4K_EINVAL, "pack_input: unshuffle factor must be 1, 2 or 4");
+  SS4K_LAUNCH_OK();
 }
 template void op_pack_input<float>(const float*, float*, int, int, int, int, int, int, hipStream_t);
 template void op_pack_input<__half>(const float*, __half*, int, int, int, int, int, int, hipStream_t);
@@ -353,9 +362,10 @@ __global__ void k_ps_nchw_addbase(const T* __restrict__ src, float* __restrict__
 template <typename T>
 void op_ps_nchw_addbase(const T* src, float* out, const float* base, int n, int h, int w, int r, int cq, hipStream_t st) {
   SS4K_REQUIRE(h <= 65535 && n <= 65535, "pixel shuffle tail: grid limits");
-  if (r == 4) hipLaunchKernelGGL((k_ps_nchw_addbase<T, 4>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq);
-  else if (r == 2) hipLaunchKernelGGL((k_ps_nchw_addbase<T, 2>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq);
+  if (r == 4) { hipLaunchKernelGGL((k_ps_nchw_addbase<T, 4>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq); }
+  else if (r == 2) { hipLaunchKernelGGL((k_ps_nchw_addbase<T, 2>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq); }
   else throw Error(SS4K_EINVAL, "SRVGG: upscale must be 2 or 4");
+  SS4K_LAUNCH_OK();
 }
 template void op_ps_nchw_addbase<float>(const float*, float*, const float*, int, int, int, int, int, hipStream_t);
 template void op_ps_nchw_addbase<__half>(const __half*, float*, const float*, int, int, int, int, int, hipStream_t);
@@ -386,7 +396,7 @@ void op_temporal_shift(const void* in, void* out, int nplanes, int frames, size_
     throw Error(SS4K_EINVAL, "temporal shift: fold must be a multiple of the 16-byte channel group");
   hipLaunchKernelGGL(k_temporal_shift, grid1d((size_t)nplanes * frames * frame_px * slots_per_record), dim3(256), 0, st,
                      reinterpret_cast<const uint4*>(in), reinterpret_cast<uint4*>(out), nplanes, frames, frame_px,
-                     slots_per_record, ch_per_plane, fold);
+                     slots_per_record, ch_per_plane, fold); SS4K_LAUNCH_OK();
 }
 
 }  // namespace ss4k

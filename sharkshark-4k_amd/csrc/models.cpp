@@ -81,7 +81,7 @@ static void validate_desc(const ss4k_model_desc& d) {
                    "RRDBNet: num_feat and num_grow_ch must be multiples of 32");
       break;
     case SS4K_SRVGG:
-      SS4K_REQUIRE(d.scale >= 1 && d.scale <= 4, "SRVGG upscale must be 1..4");
+      SS4K_REQUIRE(d.scale == 2 || d.scale == 4, "SRVGG upscale must be 2 or 4 (PixelShuffle tail)");
       SS4K_REQUIRE(d.num_feat > 0 && d.num_feat % 16 == 0 && d.num_block >= 0, "SRVGG: num_feat must be a multiple of 16");
       break;
     case SS4K_BSVD:
@@ -436,6 +436,7 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
 }
 
 
+#ifdef SS4K_DEV
 // ---- measurement hook: one conv layer in isolation (ss4k_bench_conv) --------------------------
 double bench_conv_layer(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, int n, int h, int w, int flags,
                         int iters, hipStream_t st) {
@@ -496,5 +497,7 @@ double bench_conv_layer(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, 
   dbgb.release();
   return 1000.0 * ms / iters;
 }
+
+#endif  // SS4K_DEV
 
 }  // namespace ss4k

@@ -10,7 +10,11 @@ Restates what the reference's ``TwitchUpscalerPostStreamer`` does around the ups
 * results come back per service in any interleaving and are re-ordered by ``step`` before they
   are handed to the sink (the reference only warns on out-of-order steps, ``streamer.py:77-78``);
 * the sink gets ``'upscaler.upscale.per_frame_ms'`` and queue depths in the profiler
-  (``pipeline.py:140-149``).
+  (``pipeline.py:140-149``);
+* a result that never arrives (a worker died, or ``BaseService`` dropped it on a full result queue)
+  must not stall a 24/7 stream: a step that keeps later results waiting for more than
+  ``lost_after_s`` seconds, or behind more than ``max_reorder`` pending results, is declared lost,
+  counted in ``report()['lost']`` and skipped.
 """
 from __future__ import annotations
 
@@ -27,7 +31,8 @@ from .util.profiler import Profiler
 
 class StreamDispatcher:
     def __init__(self, services: Sequence, fps: int = 24, frame_skips: bool = True,
-                 on_result: Optional[Callable[[UpscalerQueueEntry], None]] = None, max_reorder: int = 64):
+                 on_result: Optional[Callable[[UpscalerQueueEntry], None]] = None, max_reorder: int = 64,
+                 lost_after_s: float = 5.0):
         assert len(services) >= 1
         self.services = list(services)
         self.fps = fps
@@ -36,10 +41,19 @@ class StreamDispatcher:
         self.on_result = on_result
         self.frame_step = 0
         self.next_emit = 0
-        self.dropped: List[int] = []
+        self._dropped = set()        # steps skipped at submit time and not yet passed by next_emit
+        self.dropped_total = 0
+        self.lost_total = 0          # steps that were queued but whose result never came back
         self._pending: Dict[int, UpscalerQueueEntry] = {}
         self.max_reorder = max_reorder
+        self.lost_after_s = lost_after_s
+        self._stalled_since: Optional[float] = None
         self.last_reported = time.time()
+
+    @property
+    def dropped(self) -> List[int]:
+        """Dropped steps the ordered emission has not passed yet (older ones are pruned)."""
+        return sorted(self._dropped)
 
     # pipeline.py:61-108
     def submit_batch(self, frames, audio_segment=None, profiler: Optional[Profiler] = None) -> List[int]:
@@ -68,7 +82,8 @@ class StreamDispatcher:
                     svc.push_job(entry)
                 queued.append(step)
             except queue.Full:
-                self.dropped.append(step)
+                self._dropped.add(step)
+                self.dropped_total += 1
                 print("StreamDispatcher: upscaler queue full, job skipped")
         return queued
 
@@ -78,12 +93,28 @@ class StreamDispatcher:
             if self.next_emit in self._pending:
                 out.append(self._pending.pop(self.next_emit))
                 self.next_emit += 1
-            elif self.next_emit in self.dropped:
+            elif self.next_emit in self._dropped:
+                self._dropped.discard(self.next_emit)
                 self.next_emit += 1
-            elif force and self._pending:
-                self.next_emit = min(self._pending)  # a step was lost downstream: do not stall the stream
+            elif self._pending:
+                # results are waiting behind a step that has not come back
+                now = time.time()
+                if self._stalled_since is None:
+                    self._stalled_since = now
+                if force or now - self._stalled_since > self.lost_after_s:
+                    nxt = min(self._pending)  # lost downstream: do not stall the stream
+                    gone = [s for s in range(self.next_emit, nxt) if s not in self._dropped]
+                    self.lost_total += len(gone)
+                    self._dropped.difference_update(range(self.next_emit, nxt))
+                    print(f"StreamDispatcher: step(s) {gone} never came back, skipped")
+                    self.next_emit = nxt
+                    self._stalled_since = None
+                else:
+                    break
             else:
                 break
+        if out or not self._pending:
+            self._stalled_since = None
         for e in out:
             if e.profiler is not None and "upscaler.upscale" in e.profiler.data and e.frames is not None:
                 e.profiler.set("upscaler.upscale.per_frame_ms", e.profiler.data["upscaler.upscale"] / len(e.frames) * 1000)
@@ -119,5 +150,6 @@ class StreamDispatcher:
         return out
 
     def report(self) -> dict:
-        return {"frame_step": self.frame_step, "dropped": len(self.dropped), "pending": len(self._pending),
+        return {"frame_step": self.frame_step, "dropped": self.dropped_total, "lost": self.lost_total,
+                "pending": len(self._pending),
                 "upscaler.inputq": [s.job_queue.qsize() for s in self.services]}

@@ -5,8 +5,19 @@ Same constructor arguments, attributes (``lr_shape``, ``output_shape``, ``on_que
 contract as ``src/upscale/fsrcnn_upscaler.py:86-326``; all arithmetic runs in libss4k_hip.so
 (``jit_mode='hip'``, the one backend of this build).  Extra keyword arguments that the reference
 hard-codes are exposed: ``scale`` (FSRCNN factor, reference: always 4, fsrcnn_upscaler.py:101),
-``model_name`` (reference: ``ArgsData.model_name``, realesrgan/factory.py:88), ``dtype``, ``weights``
-and an ``lr_shape`` override.
+``model_name`` (reference: ``ArgsData.model_name``, realesrgan/factory.py:88), ``dtype`` and an
+``lr_shape`` override.
+
+Weights.  The reference always loads real checkpoints (``fsrcnn_x4-T91.pth``, the downloaded
+RealESRGAN ``.pth`` files with the DNI blend, ``bsvd-32.pth``); so does this service:
+
+* ``weights=None`` (default): the reference's own file names are looked up in ``checkpoint_dir``
+  (else ``$SS4K_CHECKPOINT_DIR``); ``proc_init`` raises ``FileNotFoundError`` when one is missing.
+* ``weights={'sr': X, 'sr_wdn': X, 'denoise': X}`` with X a ``.pth`` path, the dict ``torch.load``
+  returns (``state_dict`` / ``params_ema`` / ``params``; BSVD's ``nets_list`` remap is applied) or a
+  state-dict table; missing entries fall back to the ``checkpoint_dir`` lookup.
+* ``weights='synthetic'``: deterministic generated weights for every model - an explicit opt-in
+  used by the tests and ``bench.py`` only (logged loudly: the frames are noise).
 """
 from __future__ import annotations
 
@@ -30,7 +41,7 @@ class HipUpscalerService(BaseUpscalerService):
     def __init__(self, lr_level=3, device=0, on_queue=None, denoising=True, denoise_rate=1.0,
                  upscaler_model="realesrgan", batch_size=1, jit_mode="hip", lr_hr_resize=True,
                  # knobs the reference hard-codes
-                 scale=4, model_name=None, dtype="f16", weights: Optional[Mapping[str, Mapping]] = None,
+                 scale=4, model_name=None, dtype="f16", weights=None, checkpoint_dir: Optional[str] = None,
                  lr_shape=None, single_mode=None, seed=0):
         if jit_mode not in (None, "hip"):
             raise Exception(f"jit_mode={jit_mode!r}: this build has one backend, 'hip'")
@@ -51,7 +62,10 @@ class HipUpscalerService(BaseUpscalerService):
         self.lr_hr_resize = lr_hr_resize
         self.model_name = model_name
         self.dtype = dtype
-        self.weights = dict(weights) if weights is not None else {}
+        if not (weights is None or weights == "synthetic" or isinstance(weights, Mapping)):
+            raise TypeError("weights must be None (checkpoint_dir lookup), 'synthetic' or {'sr'|'sr_wdn'|'denoise': path | checkpoint | table}")
+        self.weights = weights if isinstance(weights, str) or weights is None else dict(weights)
+        self.checkpoint_dir = checkpoint_dir
         self.seed = seed
         super().__init__()
 
@@ -62,19 +76,24 @@ class HipUpscalerService(BaseUpscalerService):
         log("proc init")
         self.ctx = _capi.Context(self.device)
         self.torch_device = self.ctx.device
+        if self.weights == "synthetic":
+            log("WARNING: weights='synthetic' - every network runs on generated weights, output frames are noise")
+        def spec(name):
+            return "synthetic" if self.weights == "synthetic" else (self.weights or {}).get(name)
         if self.upscaler_model == "fsrcnn":
-            self.model = factory.build_model_fsrcnn(self.ctx, factor=self.scale, weights=self.weights.get("sr"),
-                                                    seed=self.seed)
+            self.model = factory.build_model_fsrcnn(self.ctx, factor=self.scale, weights=spec("sr"), seed=self.seed,
+                                                    checkpoint_dir=self.checkpoint_dir)
         else:
             self.model = factory.build_model_esrgan(
                 self.ctx, model_name=self.model_name or factory.DEFAULT_REALESRGAN, denoise_rate=self.denoise_rate,
-                weights=self.weights.get("sr"), dtype=self.dtype, seed=self.seed)
+                weights=spec("sr"), weights_wdn=spec("sr_wdn") if self.weights != "synthetic" else None, dtype=self.dtype,
+                seed=self.seed, checkpoint_dir=self.checkpoint_dir)
         self.denoise_model = None
         # quirk kept from the reference: with 'realesrgan' the batched path never denoises even when
         # denoising=True (fsrcnn_upscaler.py:109,168-233); the BSVD model is only used per-frame.
         if self.denoising and self.single_mode:
-            self.denoise_model = factory.build_denoise_model(self.ctx, weights=self.weights.get("denoise"),
-                                                             dtype=self.dtype, seed=self.seed)
+            self.denoise_model = factory.build_denoise_model(self.ctx, weights=spec("denoise"), dtype=self.dtype,
+                                                             seed=self.seed, checkpoint_dir=self.checkpoint_dir)
         self._upscaler = None
         self._upscaler_key = None
         log("model loaded")

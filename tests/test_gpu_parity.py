@@ -338,7 +338,7 @@ def test_image_mode_max_size_runs(ctx):
     shipped default net (SRVGG x4, fp16): 16384x8192 out.  Size-independent checks: the channel
     statistics match makes every output channel's mean equal the input's (within truncation), and
     the call is deterministic."""
-    sr = factory.build_model_esrgan(ctx, "realesr-general-x4v3", dtype="f16", seed=3)
+    sr = factory.build_model_esrgan(ctx, "realesr-general-x4v3", weights="synthetic", dtype="f16", seed=3)
     up = _capi.Upscaler(ctx, sr, (360, 640), None, False, False, None, 0.2)
     frame = torch.from_numpy(smooth_u8(77, (1, 2048, 4096, 3))).cuda()
     out = up(frame)
@@ -503,20 +503,3 @@ def test_stream_dispatcher_over_two_hip_services():
     finally:
         for s_ in svcs:
             s_.stop()
-
-
-def test_rrdbnet_x4_1080p_runs(ctx):
-    """BASELINE config 5 shape on one GPU: RRDBNet x4 (6 blocks to bound the time), 1080p -> 4320x7680,
-    bicubic to 2160x3840 through the batched service path; output statistics must be sane."""
-    table = W.rrdbnet_table(2, scale=4, num_block=6)
-    sr = factory.build_model_esrgan(ctx, "RealESRGAN_x4plus_anime_6B", weights=table, dtype="f16")
-    up = _capi.Upscaler(ctx, sr, (1080, 1920), (2160, 3840), True, False, None, 1.0)
-    # 3 frames: a 4320x7680 plane is 2.1 GB, so the library has to split this batch (2 + 1) internally
-    frames = torch.from_numpy(smooth_u8(9, (3, 1080, 1920, 3))).cuda()
-    out = up(frames)
-    assert out.shape == (3, 2160, 3840, 3) and out.dtype == torch.uint8
-    assert torch.equal(up(frames[2:3])[0], out[2])  # batch splitting does not change a frame's result
-    # mean/std matching forces the output statistics onto the input's (fsrcnn_upscaler.py:188-199)
-    fi, fo = frames.float(), out.float()
-    assert abs(float(fi.mean()) - float(fo.mean())) < 2.0
-    assert abs(float(fi.std()) - float(fo.std())) < 6.0

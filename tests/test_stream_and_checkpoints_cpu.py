@@ -69,6 +69,22 @@ def test_frame_skip_backpressure():
     assert d.report()["dropped"] == 3
 
 
+def test_lost_result_does_not_stall_the_stream():
+    """A queued job whose result never comes back (dead worker / full result queue) is declared lost
+    after lost_after_s, counted, and the later steps are emitted; dropped steps are pruned."""
+    svcs = [FakeService(maxsize=8), FakeService(maxsize=8)]
+    d = StreamDispatcher(svcs, fps=24, lost_after_s=0.2)
+    steps = d.submit_batch(torch.zeros(16, 2, 2, 3, dtype=torch.uint8))
+    assert steps == [0, 1, 2, 3]
+    svcs[0].job_queue.get()      # step 0 vanishes inside service 0
+    svcs[0].work(); svcs[1].work()
+    assert d.poll() == []        # steps 1-3 are held back for step 0 ...
+    out = d.drain([1, 2, 3], timeout=5)
+    assert [e.step for e in out] == [1, 2, 3]   # ... but only for lost_after_s
+    rep = d.report()
+    assert rep["lost"] == 1 and rep["dropped"] == 0 and rep["pending"] == 0 and d.dropped == []
+
+
 def test_dispatcher_with_real_worker_processes():
     svcs = [NearestDouble(), NearestDouble()]
     for s in svcs:
@@ -121,3 +137,73 @@ def test_bsvd_upstream_key_remap():
     got = ck.bsvd_from_checkpoint({"params": up})
     assert list(got) == W.bsvd_keys()
     assert all(np.array_equal(got[k], t[k]) for k in t)
+
+
+# ------------------------------------------------------------------------------ weight sources of the factories / service
+def test_factories_never_fall_back_to_made_up_weights(tmp_path, monkeypatch):
+    """without weights the factories look for the reference's checkpoint files and
+    raise when they are missing; 'synthetic' is an explicit opt-in; paths, torch.load dicts and
+    state-dict tables all resolve to the same table."""
+    from sharkshark4k_amd.upscale import model as factory
+    monkeypatch.delenv("SS4K_CHECKPOINT_DIR", raising=False)
+    for fn in (lambda: factory.fsrcnn_table_from(None, 4), lambda: factory.esrgan_table_from("RealESRGAN_x2plus"),
+               lambda: factory.esrgan_table_from("realesr-general-x4v3"), lambda: factory.bsvd_table_from(None)):
+        with pytest.raises(FileNotFoundError) as ei:
+            fn()
+        assert "synthetic" in str(ei.value) and ".pth" in str(ei.value)
+    # the reference's file names inside checkpoint_dir (fsrcnn/factory.py:8-10, realesrgan/factory.py:140-157, bsvd/factory.py:35)
+    t = W.fsrcnn_table(3)
+    torch.save({"epoch": 3, "state_dict": {k: torch.from_numpy(v) for k, v in t.items()}}, tmp_path / "fsrcnn_x2-T91.pth")
+    got = factory.fsrcnn_table_from(None, 2, checkpoint_dir=str(tmp_path))
+    assert all(np.array_equal(got[k], t[k]) for k in t)
+    monkeypatch.setenv("SS4K_CHECKPOINT_DIR", str(tmp_path))
+    assert np.array_equal(factory.fsrcnn_table_from(None, 2)["deconv.weight"], t["deconv.weight"])
+    with pytest.raises(FileNotFoundError):
+        factory.fsrcnn_table_from(None, 4)  # only the x2 file is there
+    # path / dict / table for one model are the same weights
+    same = [factory.fsrcnn_table_from(spec, 2) for spec in (str(tmp_path / "fsrcnn_x2-T91.pth"), {"state_dict": t}, t)]
+    assert all(np.array_equal(s_["shrink.0.bias"], t["shrink.0.bias"]) for s_ in same)
+    assert np.array_equal(factory.fsrcnn_table_from("synthetic", 2, seed=3)["shrink.0.bias"], t["shrink.0.bias"])
+
+
+def test_dni_blend_of_two_checkpoints_and_bsvd_remap_through_the_factory(tmp_path):
+    from sharkshark4k_amd.upscale import model as factory
+    a, b = W.srvgg_table(1), W.srvgg_table(2)
+    torch.save({"params": {k: torch.from_numpy(v) for k, v in a.items()}}, tmp_path / "realesr-general-x4v3.pth")
+    torch.save({"params": {k: torch.from_numpy(v) for k, v in b.items()}}, tmp_path / "realesr-general-wdn-x4v3.pth")
+    arch, kw, t = factory.esrgan_table_from("realesr-general-x4v3", denoise_rate=0.25, checkpoint_dir=str(tmp_path))
+    k = "body.4.weight"
+    assert arch == "srvgg" and np.allclose(t[k], 0.25 * a[k] + 0.75 * b[k])   # realesrgan/factory.py:152-157
+    _, _, t1 = factory.esrgan_table_from("realesr-general-x4v3", denoise_rate=1, checkpoint_dir=str(tmp_path))
+    assert np.array_equal(t1[k], a[k])                                          # no blend at strength 1
+    with pytest.raises(FileNotFoundError):  # a checkpoint without its wdn partner cannot be blended
+        factory.esrgan_table_from("realesr-general-x4v3", 0.5, weights={"params": a})
+    _, _, t2 = factory.esrgan_table_from("realesr-general-x4v3", 0.5, weights={"params": a}, weights_wdn={"params": b})
+    assert np.allclose(t2[k], 0.5 * a[k] + 0.5 * b[k])
+    # BSVD in the UPSTREAM key layout goes through the nets_list / convblock->memconv remap (INTEGRATION.md)
+    tb = W.bsvd_table(5)
+    up = {}
+    for i, blk in enumerate(("temp1", "temp2")):
+        for kk, v in tb.items():
+            if kk.startswith(blk + "."):
+                r = kk[len(blk) + 1:]
+                for d in ("downc0.", "downc1."):
+                    if r.startswith(d + "memconv."):
+                        r = d + "convblock.3." + r[len(d + "memconv."):].replace("op.conv.", "net.")
+                for u in ("upc2.", "upc1."):
+                    if r.startswith(u + "memconv."):
+                        r = u + "convblock.0." + r[len(u + "memconv."):].replace("op.conv.", "net.")
+                    elif r.startswith(u + "convblock.0."):
+                        r = u + "convblock.1." + r[len(u + "convblock.0."):]
+                up[f"base_model.nets_list.{i}.{r}"] = torch.from_numpy(v)
+    torch.save({"params": up}, tmp_path / "bsvd-32.pth")
+    got = factory.bsvd_table_from(None, checkpoint_dir=str(tmp_path))
+    assert list(got) == W.bsvd_keys() and all(np.array_equal(got[q], tb[q]) for q in tb)
+
+
+def test_service_weight_argument_is_validated():
+    from sharkshark4k_amd.upscale.hip_upscaler import HipUpscalerService
+    assert HipUpscalerService(denoising=False).weights is None                 # -> checkpoint_dir lookup in proc_init
+    assert HipUpscalerService(denoising=False, weights="synthetic").weights == "synthetic"
+    with pytest.raises(TypeError):
+        HipUpscalerService(denoising=False, weights="random")

@@ -13,7 +13,7 @@ if __name__ == "__main__":
     jobs = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     depth = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     svc = HipUpscalerService(device=0, denoising=False, upscaler_model="realesrgan", model_name="RealESRGAN_x2plus",
-                             scale=2, lr_level=3, dtype="f16")
+                             scale=2, lr_level=3, dtype="f16", weights="synthetic")
     svc.output_shape = (1440, 2560)
     svc.start()
     try:
