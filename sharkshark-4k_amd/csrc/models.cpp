@@ -160,6 +160,7 @@ PackSpec Model::spec_shifted(int c) const {
 void Model::build(const float* w, size_t n) {
   validate_desc(desc);
   if (const char* e = std::getenv("SS4K_NO_FLIP")) flip_walk = !(e[0] == '1');  // A/B switch for the tile-walk direction
+  if (const char* e = std::getenv("SS4K_SUBBATCH")) sub_batch = std::atoi(e);   // A/B switch: frames per pass through the network
   SS4K_REQUIRE(n == model_param_count(desc), "weight blob size does not match the model description");
   ParamCursor pc{w, n};
   if (desc.kind == SS4K_FSRCNN) {
@@ -309,7 +310,8 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
     const bool tail_at_out = desc.kind == SS4K_RRDBNET;
     const double plane1 = (double)(tail_at_out ? std::max(oh, h) : h) * (tail_at_out ? std::max(ow, w) : w);
     SS4K_REQUIRE(plane1 < 2147483648.0, "forward: a single frame exceeds 2^31 pixels");
-    const int max_n = std::max(1, (int)(2147483647.0 / plane1));
+    int max_n = std::max(1, (int)(2147483647.0 / plane1));
+    if (sub_batch > 0) max_n = std::min(max_n, sub_batch);
     if (n > max_n) {
       for (int i = 0; i < n; i += max_n) {
         const int nn = std::min(max_n, n - i);

@@ -36,6 +36,7 @@ struct Model {
   size_t weight_bytes = 0;
   bool flip_walk = true;   // consecutive conv launches walk their tiles in opposite directions (cache reuse)
   int launch_parity = 0;
+  int sub_batch = 0;       // > 0: a job's frames go through the network this many at a time (working set vs Infinity Cache)
   // plan_only: forward() walks the network without touching the device and records the activation
   // bytes each buffer slot would need (ss4k_model_workspace_bytes)
   bool plan_only = false;
