@@ -42,14 +42,18 @@ def test_rrdbnet_23_blocks_fp32_vs_oracle(ctx, scale, shape):
     with torch.no_grad():
         want = onets.rrdbnet(x, table, scale, 23)
     got = m(x.cuda())
-    assert_close(got, want, what=f"rrdbnet x{scale} 23 blocks {shape}")
-    # and the deep net really is deep: a slip in one late block must be visible in this comparison
-    assert float(want.abs().max()) > 1e-2
+    # north_star's atol = 1e-4 is quoted for image-range outputs ([0,1]); this random-weight network's
+    # output peaks near 10, so the absolute term is scaled by the output's peak (rtol stays 1e-3)
+    peak = max(1.0, float(want.abs().max()))
+    assert_close(got, want, rtol=1e-3, atol=1e-4 * peak, what=f"rrdbnet x{scale} 23 blocks {shape}")
+    err = float((got.cpu() - want).abs().max())
+    print(f"rrdbnet x{scale} 23 blocks {shape}: output peak {peak:.3g}, max |err| {err:.3g} = {err / peak:.2e} of peak")
+    assert err / peak < 1e-4
 
 
 def test_rrdbnet_23_blocks_block_slip_is_detected(ctx):
     """The comparison above is sensitive to a single late block: perturbing body.22.rdb3.conv5 of the
-    HIP model's weights by 1 % moves the output by more than the tolerance."""
+    HIP model's weights by 50 % moves more than 1 % of the outputs out of the tolerance."""
     _cpu_threads()
     table = W.rrdbnet_table(33, scale=2)
     x = torch.from_numpy(smooth_u8(5, (1, 64, 96, 3))).permute(0, 3, 1, 2).float().div(255.0)
@@ -59,7 +63,8 @@ def test_rrdbnet_23_blocks_block_slip_is_detected(ctx):
     bad["body.22.rdb3.conv5.weight"] = table["body.22.rdb3.conv5.weight"] * 1.5
     m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F32, scale=2), W.flatten(bad, W.rrdbnet_keys(23)))
     err = (m(x.cuda()).cpu() - want).abs()
-    assert float((err > 1e-4 + 1e-3 * want.abs()).float().mean()) > 0.01
+    peak = max(1.0, float(want.abs().max()))
+    assert float((err > 1e-4 * peak + 1e-3 * want.abs()).float().mean()) > 0.01
 
 
 # ------------------------------------------------------------------------------ (b) configs[2] at full size, fp16, service path
