@@ -1,0 +1,434 @@
+// 3x3 convolution (pad 1, stride 1), fp16 storage / fp32 accumulate, with REGISTER-STATIONARY WEIGHTS
+// on v_mfma_f32_16x16x32_f16 - the production kernel of the RRDBNet / SRVGG body layers (round 2).
+//
+// Why this shape (measurements: tools/micro/mfma_shapes.hip, tools/micro/rs_skeleton.hip):
+//   * on random data the chip holds a ~13 % higher clock on the 16x16x32 MFMA than on 32x32x16 at
+//     equal cycles per FLOP (the conv kernel is power-bound, not issue-bound);
+//   * K = 32 of that MFMA is one tap x 32 input channels = TWO 16-channel planes, so an LDS pipeline
+//     stage is a 64-byte-per-pixel halo tile (38 KB for 16x32 pixels); together with double-buffered
+//     weights that no longer fits two workgroups per CU - so the weights leave LDS altogether:
+//   * ONE 4-wave workgroup per CU (one wave per SIMD, the whole 512-entry register file per lane).  Every
+//     wave loads ITS slice of the layer's weights (all input channels x 9 taps x 16 or 32 output
+//     channels, MFMA A-fragment order, 144-288 registers) once, at the start of the persistent workgroup,
+//     and keeps it - mostly in the accumulation half of the register file (AGPRs), read by the MFMAs
+//     directly as their A operand - for every tile it processes: no weight DMA, no weight LDS reads,
+//     1/3 to 1/2 fewer L2->LDS bytes per FLOP than the LDS-weights kernel (conv_mfma.hip);
+//   * LDS holds only a ring of three halo stages filled by LDS-DMA two K-chunks ahead (across tile
+//     boundaries), counted s_waitcnt vmcnt(N) + one raw barrier per chunk; a tile's output stores drain
+//     under the next tile's MFMAs (they are accounted for in the counted wait).
+//
+// Work split of the 16x32-pixel tile over the four waves, by layer shape <NCH, ROWS, CB>
+// (NCH = 32-channel K-chunks, ROWS = output rows per wave, CB = 16-cout blocks per wave):
+//     32 couts, cin  64/ 96/128 (RDB conv1-3) : <2|3|4, 4, 2>  4 row groups, every wave all 32 couts
+//     32 couts, cin 160         (RDB conv4)   : <5, 8, 1>      2 row groups x 2 cout halves
+//     64 couts, cin  64 (trunk / tail / SRVGG): <2, 8, 2>      2 row groups x 2 cout halves
+//     64 couts, cin 192         (RDB conv5)   : <6, 16, 1>     every wave the whole tile, 16 couts each
+// Data layout in HBM is conv_mfma.hip's ("planes" of 16 channels, 32-byte records), so the two kernels
+// are interchangeable per layer; the fp32 parity path, the first / last layers and the BSVD epilogues stay
+// on conv_mfma.hip.
+#include "common.h"
+
+namespace ss4k {
+namespace rs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TH = 16, TW = 32, IN_H = TH + 2, IN_W = TW + 2;
+constexpr int PIXB = 64;                     // LDS bytes per halo pixel: 2 planes x 16 channels x fp16
+constexpr int ROWB = IN_W * PIXB;            // 2176
+constexpr int TILE_SLOTS = IN_H * IN_W * 4;  // 16-byte slots of a 32-channel halo stage (2448 = 38.25 KB)
+constexpr int NDMA = (TILE_SLOTS + 255) / 256;     // wave-level 1 KB LDS-DMA instructions per wave and stage (10)
+constexpr int STAGE = NDMA * 4 * 1024;       // stage padded to a whole number of DMA instructions per wave: every
+                                             // wave issues exactly NDMA per stage (exact counted waits, no EXEC masks)
+constexpr int NSTAGE = 3;                    // ring: one being read, two in flight (120 KB)
+constexpr int MAX_PLANES = 12;
+
+// kernel arguments, reduced to what the kernel reads (scalar registers are scarce next to 100 address
+// and loop scalars): plane pointers resolved on the host, outputs / residuals pre-offset to their first plane
+struct RsArgs {
+  const char* plane[MAX_PLANES];   // source plane of every 16-channel K-slice (two per chunk); nullptr = zeros
+  const char* zero_page;
+  const void* wrs; const float* bias; const float* prelu;
+  char* out; size_t out_plane_bytes;
+  const char* res1; size_t r1_plane_bytes;
+  const char* res2; size_t r2_plane_bytes;
+  int N, H, W, ups2, tiles_x, tiles_y, reverse;
+  float slope, alpha, gamma;       // slope: LeakyReLU slope, 1 = no activation (PReLU: per channel, `prelu`)
+};
+
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_addr_wave_uniform) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr_wave_uniform)
+               : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+// acc += W * B on the matrix core.  Written as asm so that the register file of the stationary weights is OURS
+// to choose: WA = the fragment lives in an AGPR quad and is read by the MFMA directly (hipcc, left alone, parks
+// weights beyond 256 VGPRs in AGPRs too but copies every fragment back with four v_accvgpr_read before each
+// use - two VALU issues per MFMA, which is all the issue room a 16-cycle MFMA leaves).
+// Hazards (cdna_hip_programming.md 5.7): accumulate chains need no wait states; the operands come from
+// ds_read / global_load (hipcc inserts those waits before the statement); the first MFMA of a tile and the
+// epilogue's first read of an accumulator are fenced with s_nop below.
+__device__ __forceinline__ void mfma16(f32x4& acc, const u32x4& w, const u32x4& b, bool WA) {  // WA folds after unrolling
+  if (WA) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b));
+}
+
+// 16-byte slots of a pixel are XOR-swizzled by its column so that every ds_read_b128 of a B fragment
+// (16 pixels x 4 k-groups per wave) is bank-conflict free for all three tap columns
+__device__ __forceinline__ int swz(int col) { return ((col >> 2) & 1) << 1; }
+
+// PR: per-channel PReLU slopes (SRVGG); otherwise one LeakyReLU slope / identity for the whole layer
+template <int NCH, int ROWS, int CB, bool PR>
+__global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
+  constexpr int RG = TH / ROWS, CG = 4 / RG, COUT_WG = CG * CB * 16;
+  constexpr int NV = CB * 4;                  // output channels per lane and pixel
+  constexpr int NSTEP = 3 * (ROWS + 2);       // (tap column, input row) steps per K-chunk
+  constexpr int NSTORE = ROWS * 2;            // store instructions per wave and tile
+  // K-chunks whose weight fragments live in AGPRs (<= 216 of the 256); the rest stay in VGPRs next to the
+  // accumulators, B fragments and addresses
+  constexpr int NA = (216 / (36 * CB)) < NCH ? (216 / (36 * CB)) : NCH;
+  static_assert(NCH >= 2 && 2 * NCH <= MAX_PLANES, "the two-chunks-ahead prefetch needs at least two K-chunks per tile");
+  static_assert(ROWS * 2 * CB * 4 + (NCH - NA) * 36 * CB <= 160, "VGPR budget: accumulators + VGPR-resident weights");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wave % RG, cg = wave / RG;   // this wave's row group and cout group
+  const int p = lane & 15, q = lane >> 4;
+  const int grp = blockIdx.y;
+  const int ntiles = a.N * a.tiles_y * a.tiles_x;
+
+  // XCD-aware persistent tile walk (same as conv_mfma.hip): workgroups b and b+8 share an XCD; each
+  // XCD gets a contiguous band of tiles.  Placement only changes speed, never results.
+  const bool banded = (gridDim.x % 8 == 0) && ntiles >= (int)gridDim.x;
+  const int tpx = (ntiles + 7) / 8;
+  auto tile_of = [&](int k) -> int {
+    if (!banded) {
+      const int t = blockIdx.x + k * gridDim.x;
+      return t < ntiles ? (a.reverse ? ntiles - 1 - t : t) : -1;
+    }
+    const int base = (blockIdx.x & 7) * tpx, len = min(tpx, ntiles - base);
+    const int j = (blockIdx.x >> 3) + k * (gridDim.x >> 3);
+    return j < len ? base + (a.reverse ? len - 1 - j : j) : -1;
+  };
+  auto setup_tile = [&](int tile, int& n, int& y0, int& x0) {
+    const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
+    const int ty = tyn % a.tiles_y;
+    n = tyn / a.tiles_y; y0 = ty * TH; x0 = tx * TW;
+  };
+
+  // ---- this wave's weight slice -> registers (A fragments: lane (m, kq) holds cout row m, k = 8kq..8kq+7)
+  u32x4 W[NCH][9][CB];
+  {
+    const char* wsrc = reinterpret_cast<const char*>(a.wrs) + ((size_t)(grp * CG + cg) * NCH * 9 * CB) * 1024 + lane * 16;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) W[c][t][cb] = *reinterpret_cast<const u32x4*>(wsrc + ((c * 9 + t) * CB + cb) * 1024);
+    // pin the AGPR-resident fragments to their register quads now (the loads then target AGPRs directly):
+    // left to the first MFMA that reads each, 216 registers of loads would be live in VGPRs at once
+#pragma unroll
+    for (int c = 0; c < NA; ++c)
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) asm volatile("" : "+a"(W[c][t][cb]));
+  }
+  // epilogue constants of this lane's NV channels: cout0 + NV*q + j
+  const int cout0 = grp * COUT_WG + cg * CB * 16;
+  float bias_v[NV], slope_v[PR ? NV : 1];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int v = cout0 + NV * q + j;
+    bias_v[j] = a.bias[v];
+    if constexpr (PR) slope_v[j] = a.prelu[v];
+  }
+  if constexpr (!PR) slope_v[0] = a.slope;
+
+  // per-lane B-fragment read bases: pixel column 16*pb + p + dx, k-group q (swizzled), wave's first row
+  int rdb[3][2];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      const int col = 16 * pb + p + dx;
+      rdb[dx][pb] = (rg * ROWS) * ROWB + col * PIXB + ((q ^ swz(col)) << 4);
+    }
+
+  // DMA plan.  LDS slot s = 64k + lane of a stage is pixel (row, col) of the halo tile, position qq; it receives
+  // data group dg = qq ^ swz(col)  (dg >> 1: which plane of the pair, dg & 1: which 8-channel half).
+  // Tile-independent part per DMA instruction j of this wave: row | col << 8 | dg << 16 (padding slots: row 255).
+  int plan[NDMA];
+#pragma unroll
+  for (int j = 0; j < NDMA; ++j) {
+    const int s = (wave + 4 * j) * 64 + lane;
+    const int pix = s >> 2, qq = s & 3;
+    const int row = pix / IN_W, col = pix - row * IN_W;
+    plan[j] = (s < TILE_SLOTS) ? (row | (col << 8) | ((qq ^ swz(col)) << 16)) : 0xff;
+  }
+  constexpr uint32_t OOB = 0xFFFFFFFFu;
+  // per tile: source pixel index (inside a plane) of every slot this lane moves, OOB = zero padding
+  auto tile_offsets = [&](int tn, int ty0, int tx0, uint32_t (&off)[NDMA]) {
+    const int Hs = a.ups2 ? (a.H >> 1) : a.H, Ws = a.ups2 ? (a.W >> 1) : a.W;
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) {
+      const int row = plan[j] & 0xff, col = (plan[j] >> 8) & 0xff;
+      const int iy = ty0 - 1 + row, ix = tx0 - 1 + col;
+      const bool inside = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W) & (row < IN_H);
+      const int sy = a.ups2 ? (iy >> 1) : iy, sx = a.ups2 ? (ix >> 1) : ix;
+      off[j] = inside ? (uint32_t)(tn * Hs + sy) * (uint32_t)Ws + (uint32_t)sx : OOB;
+    }
+  };
+  // One wave-level DMA instruction (1 KB) into ring slot `slot`.  pA / pB: the chunk's two source planes
+  // (a missing plane = the zero page with record stride mul = 0, so the instruction stream has no branch).
+  auto dma_op = [&](int j, const char* pA, const char* pB, uint32_t mulA, uint32_t mulB, const uint32_t (&off)[NDMA], int slot) {
+    // behind an opaque copy: the selects below depend only on (lane, j, chunk), and hoisted out of the
+    // tile loop for every (j, chunk) pair they would hold 180 VGPRs
+    int pj = plan[j];
+    asm volatile("" : "+v"(pj));
+    const int dg = pj >> 16;
+    const bool second = (dg & 2) != 0, in = off[j] != OOB;
+    const char* base = second ? pB : pA;
+    const uint32_t mul = in ? (second ? mulB : mulA) : 0u;
+    const char* src = (in ? base : a.zero_page) + (size_t)off[j] * mul + (size_t)((dg & 1) << 4);
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + slot * STAGE + (wave + 4 * j) * 1024);
+    dma16(src, dst);
+  };
+
+  int kt = 0, tile = tile_of(0);
+  if (tile < 0) return;
+  int n, y0, x0, nn = 0, ny0 = 0, nx0 = 0;
+  uint32_t offc[NDMA], offn[NDMA];
+  setup_tile(tile, n, y0, x0);
+  tile_offsets(n, y0, x0, offc);
+  int next_tile = tile_of(1);
+  if (next_tile >= 0) { setup_tile(next_tile, nn, ny0, nx0); tile_offsets(nn, ny0, nx0, offn); }
+  auto plane_or_zero = [&](int j, bool on, const char*& ptr, uint32_t& mul) {
+    const char* pl = on ? a.plane[j] : nullptr;
+    ptr = pl ? pl : a.zero_page; mul = pl ? 32u : 0u;
+  };
+
+  // prologue: K-chunks 0 and 1 of the first tile into slots 0 and 1
+  {
+    const char *p0, *p1, *p2, *p3; uint32_t m0, m1, m2, m3;
+    plane_or_zero(0, true, p0, m0); plane_or_zero(1, true, p1, m1); plane_or_zero(2, true, p2, m2); plane_or_zero(3, true, p3, m3);
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) dma_op(j, p0, p1, m0, m1, offc, 0);
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) dma_op(j, p2, p3, m2, m3, offc, 1);
+  }
+  wait_vm<NDMA>();         // chunk 0 has landed (this wave's chunk-1 pieces are still in flight)
+  __builtin_amdgcn_s_barrier();
+  int slot = 0;            // ring slot of the chunk being computed
+  bool prev_full = false;  // the previous tile issued all NSTORE stores and no other vector-memory operation
+
+  while (true) {
+    f32x4 acc[ROWS][2][CB];
+#pragma unroll
+    for (int mb = 0; mb < ROWS; ++mb)
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[mb][pb][cb][i] = bias_v[4 * cb + i];
+    asm volatile("s_nop 4");   // VALU-written accumulators -> first MFMA (the asm MFMAs get no hazard padding)
+
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      // the stage filled during this chunk: K-chunk c+2 of this tile, or chunk c+2-NCH of the next one.
+      // Past the last tile the DMAs are still issued (zeros, into a free slot): the counted waits stay
+      // exact and the MFMA stream carries no branch.
+      const bool tgt_next = (c + 2 >= NCH);
+      const int cc = (c + 2) % NCH;
+      const bool pf = tgt_next ? (next_tile >= 0) : true;
+      const char *pA, *pB; uint32_t mulA, mulB;
+      plane_or_zero(2 * cc, pf, pA, mulA); plane_or_zero(2 * cc + 1, pf, pB, mulB);
+      const int fill = slot == 0 ? 2 : slot - 1;   // (slot + 2) % 3: the slot read during the previous chunk
+      const char* sb = smem + slot * STAGE;
+
+      u32x4 bf[3][2];   // B fragments of three consecutive steps (two-step read-ahead)
+      auto ldb = [&](int s) {
+        const int dx = s / (ROWS + 2), ir = s % (ROWS + 2);
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) bf[s % 3][pb] = *reinterpret_cast<const u32x4*>(sb + rdb[dx][pb] + ir * ROWB);
+      };
+      ldb(0); ldb(1);
+      int dma_i = 0;
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        const int dx = s / (ROWS + 2), ir = s % (ROWS + 2);
+        if (s + 2 < NSTEP) ldb(s + 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int mb = ir - dy;
+          if (mb >= 0 && mb < ROWS) {
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+              for (int cb = 0; cb < CB; ++cb) mfma16(acc[mb][pb][cb], W[c][dy * 3 + dx][cb], bf[s % 3][pb], c < NA);
+          }
+        }
+        // this wave's DMA instructions of the prefetch are spread over the first 3/4 of the chunk
+        if (dma_i < NDMA && 4 * s * NDMA >= 3 * dma_i * NSTEP) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (tgt_next) dma_op(dma_i, pA, pB, mulA, mulB, offn, fill); else dma_op(dma_i, pA, pB, mulA, mulB, offc, fill);
+          ++dma_i;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // hand-over: the NEXT chunk's stage (issued one chunk ago) must have landed; what this chunk
+      // issued stays in flight.  vmcnt counts DMA, loads and stores together in issue order: right
+      // after an epilogue the tile's NSTORE stores sit between the two stages and are left in flight too.
+      if (c == 0 && prev_full) wait_vm<(NDMA + NSTORE < 63 ? NDMA + NSTORE : 63)>();
+      else wait_vm<NDMA>();
+      __builtin_amdgcn_s_barrier();
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+    asm volatile("s_nop 15");  // last MFMA's result -> first VALU read in the epilogue
+
+    // ---------------- epilogue: activation, residuals, fp16 stores (no LDS use) ----------------
+    // lane (p, q) holds, per row mb and pixel block pb, channels cout0 + NV*q .. + NV-1 of pixel 16*pb + p
+    {
+      const float alpha = a.alpha, gamma = a.gamma;
+      const int opl = cout0 / 16 + (CB == 2 ? (q >> 1) : 0);
+      const size_t sub = CB == 2 ? (size_t)((q & 1) << 4) : (size_t)(q << 3);
+      char* outp = a.out + (size_t)opl * a.out_plane_bytes + sub;
+      const char* r1p = a.res1 ? a.res1 + (size_t)opl * a.r1_plane_bytes + sub : nullptr;
+      const char* r2p = a.res2 ? a.res2 + (size_t)opl * a.r2_plane_bytes + sub : nullptr;
+#pragma unroll
+      for (int mb = 0; mb < ROWS; ++mb)
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+          const int y = y0 + rg * ROWS + mb, x = x0 + 16 * pb + p;
+          const bool ok = (y < a.H) & (x < a.W);
+          const size_t rec = (((size_t)n * a.H + y) * a.W + x) * 32;
+          float v[NV];
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float t = acc[mb][pb][cb][i], neg = t * slope_v[PR ? 4 * cb + i : 0];
+              v[4 * cb + i] = (PR ? (t >= 0.f ? t : neg) : fmaxf(t, neg)) * alpha;   // one slope in [0,1] unless PReLU
+            }
+          if (r1p || r2p) {
+            float r1[NV], r2[NV];
+            if constexpr (CB == 2) {
+              const uint4 z = make_uint4(0, 0, 0, 0);
+              const uint4 u1 = (r1p && ok) ? *reinterpret_cast<const uint4*>(r1p + rec) : z;
+              const uint4 u2 = (r2p && ok) ? *reinterpret_cast<const uint4*>(r2p + rec) : z;
+              const __half* h1 = reinterpret_cast<const __half*>(&u1);
+              const __half* h2 = reinterpret_cast<const __half*>(&u2);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { r1[j] = __half2float(h1[j]); r2[j] = __half2float(h2[j]); }
+            } else {
+              const uint2 z = make_uint2(0, 0);
+              const uint2 u1 = (r1p && ok) ? *reinterpret_cast<const uint2*>(r1p + rec) : z;
+              const uint2 u2 = (r2p && ok) ? *reinterpret_cast<const uint2*>(r2p + rec) : z;
+              const __half* h1 = reinterpret_cast<const __half*>(&u1);
+              const __half* h2 = reinterpret_cast<const __half*>(&u2);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { r1[j] = __half2float(h1[j]); r2[j] = __half2float(h2[j]); }
+            }
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[j] = (v[j] + r1[j]) * gamma + r2[j];
+          }
+          if (ok) {
+            if constexpr (CB == 2) {
+              uint4 o;
+              __half* ho = reinterpret_cast<__half*>(&o);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) ho[j] = __float2half(v[j]);
+              __builtin_nontemporal_store(*reinterpret_cast<u32x4*>(&o), reinterpret_cast<u32x4*>(outp + rec));
+            } else {
+              uint2 o;
+              __half* ho = reinterpret_cast<__half*>(&o);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) ho[j] = __float2half(v[j]);
+              __builtin_nontemporal_store(*reinterpret_cast<u32x2*>(&o), reinterpret_cast<u32x2*>(outp + rec));
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);   // keep the rows' residual loads from being hoisted in front of the whole epilogue
+        }
+    }
+    // every store instruction of the tile was issued by this wave iff no row / pixel block lies wholly
+    // outside; residual loads make hipcc wait for (= drain) everything older anyway
+    prev_full = (y0 + TH <= a.H) && (x0 + TW <= a.W) && !(a.res1 || a.res2);
+    if (next_tile < 0) break;
+    tile = next_tile; ++kt; n = nn; y0 = ny0; x0 = nx0;
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) offc[j] = offn[j];
+    next_tile = tile_of(kt + 1);
+    if (next_tile >= 0) { setup_tile(next_tile, nn, ny0, nx0); tile_offsets(nn, ny0, nx0, offn); }
+  }
+  wait_vm<0>();   // the trailing (zero) prefetches must have landed before the workgroup's LDS is released
+}
+
+template <int NCH, int ROWS, int CB, bool PR>
+static void launch_t(ss4k_ctx* ctx, const ConvArgs& c, hipStream_t st) {
+  constexpr int RG = TH / ROWS, CG = 4 / RG, COUT_WG = CG * CB * 16;
+  constexpr size_t lds = (size_t)NSTAGE * STAGE;
+  RsArgs a{};
+  const int nplanes = c.nchunks0 + c.nchunks1;
+  for (int j = 0; j < MAX_PLANES; ++j) {
+    if (j < c.nchunks0) a.plane[j] = c.in0 + (size_t)(c.in0_plane0 + j) * c.in0_plane_bytes;
+    else if (j < nplanes) a.plane[j] = c.in1 + (size_t)(c.in1_plane0 + j - c.nchunks0) * c.in1_plane_bytes;
+    else a.plane[j] = nullptr;
+  }
+  a.zero_page = c.zero_page; a.wrs = c.wrs; a.bias = c.bias; a.prelu = c.prelu;
+  a.out = c.out + (size_t)c.out_plane0 * c.out_plane_bytes; a.out_plane_bytes = c.out_plane_bytes;
+  a.res1 = c.res1 ? c.res1 + (size_t)c.r1_plane0 * c.r1_plane_bytes : nullptr; a.r1_plane_bytes = c.r1_plane_bytes;
+  a.res2 = c.res2 ? c.res2 + (size_t)c.r2_plane0 * c.r2_plane_bytes : nullptr; a.r2_plane_bytes = c.r2_plane_bytes;
+  a.N = c.N; a.H = c.H; a.W = c.W; a.ups2 = c.ups2; a.reverse = c.reverse;
+  a.tiles_x = (c.W + TW - 1) / TW;
+  a.tiles_y = (c.H + TH - 1) / TH;
+  a.slope = c.act == ACT_LRELU ? c.slope : 1.f; a.alpha = c.alpha; a.gamma = c.gamma;
+  const int groups = c.cout_pad / COUT_WG;
+  const int ntiles = a.N * a.tiles_y * a.tiles_x;
+  const void* fn = reinterpret_cast<const void*>(&conv3x3_rs_kernel<NCH, ROWS, CB, PR>);
+  if (ctx->lds_attr_set.insert(fn).second)
+    SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int gx = std::min(ntiles, std::max(1, ctx->num_cu / groups));
+  hipLaunchKernelGGL((conv3x3_rs_kernel<NCH, ROWS, CB, PR>), dim3(gx, groups), dim3(256), lds, st, a);
+  SS4K_HIP(hipGetLastError());
+}
+
+}  // namespace rs
+
+// Layer shapes the register-stationary kernel is built for: (32-channel chunks, couts) -> <NCH, ROWS, CB>
+bool rs_config(int nplanes, int cout_pad, int* nch, int* rows, int* cb) {
+  const int c = (nplanes + 1) / 2;
+  if (cout_pad == 32 && c >= 2 && c <= 4) { *nch = c; *rows = 4; *cb = 2; return true; }
+  if (cout_pad == 32 && c == 5) { *nch = 5; *rows = 8; *cb = 1; return true; }
+  if (cout_pad == 64 && c == 2) { *nch = 2; *rows = 8; *cb = 2; return true; }
+  if (cout_pad == 64 && c == 6) { *nch = 6; *rows = 16; *cb = 1; return true; }
+  return false;
+}
+
+void launch_conv3x3_rs(ss4k_ctx* ctx, const ConvArgs& a, hipStream_t st) {
+  int nch, rows, cb;
+  SS4K_REQUIRE(rs_config(a.nchunks0 + a.nchunks1, a.cout_pad, &nch, &rows, &cb), "conv3x3_rs: unsupported layer shape");
+  SS4K_REQUIRE(a.wrs && a.epi == EPI_NHWC && !a.bsvd_resid && a.act != ACT_RELU6, "conv3x3_rs: unsupported epilogue");
+  SS4K_REQUIRE(a.act != ACT_PRELU || (rows == 8 && cb == 2), "conv3x3_rs: PReLU is built for the 64->64 shape only");
+  SS4K_REQUIRE(a.act != ACT_LRELU || (a.slope >= 0.f && a.slope <= 1.f), "conv3x3_rs: LeakyReLU slope must be in [0,1]");
+  if (cb == 2 && rows == 4) {
+    if (nch == 2) rs::launch_t<2, 4, 2, false>(ctx, a, st);
+    else if (nch == 3) rs::launch_t<3, 4, 2, false>(ctx, a, st);
+    else rs::launch_t<4, 4, 2, false>(ctx, a, st);
+  } else if (rows == 8 && cb == 1) rs::launch_t<5, 8, 1, false>(ctx, a, st);
+  else if (rows == 8 && cb == 2) {
+    if (a.act == ACT_PRELU) rs::launch_t<2, 8, 2, true>(ctx, a, st); else rs::launch_t<2, 8, 2, false>(ctx, a, st);
+  } else rs::launch_t<6, 16, 1, false>(ctx, a, st);
+}
+
+}  // namespace ss4k

@@ -100,7 +100,7 @@ static void upload(DevBuf& b, const void* src, size_t bytes) {
   SS4K_HIP(hipMemcpy(b.ptr, src, bytes, hipMemcpyHostToDevice));
 }
 
-int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool has_prelu_after) {
+int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool has_prelu_after, bool allow_rs) {
   s.dtype = desc.dtype; s.cout_real = cout; s.cin_total = cin_total;
   const float* w = pc.take((size_t)cout * cin_total * 9);
   const float* b = pc.take(cout);
@@ -110,6 +110,12 @@ int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool h
   upload(L.w, p.w.data(), p.w.size());
   upload(L.bias, p.bias.data(), p.bias.size() * 4);
   if (a) upload(L.prelu, p.prelu.data(), p.prelu.size() * 4);
+  int nch, rows, cb;
+  if (allow_rs && use_rs && desc.dtype == SS4K_F16 && rs_config(s.nchunks0 + s.nchunks1, p.cout_pad, &nch, &rows, &cb)) {
+    const std::vector<uint8_t> wr = pack_conv3x3_rs(s, w, p.cout_pad, nch, rows, cb);
+    upload(L.wrs, wr.data(), wr.size());
+    weight_bytes += wr.size();
+  }
   L.has_prelu = a != nullptr;
   L.cout_real = cout; L.cout_pad = p.cout_pad; L.nchunks0 = s.nchunks0; L.nchunks1 = s.nchunks1;
   L.cin_real = 0;
@@ -161,6 +167,7 @@ void Model::build(const float* w, size_t n) {
   validate_desc(desc);
   if (const char* e = std::getenv("SS4K_NO_FLIP")) flip_walk = !(e[0] == '1');  // A/B switch for the tile-walk direction
   if (const char* e = std::getenv("SS4K_SUBBATCH")) sub_batch = std::atoi(e);   // A/B switch: frames per pass through the network
+  if (const char* e = std::getenv("SS4K_NO_RS")) use_rs = !(e[0] == '1');        // A/B switch: LDS-weights kernel for every layer
   SS4K_REQUIRE(n == model_param_count(desc), "weight blob size does not match the model description");
   ParamCursor pc{w, n};
   if (desc.kind == SS4K_FSRCNN) {
@@ -207,14 +214,14 @@ void Model::build(const float* w, size_t n) {
       for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 5; ++c) {
           const int co = c < 4 ? g : nf;
-          add_conv(pc, co, nf + c * g, c == 0 ? spec_plain(nf) : spec_concat(nf, c * g), false);
+          add_conv(pc, co, nf + c * g, c == 0 ? spec_plain(nf) : spec_concat(nf, c * g), false, /*allow_rs=*/true);
         }
-    for (int i = 0; i < 4; ++i) add_conv(pc, nf, nf, spec_plain(nf), false);
+    for (int i = 0; i < 4; ++i) add_conv(pc, nf, nf, spec_plain(nf), false, /*allow_rs=*/true);
     add_conv(pc, 3, nf, spec_plain(nf), false);
   } else if (desc.kind == SS4K_SRVGG) {
     const int nf = desc.num_feat;
     add_conv(pc, nf, 3, spec_plain(3), true);
-    for (int i = 0; i < desc.num_block; ++i) add_conv(pc, nf, nf, spec_plain(nf), true);
+    for (int i = 0; i < desc.num_block; ++i) add_conv(pc, nf, nf, spec_plain(nf), true, /*allow_rs=*/true);
     add_conv(pc, 3 * desc.scale * desc.scale, nf, spec_plain(nf), false);
   } else {  // BSVD
     for (int blk = 0; blk < 2; ++blk) {
@@ -240,7 +247,7 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
   if (in1) { a.in1 = in1->p; a.in1_plane_bytes = in1->plane_bytes; a.in1_plane0 = in1->plane0; a.nchunks1 = L.nchunks1; }
   SS4K_REQUIRE((in1 != nullptr) == (L.nchunks1 > 0), "internal: conv segment mismatch");
   a.N = N; a.H = H; a.W = W; a.ups2 = o.ups2;
-  a.wpk = L.w.ptr; a.bias = L.bias.as<float>(); a.prelu = L.has_prelu ? L.prelu.as<float>() : nullptr;
+  a.wpk = L.w.ptr; a.wrs = L.wrs.ptr; a.bias = L.bias.as<float>(); a.prelu = L.has_prelu ? L.prelu.as<float>() : nullptr;
   a.act = o.act; a.slope = o.slope; a.alpha = o.alpha; a.gamma = o.gamma;
   if (o.res1) { a.res1 = o.res1->p; a.r1_plane_bytes = o.res1->plane_bytes; a.r1_plane0 = o.res1->plane0; }
   if (o.res2) { a.res2 = o.res2->p; a.r2_plane_bytes = o.res2->plane_bytes; a.r2_plane0 = o.res2->plane0; }

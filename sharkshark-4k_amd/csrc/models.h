@@ -10,6 +10,7 @@ struct Tens { char* p; size_t plane_bytes; int plane0; };
 
 struct ConvLayer {
   DevBuf w, bias, prelu;
+  DevBuf wrs;              // conv_rs.hip weight order (fp16 layers of a supported shape, else empty)
   bool has_prelu = false;
   int cout_real = 0, cout_pad = 0, cin_real = 0, nchunks0 = 0, nchunks1 = 0;
 };
@@ -49,13 +50,14 @@ struct Model {
   void forward(const float* in, float* out, int n, int h, int w, hipStream_t st);
   void out_shape(int n, int h, int w, int* oc, int* oh, int* ow) const;
   int in_channels() const;
+  bool use_rs = true;      // route eligible fp16 layers to the register-stationary kernel (SS4K_NO_RS=1: A/B switch)
   ~Model() {
-    for (auto& l : layers) { l.w.release(); l.bias.release(); l.prelu.release(); }
+    for (auto& l : layers) { l.w.release(); l.bias.release(); l.prelu.release(); l.wrs.release(); }
     for (auto& a : acts) a.release();
     fs_blob.release();
   }
 
-  int add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec spec, bool has_prelu_after);
+  int add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec spec, bool has_prelu_after, bool allow_rs = false);
   PackSpec spec_plain(int cin_real, int ps2 = 0) const;
   PackSpec spec_concat(int c0, int c1) const;
   PackSpec spec_masked(int c) const;

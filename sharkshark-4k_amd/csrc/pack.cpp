@@ -82,4 +82,40 @@ PackedConv pack_conv3x3(const PackSpec& s, const float* w, const float* bias, co
   return p;
 }
 
+// conv_rs.hip: every wave holds its slice of the layer's weights in registers as v_mfma_f32_16x16x32_f16
+// A fragments.  Order [group][cout group cg][32-channel chunk c][tap dy*3+dx][cb][lane][8 fp16]:
+//   lane l: cout row m = l & 15 of block cb, k-group kq = l >> 4; element e: channel 8*kq + e of the chunk
+//   (= plane 2c + (kq >> 1), channel 8*(kq & 1) + e of that plane).  Row m of block cb of cout group cg is
+//   virtual cout  g*COUT_WG + cg*cb_count*16 + (cb_count == 2 ? 8*(m >> 2) + 4*cb + (m & 3) : m)  so that
+//   result lane (pixel, q) holds cb_count*4 CONSECUTIVE channels (16- or 8-byte stores).
+std::vector<uint8_t> pack_conv3x3_rs(const PackSpec& s, const float* w, int cout_pad, int nch, int rows, int cbn) {
+  SS4K_REQUIRE(s.dtype == SS4K_F16, "pack_conv3x3_rs: fp16 only");
+  const int nplanes = s.nchunks0 + s.nchunks1;
+  SS4K_REQUIRE((int)s.cin_map.size() == nplanes * 16 && nplanes <= 2 * nch, "pack_conv3x3_rs: cin_map size");
+  const int RG = 16 / rows, CG = 4 / RG, COUT_WG = CG * cbn * 16;
+  SS4K_REQUIRE(cout_pad % COUT_WG == 0, "pack_conv3x3_rs: cout_pad");
+  const int groups = cout_pad / COUT_WG;
+  std::vector<uint8_t> out((size_t)groups * CG * nch * 9 * cbn * 64 * 8 * 2, 0);
+  size_t idx = 0;
+  for (int g = 0; g < groups; ++g)
+    for (int cg = 0; cg < CG; ++cg)
+      for (int c = 0; c < nch; ++c)
+        for (int t = 0; t < 9; ++t)
+          for (int cb = 0; cb < cbn; ++cb)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int m = lane & 15, kq = lane >> 4;
+              const int vl = cbn == 2 ? 8 * (m >> 2) + 4 * cb + (m & 3) : m;
+              const int co = virt_to_real_cout(s, g * COUT_WG + cg * cbn * 16 + vl);
+              for (int e = 0; e < 8; ++e, ++idx) {
+                const int plane = 2 * c + (kq >> 1), ch = 8 * (kq & 1) + e;
+                const int ci = plane < nplanes ? s.cin_map[(size_t)plane * 16 + ch] : -1;
+                float val = 0.f;
+                if (ci >= 0 && co >= 0) val = w[((size_t)co * s.cin_total + ci) * 9 + t];
+                const uint16_t h = f32_to_f16_bits(val);
+                std::memcpy(&out[idx * 2], &h, 2);
+              }
+            }
+  return out;
+}
+
 }  // namespace ss4k

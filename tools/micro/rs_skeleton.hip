@@ -1,0 +1,154 @@
+// Dev tool (round 2): ceiling of a REGISTER-STATIONARY-WEIGHTS conv loop on v_mfma_f32_16x16x32_f16.
+//
+// Question (VERDICT r1 "next" 2a + 2c): the 16x16x32 MFMA shape holds a 13 % higher clock than 32x32x16
+// (tools/micro/mfma_shapes.hip), but its K = 32 needs two 16-channel planes per MFMA, which doubles the
+// LDS halo stage and does not fit two workgroups per CU next to double-buffered weights.  Alternative
+// structure measured here: ONE 4-wave workgroup per CU (one wave per SIMD, 512 registers each), the
+// layer's weights held in registers for the life of the persistent workgroup (no weight DMA, no weight
+// LDS reads), LDS holds only a ring of 32-channel halo stages (18x34 pixels x 64 B = 38.25 KB) filled by
+// LDS-DMA several chunks ahead; one barrier per chunk.
+//   <NCH, ROWS, CB>: 32-channel chunks per layer, output rows per wave, 16-cout blocks per wave
+//   conv1..3 of an RDB: <2|3|4, 4, 2>   conv4: <5, 8, 1>   conv5 (192->64): <6, 16, 1>
+// Reports TFLOP/s (wall), in-kernel clock and MFMA-pipe utilisation in cycles, with the DMA source
+// either a 2 MB L2-resident window or a 2 GB stream.
+// hipcc --offload-arch=gfx950 -O3 rs_skeleton.hip -o rs_skeleton
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+struct Res { unsigned long long cyc, rt; };
+constexpr int STAGE = 18 * 34 * 64;             // 39168 B
+constexpr int NDMA = (STAGE / 1024 + 4) / 4;    // wave-level 1 KB DMA instructions per wave per stage (10)
+__device__ __forceinline__ void dma16(const void* g, unsigned lds) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+}
+__global__ void k_fill(uint32_t* p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t s = (uint32_t)i * 2654435761u; s ^= s >> 15; s *= 2246822519u; s ^= s >> 13;
+    p[i] = (s & 0x83FF83FFu) | 0x38003800u;
+  }
+}
+template <int NCH, int ROWS, int CB, int NSTAGE>
+__global__ __launch_bounds__(256, 1) void k(const uint4* __restrict__ wsrc, const char* __restrict__ buf, size_t span,
+                                            float* out, int ntiles, Res* res) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint4 W[NCH][9][CB];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) W[c][t][cb] = wsrc[(((c * 9 + t) * CB + cb) * 64 + lane) & 4095];
+  for (int i = threadIdx.x; i < NSTAGE * STAGE / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = wsrc[i & 4095];
+  __syncthreads();
+  const int rowbase = (ROWS == 16 ? 0 : wave * ROWS % 16);
+  const char* rd = smem + lane * 16 + rowbase * 2176;
+  size_t pos = ((size_t)blockIdx.x * 4 + wave) * 1024;
+  const size_t stride = (size_t)gridDim.x * 4 * 1024;
+  int g = 0;  // global chunk counter: stage slot = g % NSTAGE; DMA runs NSTAGE-1 chunks ahead
+  unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    f32x4 acc[ROWS][2][CB];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) for (int j = 0; j < 2; ++j) for (int c = 0; c < CB; ++c) for (int e = 0; e < 4; ++e) acc[i][j][c][e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c, ++g) {
+      const int slot = g % NSTAGE, fill = (g + NSTAGE - 1) % NSTAGE;
+      const char* st = rd + slot * STAGE;
+      const unsigned dst = lds0 + fill * STAGE;
+      int dma_i = 0;
+      constexpr int NM = 3 * (ROWS + 2);   // (dx, input row) steps per chunk
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+        for (int ir = 0; ir < ROWS + 2; ++ir) {
+          uint4 b[2];
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) b[pb] = *reinterpret_cast<const uint4*>(st + ir * 2176 + pb * 1024 + dx * 64);
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const int mb = ir - dy;
+            if (mb >= 0 && mb < ROWS) {
+#pragma unroll
+              for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+                  acc[mb][pb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&W[c][dy * 3 + dx][cb]),
+                                                                           *reinterpret_cast<const f16x8*>(&b[pb]), acc[mb][pb][cb], 0, 0, 0);
+            }
+          }
+          // spread this wave's NDMA DMA instructions for the stage NSTAGE-1 chunks ahead over the chunk
+          const int step = dx * (ROWS + 2) + ir;
+          if (dma_i < NDMA && step * NDMA >= dma_i * NM) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int kk = wave + 4 * dma_i;
+            if (kk * 1024 < STAGE) dma16(buf + (pos & (span - 1)) + lane * 16, dst + kk * 1024);
+            pos += stride;
+            ++dma_i;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      // next chunk's stage was issued NSTAGE-2 chunks ago: leave the younger (NSTAGE-2) stages in flight
+      if (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (NSTAGE == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * NDMA) : "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) for (int j = 0; j < 2; ++j) for (int c = 0; c < CB; ++c) for (int e = 0; e < 4; ++e) s += acc[i][j][c][e];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 17) { res->cyc = t1 - t0; res->rt = r1 - r0; }
+}
+template <int NCH, int ROWS, int CB, int NSTAGE>
+void run(const uint4* w, const char* buf, size_t span, float* out, Res* res, const char* what) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int ntiles = 6000 / NCH, grid = 256;
+  const void* fn = reinterpret_cast<const void*>(&k<NCH, ROWS, CB, NSTAGE>);
+  hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE);
+  const double mfma_per_wave = (double)ntiles * NCH * 9 * ROWS * 2 * CB;
+  float ms = 0;
+  hipEventRecord(e0);
+  do {
+    hipLaunchKernelGGL((k<NCH, ROWS, CB, NSTAGE>), dim3(grid), dim3(256), NSTAGE * STAGE, 0, w, buf, span, out, ntiles, res);
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+  } while (ms < 1500.0);
+  hipEventRecord(e0);
+  const int reps = 4;
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<NCH, ROWS, CB, NSTAGE>), dim3(grid), dim3(256), NSTAGE * STAGE, 0, w, buf, span, out, ntiles, res);
+  hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+  Res r; hipMemcpy(&r, res, sizeof(Res), hipMemcpyDeviceToHost);
+  const double tf = grid * 4 * mfma_per_wave * 16384.0 * reps / ms / 1e9;
+  printf("%-34s <NCH %d, rows %2d, cb %d, stages %d> %6.0f TFLOP/s  clock %4.0f MHz  MFMA-pipe %4.1f %% of cycles  DMA %4.1f B per 32K-FLOP\n", what, NCH, ROWS, CB,
+         NSTAGE, tf, (double)r.cyc / r.rt * 100.0, 100.0 * mfma_per_wave * 16.0 / (double)r.cyc, (double)STAGE / (4.0 * 9 * ROWS * 2 * CB / 2));
+  fflush(stdout);
+}
+int main() {
+  std::vector<uint32_t> h(4096 * 4);
+  uint32_t s = 1;
+  for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (s & 0x83FF83FFu) | 0x38003800u; }
+  uint4* w; hipMalloc(&w, h.size() * 4); hipMemcpy(w, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  char* big; const size_t BIG = 2048ull << 20; hipMalloc(&big, BIG);
+  hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, reinterpret_cast<uint32_t*>(big), BIG / 4); hipDeviceSynchronize();
+  float* out; Res* res; hipMalloc(&out, 1 << 22); hipMalloc(&res, sizeof(Res));
+  for (int rep = 0; rep < 2; ++rep) {
+    run<4, 4, 2, 3>(w, big, 2u << 20, out, res, "conv3 shape, DMA from L2 window");
+    run<4, 4, 2, 3>(w, big, BIG, out, res, "conv3 shape, DMA from 2 GB stream");
+    run<4, 4, 2, 4>(w, big, BIG, out, res, "conv3 shape, DMA from 2 GB stream");
+    run<2, 4, 2, 3>(w, big, BIG, out, res, "conv1 shape, DMA from 2 GB stream");
+    run<5, 8, 1, 3>(w, big, BIG, out, res, "conv4 shape, DMA from 2 GB stream");
+    run<6, 16, 1, 3>(w, big, 2u << 20, out, res, "conv5 shape, DMA from L2 window");
+    run<6, 16, 1, 3>(w, big, BIG, out, res, "conv5 shape, DMA from 2 GB stream");
+    run<2, 8, 2, 3>(w, big, BIG, out, res, "64->64 shape, DMA from 2 GB stream");
+  }
+  return 0;
+}
