@@ -18,7 +18,8 @@ extern "C" {
  *        the timing-only ablations 1 (no output stores), 2 (every DMA reads one hot line), 16 (with 1:
  *        halo tiles from a 2 MB L2-resident window) - results are garbage in those builds;
  *        | shape_id << 8 selects another compiled tile shape (conv_mfma.hip, launch_conv3x3);
- *        | 2048 makes it conv5 of an RDB (no activation, out = conv * 0.2 + x). */
+ *        | 2048 makes it conv5 of an RDB (no activation, out = conv * 0.2 + x);
+ *        | 4096 runs the register-stationary kernel (conv_rs.hip) where the layer shape is built for it. */
 int ss4k_bench_conv(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, int n, int h, int w, int flags,
                     int iters, double* avg_us, void* hip_stream);
 

@@ -27,6 +27,7 @@
 // are interchangeable per layer; the fp32 parity path, the first / last layers and the BSVD epilogues stay
 // on conv_mfma.hip.
 #include "common.h"
+#include <type_traits>
 
 namespace ss4k {
 namespace rs {
@@ -83,8 +84,13 @@ __device__ __forceinline__ void mfma16(f32x4& acc, const u32x4& w, const u32x4& 
 // (16 pixels x 4 k-groups per wave) is bank-conflict free for all three tap columns
 __device__ __forceinline__ int swz(int col) { return ((col >> 2) & 1) << 1; }
 
-// PR: per-channel PReLU slopes (SRVGG); otherwise one LeakyReLU slope / identity for the whole layer
-template <int NCH, int ROWS, int CB, bool PR>
+// PR: per-channel PReLU slopes (SRVGG); otherwise one LeakyReLU slope / identity for the whole layer.
+// RL: res1 is the layer's own input tensor (conv5 of an RDB: out = conv * 0.2 + x) and there is no activation:
+//     x's centre pixels are already in LDS as part of K-chunks 0 / 1, so they are added to the accumulators
+//     there (scaled by 1 / alpha) instead of being read from HBM a second time in the epilogue - at one wave
+//     per SIMD nothing would hide that latency.
+// RES: the epilogue reads residual(s) from memory (res1 unless RL, res2); built only where a network needs it.
+template <int NCH, int ROWS, int CB, bool PR, bool RL, bool RES>
 __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
   constexpr int RG = TH / ROWS, CG = 4 / RG, COUT_WG = CG * CB * 16;
   constexpr int NV = CB * 4;                  // output channels per lane and pixel
@@ -95,6 +101,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
   constexpr int NA = (216 / (36 * CB)) < NCH ? (216 / (36 * CB)) : NCH;
   static_assert(NCH >= 2 && 2 * NCH <= MAX_PLANES, "the two-chunks-ahead prefetch needs at least two K-chunks per tile");
   static_assert(ROWS * 2 * CB * 4 + (NCH - NA) * 36 * CB <= 160, "VGPR budget: accumulators + VGPR-resident weights");
+  static_assert(!RL || (CB == 1 && ROWS == 16), "RL is built for the conv5 shape: a wave owns one output plane of the whole tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -256,6 +263,28 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
       const int fill = slot == 0 ? 2 : slot - 1;   // (slot + 2) % 3: the slot read during the previous chunk
       const char* sb = smem + slot * STAGE;
 
+      if constexpr (RL) {
+        // this wave's output plane cg is plane cg of x = half (cg & 1) of K-chunk cg >> 1: when that chunk is the
+        // one in `slot`, add x / alpha at the tile's centre pixels (halo row mb + 1, column 16*pb + p + 1)
+        if (c < 2 && (cg >> 1) == c) {
+          const float inv_alpha = 1.f / a.alpha;
+          const int dg = 2 * (cg & 1) + (q >> 1);
+#pragma unroll
+          for (int mb = 0; mb < ROWS; ++mb) {
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+              const int col = 16 * pb + p + 1;
+              const u32x2 u = *reinterpret_cast<const u32x2*>(sb + (mb + 1) * ROWB + col * PIXB + ((dg ^ swz(col)) << 4) + ((q & 1) << 3));
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                acc[mb][pb][0][i] += __half2float(__ushort_as_half((unsigned short)((u[i >> 1] >> (16 * (i & 1))) & 0xffffu))) * inv_alpha;
+            }
+            if ((mb & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four rows of reads in flight at a time (registers)
+          }
+          asm volatile("s_nop 4");   // VALU-written accumulators -> MFMA
+        }
+      }
+
       u32x4 bf[3][2];   // B fragments of three consecutive steps (two-step read-ahead)
       auto ldb = [&](int s) {
         const int dx = s / (ROWS + 2), ir = s % (ROWS + 2);
@@ -298,72 +327,83 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
     asm volatile("s_nop 15");  // last MFMA's result -> first VALU read in the epilogue
 
     // ---------------- epilogue: activation, residuals, fp16 stores (no LDS use) ----------------
-    // lane (p, q) holds, per row mb and pixel block pb, channels cout0 + NV*q .. + NV-1 of pixel 16*pb + p
+    // lane (p, q) holds, per row mb and pixel block pb, channels cout0 + NV*q .. + NV-1 of pixel 16*pb + p.
+    // Residuals still read from memory are fetched RB rows at a time (all loads of a batch first: one exposed
+    // round trip per batch, not per row - nothing else runs on this SIMD).
     {
       const float alpha = a.alpha, gamma = a.gamma;
-      const int opl = cout0 / 16 + (CB == 2 ? (q >> 1) : 0);
-      const size_t sub = CB == 2 ? (size_t)((q & 1) << 4) : (size_t)(q << 3);
+      // the per-lane plane pointers depend only on kernel arguments: behind an opaque copy of q they are
+      // re-derived per tile instead of being carried (and spilled) across the MFMA loop
+      int qe = q;
+      asm volatile("" : "+v"(qe));
+      const int opl = cout0 / 16 + (CB == 2 ? (qe >> 1) : 0);
+      const size_t sub = CB == 2 ? (size_t)((qe & 1) << 4) : (size_t)(qe << 3);
       char* outp = a.out + (size_t)opl * a.out_plane_bytes + sub;
-      const char* r1p = a.res1 ? a.res1 + (size_t)opl * a.r1_plane_bytes + sub : nullptr;
+      const char* r1p = (a.res1 && !RL) ? a.res1 + (size_t)opl * a.r1_plane_bytes + sub : nullptr;
       const char* r2p = a.res2 ? a.res2 + (size_t)opl * a.r2_plane_bytes + sub : nullptr;
+      typedef typename std::conditional<CB == 2, u32x4, u32x2>::type rvec;   // NV fp16 channels
+      constexpr int RB = ROWS < 8 ? ROWS : 8;
 #pragma unroll
-      for (int mb = 0; mb < ROWS; ++mb)
+      for (int mb0 = 0; mb0 < ROWS; mb0 += RB) {
+        rvec u1[RES ? RB : 1][2], u2[RES ? RB : 1][2];
+        const bool any_res = RES && (r1p || r2p);
+        if constexpr (RES) if (any_res) {
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
-          const int y = y0 + rg * ROWS + mb, x = x0 + 16 * pb + p;
-          const bool ok = (y < a.H) & (x < a.W);
-          const size_t rec = (((size_t)n * a.H + y) * a.W + x) * 32;
-          float v[NV];
+          for (int j = 0; j < RB; ++j)
 #pragma unroll
-          for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float t = acc[mb][pb][cb][i], neg = t * slope_v[PR ? 4 * cb + i : 0];
-              v[4 * cb + i] = (PR ? (t >= 0.f ? t : neg) : fmaxf(t, neg)) * alpha;   // one slope in [0,1] unless PReLU
+            for (int pb = 0; pb < 2; ++pb) {
+              const int y = y0 + rg * ROWS + mb0 + j, x = x0 + 16 * pb + p;
+              const bool ok = (y < a.H) & (x < a.W);
+              const size_t rec = (((size_t)n * a.H + y) * a.W + x) * 32;
+              // out-of-image lanes read the tile's first pixel instead (always inside) and are never stored
+              const size_t rc = ok ? rec : (((size_t)n * a.H + y0) * a.W + x0) * 32;
+              u1[j][pb] = *reinterpret_cast<const rvec*>((r1p ? r1p : r2p) + rc);
+              u2[j][pb] = *reinterpret_cast<const rvec*>((r2p ? r2p : r1p) + rc);
             }
-          if (r1p || r2p) {
-            float r1[NV], r2[NV];
-            if constexpr (CB == 2) {
-              const uint4 z = make_uint4(0, 0, 0, 0);
-              const uint4 u1 = (r1p && ok) ? *reinterpret_cast<const uint4*>(r1p + rec) : z;
-              const uint4 u2 = (r2p && ok) ? *reinterpret_cast<const uint4*>(r2p + rec) : z;
-              const __half* h1 = reinterpret_cast<const __half*>(&u1);
-              const __half* h2 = reinterpret_cast<const __half*>(&u2);
-#pragma unroll
-              for (int j = 0; j < 8; ++j) { r1[j] = __half2float(h1[j]); r2[j] = __half2float(h2[j]); }
-            } else {
-              const uint2 z = make_uint2(0, 0);
-              const uint2 u1 = (r1p && ok) ? *reinterpret_cast<const uint2*>(r1p + rec) : z;
-              const uint2 u2 = (r2p && ok) ? *reinterpret_cast<const uint2*>(r2p + rec) : z;
-              const __half* h1 = reinterpret_cast<const __half*>(&u1);
-              const __half* h2 = reinterpret_cast<const __half*>(&u2);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) { r1[j] = __half2float(h1[j]); r2[j] = __half2float(h2[j]); }
-            }
-#pragma unroll
-            for (int j = 0; j < NV; ++j) v[j] = (v[j] + r1[j]) * gamma + r2[j];
-          }
-          if (ok) {
-            if constexpr (CB == 2) {
-              uint4 o;
-              __half* ho = reinterpret_cast<__half*>(&o);
-#pragma unroll
-              for (int j = 0; j < 8; ++j) ho[j] = __float2half(v[j]);
-              __builtin_nontemporal_store(*reinterpret_cast<u32x4*>(&o), reinterpret_cast<u32x4*>(outp + rec));
-            } else {
-              uint2 o;
-              __half* ho = reinterpret_cast<__half*>(&o);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) ho[j] = __float2half(v[j]);
-              __builtin_nontemporal_store(*reinterpret_cast<u32x2*>(&o), reinterpret_cast<u32x2*>(outp + rec));
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);   // keep the rows' residual loads from being hoisted in front of the whole epilogue
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < RB; ++j)
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) {
+            const int mb = mb0 + j;
+            const int y = y0 + rg * ROWS + mb, x = x0 + 16 * pb + p;
+            const bool ok = (y < a.H) & (x < a.W);
+            const size_t rec = (((size_t)n * a.H + y) * a.W + x) * 32;
+            float v[NV];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float t = acc[mb][pb][cb][i], neg = t * slope_v[PR ? 4 * cb + i : 0];
+                v[4 * cb + i] = (PR ? (t >= 0.f ? t : neg) : fmaxf(t, neg)) * alpha;   // one slope in [0,1] unless PReLU
+              }
+            if (any_res) {
+              const rvec w1 = u1[RES ? j : 0][pb], w2 = u2[RES ? j : 0][pb];
+              const float m1 = r1p ? 1.f : 0.f, m2 = r2p ? 1.f : 0.f;   // an absent residual is read as the other one, times 0
+#pragma unroll
+              for (int k = 0; k < NV; ++k) {
+                const unsigned b1 = (w1[k >> 1] >> (16 * (k & 1))) & 0xffffu, b2 = (w2[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+                v[k] = (v[k] + m1 * __half2float(__ushort_as_half((unsigned short)b1))) * gamma + m2 * __half2float(__ushort_as_half((unsigned short)b2));
+              }
+            } else if (RL) {
+#pragma unroll
+              for (int k = 0; k < NV; ++k) v[k] *= gamma;
+            }
+            if (ok) {
+              rvec o;
+#pragma unroll
+              for (int k = 0; k < NV; k += 2)
+                o[k >> 1] = (unsigned)__half_as_ushort(__float2half(v[k])) | ((unsigned)__half_as_ushort(__float2half(v[k + 1])) << 16);
+              __builtin_nontemporal_store(o, reinterpret_cast<rvec*>(outp + rec));
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     // every store instruction of the tile was issued by this wave iff no row / pixel block lies wholly
     // outside; residual loads make hipcc wait for (= drain) everything older anyway
-    prev_full = (y0 + TH <= a.H) && (x0 + TW <= a.W) && !(a.res1 || a.res2);
+    prev_full = (y0 + TH <= a.H) && (x0 + TW <= a.W) && !(RES && ((a.res1 && !RL) || a.res2));
     if (next_tile < 0) break;
     tile = next_tile; ++kt; n = nn; y0 = ny0; x0 = nx0;
 #pragma unroll
@@ -374,8 +414,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
   wait_vm<0>();   // the trailing (zero) prefetches must have landed before the workgroup's LDS is released
 }
 
-template <int NCH, int ROWS, int CB, bool PR>
+template <int NCH, int ROWS, int CB, bool PR, bool RL = false, bool RES = false>
 static void launch_t(ss4k_ctx* ctx, const ConvArgs& c, hipStream_t st) {
+  SS4K_REQUIRE(RES || ((RL || !c.res1) && !c.res2), "internal: conv3x3_rs build without residual support");
   constexpr int RG = TH / ROWS, CG = 4 / RG, COUT_WG = CG * CB * 16;
   constexpr size_t lds = (size_t)NSTAGE * STAGE;
   RsArgs a{};
@@ -395,11 +436,11 @@ static void launch_t(ss4k_ctx* ctx, const ConvArgs& c, hipStream_t st) {
   a.slope = c.act == ACT_LRELU ? c.slope : 1.f; a.alpha = c.alpha; a.gamma = c.gamma;
   const int groups = c.cout_pad / COUT_WG;
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
-  const void* fn = reinterpret_cast<const void*>(&conv3x3_rs_kernel<NCH, ROWS, CB, PR>);
+  const void* fn = reinterpret_cast<const void*>(&conv3x3_rs_kernel<NCH, ROWS, CB, PR, RL, RES>);
   if (ctx->lds_attr_set.insert(fn).second)
     SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int gx = std::min(ntiles, std::max(1, ctx->num_cu / groups));
-  hipLaunchKernelGGL((conv3x3_rs_kernel<NCH, ROWS, CB, PR>), dim3(gx, groups), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_rs_kernel<NCH, ROWS, CB, PR, RL, RES>), dim3(gx, groups), dim3(256), lds, st, a);
   SS4K_HIP(hipGetLastError());
 }
 
@@ -415,20 +456,35 @@ bool rs_config(int nplanes, int cout_pad, int* nch, int* rows, int* cb) {
   return false;
 }
 
+static bool cout_is_64(const ConvArgs& a) { return a.cout_pad == 64; }
+
 void launch_conv3x3_rs(ss4k_ctx* ctx, const ConvArgs& a, hipStream_t st) {
   int nch, rows, cb;
   SS4K_REQUIRE(rs_config(a.nchunks0 + a.nchunks1, a.cout_pad, &nch, &rows, &cb), "conv3x3_rs: unsupported layer shape");
   SS4K_REQUIRE(a.wrs && a.epi == EPI_NHWC && !a.bsvd_resid && a.act != ACT_RELU6, "conv3x3_rs: unsupported epilogue");
-  SS4K_REQUIRE(a.act != ACT_PRELU || (rows == 8 && cb == 2), "conv3x3_rs: PReLU is built for the 64->64 shape only");
+  SS4K_REQUIRE(a.act != ACT_PRELU || (rows == 8 && cb == 2 && !a.res1 && !a.res2), "conv3x3_rs: PReLU is built for the 64->64 shape without residuals only");
   SS4K_REQUIRE(a.act != ACT_LRELU || (a.slope >= 0.f && a.slope <= 1.f), "conv3x3_rs: LeakyReLU slope must be in [0,1]");
+  const bool res = a.res1 || a.res2;
+  SS4K_REQUIRE(!res || (cout_is_64(a)), "conv3x3_rs: residual epilogues are built for the 64-cout shapes only");
   if (cb == 2 && rows == 4) {
     if (nch == 2) rs::launch_t<2, 4, 2, false>(ctx, a, st);
     else if (nch == 3) rs::launch_t<3, 4, 2, false>(ctx, a, st);
     else rs::launch_t<4, 4, 2, false>(ctx, a, st);
   } else if (rows == 8 && cb == 1) rs::launch_t<5, 8, 1, false>(ctx, a, st);
   else if (rows == 8 && cb == 2) {
-    if (a.act == ACT_PRELU) rs::launch_t<2, 8, 2, true>(ctx, a, st); else rs::launch_t<2, 8, 2, false>(ctx, a, st);
-  } else rs::launch_t<6, 16, 1, false>(ctx, a, st);
+    if (a.act == ACT_PRELU) rs::launch_t<2, 8, 2, true>(ctx, a, st);
+    else if (res) rs::launch_t<2, 8, 2, false, false, true>(ctx, a, st);
+    else rs::launch_t<2, 8, 2, false>(ctx, a, st);
+  } else {
+    // conv5 of an RDB: res1 is the conv's own input tensor (segment 0, 4 planes) and there is no activation
+    const bool res_is_input = a.res1 && a.act == ACT_NONE && a.alpha != 0.f && a.nchunks0 == 4 && a.cout_pad == 64 &&
+                              a.res1 + (size_t)a.r1_plane0 * a.r1_plane_bytes == a.in0 + (size_t)a.in0_plane0 * a.in0_plane_bytes &&
+                              a.r1_plane_bytes == a.in0_plane_bytes && !a.ups2;
+    if (res_is_input && !a.res2) rs::launch_t<6, 16, 1, false, true, false>(ctx, a, st);
+    else if (res_is_input) rs::launch_t<6, 16, 1, false, true, true>(ctx, a, st);
+    else if (res) rs::launch_t<6, 16, 1, false, false, true>(ctx, a, st);
+    else rs::launch_t<6, 16, 1, false>(ctx, a, st);
+  }
 }
 
 }  // namespace ss4k

@@ -451,12 +451,13 @@ double bench_conv_layer(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, 
                         int iters, hipStream_t st) {
   ss4k_model_desc d{}; d.kind = SS4K_RRDBNET; d.dtype = dtype; d.scale = 2; d.num_feat = 64; d.num_block = 1; d.num_grow_ch = 32;
   Model m; m.ctx = ctx; m.desc = d;
+  m.use_rs = (flags & 4096) != 0;   // 4096: the register-stationary kernel (conv_rs.hip) where the shape is built
   const int cin = cin0 + cin1;
   std::vector<float> blob((size_t)cout * cin * 9 + cout);
   uint32_t s = 12345;
   for (auto& v : blob) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0f * 0.02f - 0.01f; }
   ParamCursor pc{blob.data(), blob.size()};
-  const int li = m.add_conv(pc, cout, cin, cin1 ? m.spec_concat(cin0, cin1) : m.spec_plain(cin0), false);
+  const int li = m.add_conv(pc, cout, cin, cin1 ? m.spec_concat(cin0, cin1) : m.spec_plain(cin0), false, /*allow_rs=*/true);
   const size_t px = (size_t)n * h * w;
   Tens X = m.act(0, px, cin0), G = m.act(1, px, std::max(cin1, 32)), O = m.act(2, px, cout);
   {  // random operands: constant data lets the chip hold a higher clock than real frames do
@@ -474,7 +475,7 @@ double bench_conv_layer(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, 
   }
   ConvOpts o; o.act = ACT_LRELU; o.slope = 0.2f; o.out = O;
   if ((flags & 2048) && cout <= cin0) { o.act = ACT_NONE; o.alpha = 0.2f; o.res1 = &X; }  // conv5 of an RDB: x5 * 0.2 + x
-  m.dbg = flags & ~2048;
+  m.dbg = flags & ~(2048 | 4096);
   DevBuf dbgb; dbgb.ensure(1024 * 16 * 8); SS4K_HIP(hipMemsetAsync(dbgb.ptr, 0, 1024 * 16 * 8, st)); m.dbg_buf = dbgb.as<unsigned long long>();
   for (int i = 0; i < 3; ++i) m.conv(li, X, cin1 ? &G : nullptr, n, h, w, o, st);
   hipEvent_t e0, e1; SS4K_HIP(hipEventCreate(&e0)); SS4K_HIP(hipEventCreate(&e1));
