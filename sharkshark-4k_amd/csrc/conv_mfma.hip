@@ -167,9 +167,17 @@ __device__ __forceinline__ f32x16 mma(const uint4& w, const uint4& x, f32x16 acc
   }
 }
 
-// GEN = false: only the plain-layout epilogue is compiled (every RRDBNet / SRVGG body layer);
-// GEN = true adds the stride-2 / PixelShuffle / NCHW / BSVD-residual / ReLU6 epilogues.
-template <typename T, int NB, int MB, int NW, int DBG, bool GEN>
+// EK = epilogue kind the build is specialised for (a runtime switch between them costs registers - the all-in-one
+// build of round 1 spilled 52-68 bytes - and the kinds differ in the MFMA loop as well):
+//   EK_PLAIN   plain layout (every RRDBNet / SRVGG body layer, most BSVD layers): branch-free fast path
+//   EK_SUB2    stride-2 conv (BSVD downc0 / downc1): only the even output rows are computed (half the MFMAs of the
+//              stride-1 form), even pixels stored
+//   EK_PS2     PixelShuffle(2) (BSVD upc2 / upc1): the virtual cout order (pack.cpp) puts the two horizontal
+//              sub-pixels of an output row into the two planes of a 32-cout block, so a wave's two store
+//              instructions write one contiguous run of output records
+//   EK_GENERAL fp32 NCHW hand-off (network outputs), BSVD residual, anything else
+enum { EK_PLAIN = 0, EK_SUB2 = 1, EK_PS2 = 2, EK_GENERAL = 3 };
+template <typename T, int NB, int MB, int NW, int DBG, int EK>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>())) void conv3x3_kernel(const ConvArgs a) {
   using G = Geo<T, MB, NW>;
   constexpr int KS = G::KS, SPR = G::SPR, REC = G::REC, NG = 3 * KS;
@@ -375,8 +383,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
           for (int dy = 0; dy < 3; ++dy) {
             const int mb = ir - dy;
             if (mb >= 0 && mb < MB) {
+              if (!(EK == EK_SUB2 && (mb & 1))) {   // stride 2: odd output rows are never stored
 #pragma unroll
-              for (int nb = 0; nb < NB; ++nb) acc[nb][mb] = mma<T>(f.wf[dy][nb], f.af[ir], acc[nb][mb]);
+                for (int nb = 0; nb < NB; ++nb) acc[nb][mb] = mma<T>(f.wf[dy][nb], f.af[ir], acc[nb][mb]);
+              }
               if (m % SE == SE / 2 && g * (3 * MB / SE) + m / SE < NDMA) {
                 __builtin_amdgcn_sched_barrier(0);
                 dma_op(g * (3 * MB / SE) + m / SE);
@@ -420,8 +430,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
             for (int dy = 0; dy < 3; ++dy) {
               const int mb = ir - dy;
               if (mb >= 0 && mb < MB) {
+                if (!(EK == EK_SUB2 && (mb & 1))) {   // stride 2: odd output rows are never stored
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nb][mb] = mma<T>(f.wf[dy][nb], f.af[ir], acc[nb][mb]);
+                  for (int nb = 0; nb < NB; ++nb) acc[nb][mb] = mma<T>(f.wf[dy][nb], f.af[ir], acc[nb][mb]);
+                }
                 if (m % SE == SE / 2 && g * (3 * MB / SE) + m / SE < NDMA) {
                   __builtin_amdgcn_sched_barrier(0);
                   dma_op(g * (3 * MB / SE) + m / SE);
@@ -481,7 +493,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
     // Fast path (every RRDBNet / SRVGG body layer): plain layout, branch-free arithmetic
     //   v = act(acc) * alpha + res1;  v = v * gamma + res2      (absent residuals are zeros,
     // absent activation is slope 1, so the same instruction stream serves every such layer)
-    const bool fast_epi = !GEN || (a.epi == EPI_NHWC && !a.bsvd_resid);
+    constexpr bool GEN = EK == EK_GENERAL;
+    const bool fast_epi = EK == EK_PLAIN;
     // the epilogue's per-lane plane pointers depend only on kernel arguments: left alone, the
     // compiler computes them once before the tile loop and carries ~16 registers through the MFMA
     // loop (spilling in the 4-rows-per-wave builds).  Re-derive them per tile instead.
@@ -592,6 +605,65 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+    } else if constexpr (EK == EK_SUB2 || EK == EK_PS2) {
+      // activation (ReLU6 / LeakyReLU / PReLU / none), * alpha, [+ res1 at the output position], layout-aware store
+      const float alpha = a.alpha;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int blk = grp * NB + nb, vblock = blk * 32;
+        if (vblock >= a.cout_pad) continue;
+        float slope_v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 s4 = *reinterpret_cast<const float4*>(epi_lds + NB * 32 + nb * 32 + 16 * (q >> 1) + 8 * lhe + 4 * (q & 1));
+          slope_v[4 * q] = s4.x; slope_v[4 * q + 1] = s4.y; slope_v[4 * q + 2] = s4.z; slope_v[4 * q + 3] = s4.w;
+        }
+        const size_t sub = (size_t)lhe * HB;
+        // PS2: block blk holds output row parity dy, output channels oc0 .. oc0+15; its first plane is sub-pixel dx = 0,
+        // its second dx = 1 (virt_to_real_cout, pack.cpp).  SUB2: the block's two planes, as in the plain layout.
+        const int cpb = EK == EK_PS2 ? (a.cout_real >> 2) / CW : 1;          // 16-channel planes of the shuffled output
+        const int ps_dy = EK == EK_PS2 ? blk / cpb : 0;
+        const int opl = EK == EK_PS2 ? blk - ps_dy * cpb : vblock / CW;
+        char* outp = a.out + (size_t)(a.out_plane0 + opl) * a.out_plane_bytes + sub;
+        const char* r1p = a.res1 ? a.res1 + (size_t)(a.r1_plane0 + opl) * a.r1_plane_bytes + sub : nullptr;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          if (EK == EK_SUB2 && (mb & 1)) continue;
+          const int y = cur_y0 + wave * MB + mb;
+          bool ok = y < a.H && xo < a.W;
+          size_t opix0, ostep;   // first output record of this lane, distance (in records' planes) of the second one
+          if constexpr (EK == EK_SUB2) {
+            ok = ok && !(xo & 1);
+            opix0 = ((size_t)cur_n * ((a.H + 1) >> 1) + (y >> 1)) * ((a.W + 1) >> 1) + (xo >> 1);
+          } else {
+            opix0 = ((size_t)cur_n * 2 * a.H + 2 * y + ps_dy) * (2 * (size_t)a.W) + 2 * xo;
+          }
+          float v[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float t = acc[nb][mb][i];
+            if (a.act == ACT_RELU6) t = fminf(fmaxf(t, 0.f), 6.f);
+            else { const float neg = t * slope_v[i]; t = t >= 0.f ? t : neg; }
+            v[i] = t * alpha;
+          }
+          if (ok) {
+            // the lane's two 8-channel groups: PS2 -> the same channels of two horizontally adjacent output pixels
+            // (adjacent records of one plane); SUB2 -> the two planes of the block at one pixel
+            char* o0 = outp + opix0 * REC;
+            char* o1 = EK == EK_PS2 ? o0 + REC : o0 + a.out_plane_bytes;
+            if (r1p) {
+              float r[16];
+              const char* q0 = r1p + opix0 * REC;
+              load8<T>(q0, r); load8<T>(EK == EK_PS2 ? q0 + REC : q0 + a.r1_plane_bytes, r + 8);
+#pragma unroll
+              for (int i = 0; i < 16; ++i) v[i] += r[i];
+            }
+            store8<T>(o0, v);
+            store8<T>(o1, v + 8);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     } else if constexpr (GEN) {
       // general epilogue, one 8-channel half (hq) of a 32-cout block at a time
 #pragma unroll
@@ -650,17 +722,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
               for (int i = 0; i < 8; ++i) v[i] = fminf(fmaxf(v[i], 0.f), 6.f);
             }
             // where this 8-channel group lands
-            size_t opix = ipix; int oc = vbase; bool keep = true;
-            if (a.epi == EPI_NHWC_SUB2) {
-              keep = !((y | xo) & 1);
-              opix = ((size_t)cur_n * ((a.H + 1) >> 1) + (y >> 1)) * ((a.W + 1) >> 1) + (xo >> 1);
-            } else if (a.epi == EPI_NHWC_PS2) {
-              const int cp = a.cout_real >> 2, sub = vbase / cp;
-              oc = vbase - sub * cp;
-              opix = ((size_t)cur_n * 2 * a.H + 2 * y + (sub >> 1)) * (2 * a.W) + 2 * xo + (sub & 1);
-              keep = vbase < a.cout_real;
-            }
-            if (keep) {
+            const size_t opix = ipix; const int oc = vbase;   // (stride-2 / PixelShuffle layers have their own builds)
+            {
               if (a.alpha != 1.f) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] *= a.alpha;
@@ -737,7 +800,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
   }
 }
 
-template <typename T, int NB, int MB, int NW, int DBG, bool GEN>
+template <typename T, int NB, int MB, int NW, int DBG, int EK>
 static void launch_t(ss4k_ctx* ctx, const ConvArgs& a0, int groups, hipStream_t st) {
   using G = Geo<T, MB, NW>;
   constexpr size_t lds = lds_bytes<T, NB, MB, NW>();
@@ -746,11 +809,11 @@ static void launch_t(ss4k_ctx* ctx, const ConvArgs& a0, int groups, hipStream_t 
   ConvArgs a = a0;
   a.tiles_y = (a.H + G::TH - 1) / G::TH;
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
-  const void* fn = reinterpret_cast<const void*>(&conv3x3_kernel<T, NB, MB, NW, DBG, GEN>);
+  const void* fn = reinterpret_cast<const void*>(&conv3x3_kernel<T, NB, MB, NW, DBG, EK>);
   if (ctx->lds_attr_set.insert(fn).second)  // per context = per device
     SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int gx = std::min(ntiles, std::max(1, ctx->num_cu * per_cu / groups));
-  hipLaunchKernelGGL((conv3x3_kernel<T, NB, MB, NW, DBG, GEN>), dim3(gx, groups), dim3(64 * NW), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_kernel<T, NB, MB, NW, DBG, EK>), dim3(gx, groups), dim3(64 * NW), lds, st, a);
   SS4K_HIP(hipGetLastError());
 }
 
@@ -759,17 +822,17 @@ static void launch_t(ss4k_ctx* ctx, const ConvArgs& a0, int groups, hipStream_t 
 template <int NB, int MB, int NW>
 static void launch_dbg(ss4k_ctx* ctx, const ConvArgs& a, int groups, hipStream_t st) {
   switch (a.dbg & 0xff) {
-    case DBG_STAMP: launch_t<__half, NB, MB, NW, DBG_STAMP, false>(ctx, a, groups, st); break;
+    case DBG_STAMP: launch_t<__half, NB, MB, NW, DBG_STAMP, EK_PLAIN>(ctx, a, groups, st); break;
     // timing-only ablations of the memory traffic (results are garbage), see DESIGN.md 4.1:
     //   33: halo tiles from a 2 MB L2-resident window, no output stores   (no fabric traffic)
     //   49: real halo tiles, no output stores                             (no fabric writes)
     //   48: halo tiles from the 2 MB window, real stores                  (no fabric reads)
     //   34: every DMA instruction reads one hot cache line                (no L2 traffic either)
-    case DBG_STAMP | DBG_NO_STORE: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_STORE, false>(ctx, a, groups, st); break;
-    case DBG_STAMP | DBG_NO_STORE | DBG_NO_EPILOGUE: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_STORE | DBG_NO_EPILOGUE, false>(ctx, a, groups, st); break;
-    case DBG_STAMP | DBG_NO_EPILOGUE: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_EPILOGUE, false>(ctx, a, groups, st); break;
-    case DBG_STAMP | DBG_NO_MMA: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_MMA, false>(ctx, a, groups, st); break;
-    case 0: launch_t<__half, NB, MB, NW, 0, false>(ctx, a, groups, st); break;
+    case DBG_STAMP | DBG_NO_STORE: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_STORE, EK_PLAIN>(ctx, a, groups, st); break;
+    case DBG_STAMP | DBG_NO_STORE | DBG_NO_EPILOGUE: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_STORE | DBG_NO_EPILOGUE, EK_PLAIN>(ctx, a, groups, st); break;
+    case DBG_STAMP | DBG_NO_EPILOGUE: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_EPILOGUE, EK_PLAIN>(ctx, a, groups, st); break;
+    case DBG_STAMP | DBG_NO_MMA: launch_t<__half, NB, MB, NW, DBG_STAMP | DBG_NO_MMA, EK_PLAIN>(ctx, a, groups, st); break;
+    case 0: launch_t<__half, NB, MB, NW, 0, EK_PLAIN>(ctx, a, groups, st); break;
     default: throw Error(SS4K_EINVAL, "ss4k_bench_conv: flags are 0 or 32 (phase stamps), | tile-shape id << 8");
   }
 }
@@ -820,14 +883,20 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
 #endif
   {
     SS4K_REQUIRE(a.dbg == 0, "instrumented conv builds live in libss4k_hip_dev.so only");
-    const bool gen = !(a.epi == EPI_NHWC && !a.bsvd_resid);
-    if (dtype == SS4K_F16) {
-      if (nb == 1) { if (gen) launch_t<__half, 1, 4, 4, 0, true>(ctx, a, groups, st); else launch_t<__half, 1, 4, 4, 0, false>(ctx, a, groups, st); }
-      else { if (gen) launch_t<__half, 2, 4, 4, 0, true>(ctx, a, groups, st); else launch_t<__half, 2, 4, 4, 0, false>(ctx, a, groups, st); }
-    } else {
-      if (nb == 1) { if (gen) launch_t<float, 1, 4, 4, 0, true>(ctx, a, groups, st); else launch_t<float, 1, 4, 4, 0, false>(ctx, a, groups, st); }
-      else { if (gen) launch_t<float, 2, 4, 4, 0, true>(ctx, a, groups, st); else launch_t<float, 2, 4, 4, 0, false>(ctx, a, groups, st); }
+    const int ek = a.epi == EPI_NHWC_SUB2 ? EK_SUB2 : a.epi == EPI_NHWC_PS2 ? EK_PS2 : (a.epi == EPI_NHWC && !a.bsvd_resid) ? EK_PLAIN : EK_GENERAL;
+    SS4K_REQUIRE(ek == EK_PLAIN || ek == EK_GENERAL || (!a.res2 && !a.bsvd_resid), "conv3x3: stride-2 / PixelShuffle epilogues take res1 only");
+    SS4K_REQUIRE(ek != EK_SUB2 || !a.res1, "conv3x3: the stride-2 epilogue takes no residual");
+    SS4K_REQUIRE(ek != EK_PS2 || ((a.cout_real & 63) == 0 && a.cout_pad == a.cout_real), "conv3x3: PixelShuffle(2) needs a multiple of 64 output channels");
+#define SS4K_LAUNCH_EK(T_, NB_)                                                          \
+    switch (ek) {                                                                        \
+      case EK_PLAIN: launch_t<T_, NB_, 4, 4, 0, EK_PLAIN>(ctx, a, groups, st); break;     \
+      case EK_SUB2: launch_t<T_, NB_, 4, 4, 0, EK_SUB2>(ctx, a, groups, st); break;       \
+      case EK_PS2: launch_t<T_, NB_, 4, 4, 0, EK_PS2>(ctx, a, groups, st); break;         \
+      default: launch_t<T_, NB_, 4, 4, 0, EK_GENERAL>(ctx, a, groups, st); break;         \
     }
+    if (dtype == SS4K_F16) { if (nb == 1) { SS4K_LAUNCH_EK(__half, 1) } else { SS4K_LAUNCH_EK(__half, 2) } }
+    else { if (nb == 1) { SS4K_LAUNCH_EK(float, 1) } else { SS4K_LAUNCH_EK(float, 2) } }
+#undef SS4K_LAUNCH_EK
   }
   if (ctx->prof) {
     SS4K_HIP(hipEventRecord(pe.b, st));

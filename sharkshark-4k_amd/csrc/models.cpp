@@ -100,6 +100,9 @@ static void upload(DevBuf& b, const void* src, size_t bytes) {
   SS4K_HIP(hipMemcpy(b.ptr, src, bytes, hipMemcpyHostToDevice));
 }
 
+// bit of a layer shape in Model::rs_mask: 0-2 = 32 couts with 2/3/4 K-chunks (RDB conv1-3), 3 = conv4, 4 = 64->64, 5 = conv5
+static int rs_shape_bit(int nch, int cout_pad) { return cout_pad == 32 ? nch - 2 : (nch == 2 ? 4 : 5); }
+
 int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool has_prelu_after, bool allow_rs) {
   s.dtype = desc.dtype; s.cout_real = cout; s.cin_total = cin_total;
   const float* w = pc.take((size_t)cout * cin_total * 9);
@@ -111,7 +114,8 @@ int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool h
   upload(L.bias, p.bias.data(), p.bias.size() * 4);
   if (a) upload(L.prelu, p.prelu.data(), p.prelu.size() * 4);
   int nch, rows, cb;
-  if (allow_rs && use_rs && desc.dtype == SS4K_F16 && rs_config(s.nchunks0 + s.nchunks1, p.cout_pad, &nch, &rows, &cb)) {
+  if (allow_rs && use_rs && desc.dtype == SS4K_F16 && rs_config(s.nchunks0 + s.nchunks1, p.cout_pad, &nch, &rows, &cb) &&
+      (rs_mask >> rs_shape_bit(nch, p.cout_pad)) & 1) {
     const std::vector<uint8_t> wr = pack_conv3x3_rs(s, w, p.cout_pad, nch, rows, cb);
     upload(L.wrs, wr.data(), wr.size());
     weight_bytes += wr.size();
@@ -168,6 +172,7 @@ void Model::build(const float* w, size_t n) {
   if (const char* e = std::getenv("SS4K_NO_FLIP")) flip_walk = !(e[0] == '1');  // A/B switch for the tile-walk direction
   if (const char* e = std::getenv("SS4K_SUBBATCH")) sub_batch = std::atoi(e);   // A/B switch: frames per pass through the network
   if (const char* e = std::getenv("SS4K_NO_RS")) use_rs = !(e[0] == '1');        // A/B switch: LDS-weights kernel for every layer
+  if (const char* e = std::getenv("SS4K_RS_MASK")) rs_mask = std::atoi(e);       // A/B switch: which layer shapes take conv_rs.hip
   SS4K_REQUIRE(n == model_param_count(desc), "weight blob size does not match the model description");
   ParamCursor pc{w, n};
   if (desc.kind == SS4K_FSRCNN) {

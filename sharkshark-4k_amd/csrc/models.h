@@ -50,6 +50,7 @@ struct Model {
   void forward(const float* in, float* out, int n, int h, int w, hipStream_t st);
   void out_shape(int n, int h, int w, int* oc, int* oh, int* ow) const;
   int in_channels() const;
+  int rs_mask = 32;        // layer shapes routed to conv_rs.hip (bit per shape, models.cpp rs_shape_bit); default: RDB conv5
   bool use_rs = true;      // route eligible fp16 layers to the register-stationary kernel (SS4K_NO_RS=1: A/B switch)
   ~Model() {
     for (auto& l : layers) { l.w.release(); l.bias.release(); l.prelu.release(); l.wrs.release(); }

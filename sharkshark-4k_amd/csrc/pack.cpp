@@ -36,8 +36,14 @@ static inline uint16_t f32_to_f16_bits(float f) {
 int virt_to_real_cout(const PackSpec& s, int v) {
   if (v >= s.cout_real) return -1;
   if (s.ps2) {
-    const int cp = s.cout_real / 4, sub = v / cp, c = v - sub * cp;
-    return c * 4 + sub;
+    // PixelShuffle(2): real channel c*4 + dy*2 + dx lands at output channel c of pixel (2y+dy, 2x+dx).  Virtual
+    // order (conv_mfma.hip, EK_PS2): 32-cout block b = (dy, 16 output channels oc0..oc0+15); its first
+    // 16-channel plane is sub-pixel dx = 0, its second dx = 1 - so one lane holds the same 8 channels of two
+    // horizontally adjacent output pixels and a wave's stores cover whole runs of output records
+    const int cp = s.cout_real / 4, cpb = cp / 16;
+    const int b = v / 32, dx = (v >> 4) & 1, j = v & 15;
+    const int dy = b / cpb, c = 16 * (b - dy * cpb) + j;
+    return c * 4 + dy * 2 + dx;
   }
   return v;
 }
