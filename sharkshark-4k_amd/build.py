@@ -15,6 +15,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libss4k_hip.so")
 LIB_DEV = os.path.join(HERE, "libss4k_hip_dev.so")
 SOURCES = ["conv_mfma.hip", "conv_rs.hip", "glue.hip", "fsrcnn.hip", "pack.cpp", "models.cpp", "api.cpp"]
+# conv_rs.hip: the per-tile body is thousands of fully unrolled MFMAs (weights live in named registers); hipcc's
+# default cap on '#pragma unroll' size would leave the chunk loop rolled and the weights in scratch
+EXTRA_FLAGS = {"conv_rs.hip": ["-mllvm", "-pragma-unroll-threshold=4000000"]}
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-x", "hip", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable"]
 
@@ -50,7 +53,7 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
 
     def run(job):
         src, obj = job
-        cmd = [hipcc, *flags, "-c", src, "-o", obj]
+        cmd = [hipcc, *flags, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

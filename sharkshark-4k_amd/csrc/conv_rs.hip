@@ -43,7 +43,7 @@ constexpr int TILE_SLOTS = IN_H * IN_W * 4;  // 16-byte slots of a 32-channel ha
 constexpr int NDMA = (TILE_SLOTS + 255) / 256;     // wave-level 1 KB LDS-DMA instructions per wave and stage (10)
 constexpr int STAGE = NDMA * 4 * 1024;       // stage padded to a whole number of DMA instructions per wave: every
                                              // wave issues exactly NDMA per stage (exact counted waits, no EXEC masks)
-constexpr int NSTAGE = 3;                    // ring: one being read, two in flight (120 KB)
+constexpr int NSTAGE = 4;                    // ring: one being read, three in flight (all 160 KB of the CU)
 constexpr int MAX_PLANES = 12;
 
 // kernel arguments, reduced to what the kernel reads (scalar registers are scarce next to 100 address
@@ -78,6 +78,12 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 __device__ __forceinline__ void mfma16(f32x4& acc, const u32x4& w, const u32x4& b, bool WA) {  // WA folds after unrolling
   if (WA) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
   else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b));
+}
+
+// first MFMA of an accumulator in a tile: C = the bias quad (D is written whole, so acc needs no initialisation)
+__device__ __forceinline__ void mfma16_init(f32x4& acc, const u32x4& w, const u32x4& b, const f32x4& c, bool WA) {
+  if (WA) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(acc) : "a"(w), "v"(b), "v"(c));
+  else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(acc) : "v"(w), "v"(b), "v"(c));
 }
 
 // 16-byte slots of a pixel are XOR-swizzled by its column so that every ds_read_b128 of a B fragment
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
   // XCD gets a contiguous band of tiles.  Placement only changes speed, never results.
   const bool banded = (gridDim.x % 8 == 0) && ntiles >= (int)gridDim.x;
   const int tpx = (ntiles + 7) / 8;
-  auto tile_of = [&](int k) -> int {
+  auto tile_of = [&](int k) __attribute__((always_inline)) -> int {
     if (!banded) {
       const int t = blockIdx.x + k * gridDim.x;
       return t < ntiles ? (a.reverse ? ntiles - 1 - t : t) : -1;
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
     const int j = (blockIdx.x >> 3) + k * (gridDim.x >> 3);
     return j < len ? base + (a.reverse ? len - 1 - j : j) : -1;
   };
-  auto setup_tile = [&](int tile, int& n, int& y0, int& x0) {
+  auto setup_tile = [&](int tile, int& n, int& y0, int& x0) __attribute__((always_inline)) {
     const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
     const int ty = tyn % a.tiles_y;
     n = tyn / a.tiles_y; y0 = ty * TH; x0 = tx * TW;
@@ -195,109 +201,151 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
       off[j] = inside ? (uint32_t)(tn * Hs + sy) * (uint32_t)Ws + (uint32_t)sx : OOB;
     }
   };
-  // One wave-level DMA instruction (1 KB) into ring slot `slot`.  pA / pB: the chunk's two source planes
-  // (a missing plane = the zero page with record stride mul = 0, so the instruction stream has no branch).
-  auto dma_op = [&](int j, const char* pA, const char* pB, uint32_t mulA, uint32_t mulB, const uint32_t (&off)[NDMA], int slot) {
-    // behind an opaque copy: the selects below depend only on (lane, j, chunk), and hoisted out of the
-    // tile loop for every (j, chunk) pair they would hold 180 VGPRs
-    int pj = plan[j];
-    asm volatile("" : "+v"(pj));
-    const int dg = pj >> 16;
-    const bool second = (dg & 2) != 0, in = off[j] != OOB;
-    const char* base = second ? pB : pA;
-    const uint32_t mul = in ? (second ? mulB : mulA) : 0u;
-    const char* src = (in ? base : a.zero_page) + (size_t)off[j] * mul + (size_t)((dg & 1) << 4);
-    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + slot * STAGE + (wave + 4 * j) * 1024);
-    dma16(src, dst);
+  // One wave-level DMA instruction (1 KB) into a ring slot, issued in four parts that are placed between
+  // consecutive MFMAs (at one wave per SIMD a block of a dozen VALU in a row is a hole in the matrix pipe).
+  // pA / pB: the chunk's two source planes (a missing plane = the zero page with record stride mul = 0, so the
+  // instruction stream has no branch).
+  struct DmaState { int dg; bool second, in; const char* bsel; uint32_t mul, off; const char* src; };
+  DmaState ds{};
+  auto dma_part = [&](int part, int j, const char* pA, const char* pB, uint32_t mulA, uint32_t mulB, const uint32_t (&off)[NDMA],
+                      uint32_t fill_base) __attribute__((always_inline)) {
+    if (part == 0) {
+      // behind an opaque copy: the selects below depend only on (lane, j, chunk), and hoisted out of the
+      // tile loop for every (j, chunk) pair they would hold 180 VGPRs
+      int pj = plan[j];
+      asm volatile("" : "+v"(pj));
+      ds.dg = pj >> 16; ds.second = (ds.dg & 2) != 0; ds.off = off[j]; ds.in = ds.off != OOB;
+    } else if (part == 1) {
+      const char* base = ds.second ? pB : pA;
+      ds.mul = ds.in ? (ds.second ? mulB : mulA) : 0u;
+      ds.bsel = ds.in ? base : a.zero_page;
+    } else if (part == 2) {
+      ds.src = ds.bsel + (size_t)ds.off * ds.mul + (size_t)((ds.dg & 1) << 4);
+    } else {
+      dma16(ds.src, __builtin_amdgcn_readfirstlane(fill_base + j * 4096));
+    }
   };
 
-  int kt = 0, tile = tile_of(0);
-  if (tile < 0) return;
-  int n, y0, x0, nn = 0, ny0 = 0, nx0 = 0;
-  uint32_t offc[NDMA], offn[NDMA];
-  setup_tile(tile, n, y0, x0);
-  tile_offsets(n, y0, x0, offc);
-  int next_tile = tile_of(1);
-  if (next_tile >= 0) { setup_tile(next_tile, nn, ny0, nx0); tile_offsets(nn, ny0, nx0, offn); }
-  auto plane_or_zero = [&](int j, bool on, const char*& ptr, uint32_t& mul) {
+  // tiles in flight: [0] the one being computed, [1..NT-1] the next ones the prefetch already reaches into
+  // (three K-chunks ahead: the tile after next when a tile has only two chunks)
+  constexpr int NT = (NCH + 2) / NCH + 1;
+  int tl[NT], tn[NT], ty0[NT], tx0[NT];
+  uint32_t offs[NT][NDMA];
+  int kt = 0;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    tl[t] = tile_of(t); tn[t] = ty0[t] = tx0[t] = 0;
+    if (tl[t] >= 0) { setup_tile(tl[t], tn[t], ty0[t], tx0[t]); tile_offsets(tn[t], ty0[t], tx0[t], offs[t]); }
+  }
+  if (tl[0] < 0) return;
+  auto plane_or_zero = [&](int j, bool on, const char*& ptr, uint32_t& mul) __attribute__((always_inline)) {
     const char* pl = on ? a.plane[j] : nullptr;
     ptr = pl ? pl : a.zero_page; mul = pl ? 32u : 0u;
   };
 
-  // prologue: K-chunks 0 and 1 of the first tile into slots 0 and 1
-  {
-    const char *p0, *p1, *p2, *p3; uint32_t m0, m1, m2, m3;
-    plane_or_zero(0, true, p0, m0); plane_or_zero(1, true, p1, m1); plane_or_zero(2, true, p2, m2); plane_or_zero(3, true, p3, m3);
+  // prologue: the first three K-chunks of the walk into slots 0, 1, 2
 #pragma unroll
-    for (int j = 0; j < NDMA; ++j) dma_op(j, p0, p1, m0, m1, offc, 0);
+  for (int g = 0; g < 3; ++g) {
+    const int t = g / NCH, cc = g % NCH;
+    const char *pA, *pB; uint32_t mA, mB;
+    plane_or_zero(2 * cc, tl[t] >= 0, pA, mA); plane_or_zero(2 * cc + 1, tl[t] >= 0, pB, mB);
+    const uint32_t fb = lds0 + g * STAGE + wave * 1024;
 #pragma unroll
-    for (int j = 0; j < NDMA; ++j) dma_op(j, p2, p3, m2, m3, offc, 1);
+    for (int j = 0; j < NDMA; ++j)
+#pragma unroll
+      for (int part = 0; part < 4; ++part) dma_part(part, j, pA, pB, mA, mB, offs[t], fb);
   }
-  wait_vm<NDMA>();         // chunk 0 has landed (this wave's chunk-1 pieces are still in flight)
+  wait_vm<2 * NDMA>();     // chunk 0 has landed (this wave's pieces of chunks 1 and 2 are still in flight)
   __builtin_amdgcn_s_barrier();
   int slot = 0;            // ring slot of the chunk being computed
   bool prev_full = false;  // the previous tile issued all NSTORE stores and no other vector-memory operation
 
+  // residual through the matrix core (RL): A fragment of (1 / alpha) * I restricted to this wave's 16 channels
+  // of x, which are half (cg & 1) of K-chunk cg >> 1:  A[m][k] = 1 / alpha  iff  k = 16 * (cg & 1) + m
+  u32x4 a_res = {0u, 0u, 0u, 0u};
+  if constexpr (RL) {
+    const int m = lane & 15, kq = lane >> 4;
+    if (kq == 2 * (cg & 1) + (m >> 3)) {
+      const unsigned hv = (unsigned)__half_as_ushort(__float2half(1.f / a.alpha));
+      a_res[(m & 7) >> 1] = hv << (16 * (m & 1));
+    }
+  }
+  // bias as the C operand of each accumulator's first MFMA of a tile (no per-tile v_mov of 128 registers)
+  f32x4 bias_q[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias_q[cb][i] = bias_v[4 * cb + i];
+
+  // B fragments of three consecutive steps (two-step read-ahead, running across chunk and tile boundaries)
+  u32x4 bf[3][2];
+  auto ldb = [&](int s, const char* sbase) __attribute__((always_inline)) {   // s: step inside the chunk whose stage starts at sbase
+    const int dx = s / (ROWS + 2), ir = s % (ROWS + 2);
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) bf[s % 3][pb] = *reinterpret_cast<const u32x4*>(sbase + rdb[dx][pb] + ir * ROWB);
+  };
+  ldb(0, smem); ldb(1, smem);
+
   while (true) {
     f32x4 acc[ROWS][2][CB];
+    const int n = tn[0], y0 = ty0[0], x0 = tx0[0];
+    // epilogue addressing of this tile: lane (p, q) holds, per row mb and pixel block pb, channels
+    // cout0 + NV*q .. + NV-1 of pixel (y0 + rg*ROWS + mb, x0 + 16*pb + p)
+    const float alpha = a.alpha, gamma = a.gamma;
+    int qe = q;
+    asm volatile("" : "+v"(qe));   // re-derive the plane pointers per tile instead of carrying them through the loop
+    const int opl = cout0 / 16 + (CB == 2 ? (qe >> 1) : 0);
+    const size_t sub = CB == 2 ? (size_t)((qe & 1) << 4) : (size_t)(qe << 3);
+    const size_t rec0 = (((size_t)n * a.H + y0 + rg * ROWS) * a.W + x0 + p) * 32;
+    char* outp = a.out + (size_t)opl * a.out_plane_bytes + sub + rec0;
+    const size_t row_bytes = (size_t)a.W * 32;
+    const bool x_ok[2] = {x0 + p < a.W, x0 + 16 + p < a.W};
+    typedef typename std::conditional<CB == 2, u32x4, u32x2>::type rvec;   // NV fp16 channels
+    // activation, scaling and the fp16 store of one finished output row (no residual from memory)
+    auto finish_row = [&](int mb) __attribute__((always_inline)) {
+      if (y0 + rg * ROWS + mb >= a.H) return;   // wave-uniform
 #pragma unroll
-    for (int mb = 0; mb < ROWS; ++mb)
-#pragma unroll
-      for (int pb = 0; pb < 2; ++pb)
+      for (int pb = 0; pb < 2; ++pb) {
+        float v[NV];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[mb][pb][cb][i] = bias_v[4 * cb + i];
-    asm volatile("s_nop 4");   // VALU-written accumulators -> first MFMA (the asm MFMAs get no hazard padding)
+          for (int i = 0; i < 4; ++i) {
+            const float t = acc[mb][pb][cb][i], neg = t * slope_v[PR ? 4 * cb + i : 0];
+            v[4 * cb + i] = (PR ? (t >= 0.f ? t : neg) : fmaxf(t, neg)) * (RL ? alpha * gamma : alpha);   // one slope in [0,1] unless PReLU
+          }
+        rvec o;
+#pragma unroll
+        for (int k = 0; k < NV; k += 2)
+          o[k >> 1] = (unsigned)__half_as_ushort(__float2half(v[k])) | ((unsigned)__half_as_ushort(__float2half(v[k + 1])) << 16);
+        if (x_ok[pb]) __builtin_nontemporal_store(o, reinterpret_cast<rvec*>(outp + mb * row_bytes + pb * 512));
+      }
+    };
 
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      // the stage filled during this chunk: K-chunk c+2 of this tile, or chunk c+2-NCH of the next one.
-      // Past the last tile the DMAs are still issued (zeros, into a free slot): the counted waits stay
-      // exact and the MFMA stream carries no branch.
-      const bool tgt_next = (c + 2 >= NCH);
-      const int cc = (c + 2) % NCH;
-      const bool pf = tgt_next ? (next_tile >= 0) : true;
+      // the stage filled during this chunk: three K-chunks ahead (of this tile or of a later one).  Past the
+      // last tile the DMAs are still issued (zeros, into a free slot): the counted waits stay exact and the MFMA
+      // stream carries no branch.
+      const int tt = (c + 3) / NCH, cc = (c + 3) % NCH;
       const char *pA, *pB; uint32_t mulA, mulB;
-      plane_or_zero(2 * cc, pf, pA, mulA); plane_or_zero(2 * cc + 1, pf, pB, mulB);
-      const int fill = slot == 0 ? 2 : slot - 1;   // (slot + 2) % 3: the slot read during the previous chunk
+      plane_or_zero(2 * cc, tl[tt] >= 0, pA, mulA); plane_or_zero(2 * cc + 1, tl[tt] >= 0, pB, mulB);
+      const uint32_t fill_base = lds0 + ((slot + 3) & 3) * STAGE + wave * 1024;   // the slot read during the previous chunk
       const char* sb = smem + slot * STAGE;
-
-      if constexpr (RL) {
-        // this wave's output plane cg is plane cg of x = half (cg & 1) of K-chunk cg >> 1: when that chunk is the
-        // one in `slot`, add x / alpha at the tile's centre pixels (halo row mb + 1, column 16*pb + p + 1)
-        if (c < 2 && (cg >> 1) == c) {
-          const float inv_alpha = 1.f / a.alpha;
-          const int dg = 2 * (cg & 1) + (q >> 1);
-#pragma unroll
-          for (int mb = 0; mb < ROWS; ++mb) {
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
-              const int col = 16 * pb + p + 1;
-              const u32x2 u = *reinterpret_cast<const u32x2*>(sb + (mb + 1) * ROWB + col * PIXB + ((dg ^ swz(col)) << 4) + ((q & 1) << 3));
-#pragma unroll
-              for (int i = 0; i < 4; ++i)
-                acc[mb][pb][0][i] += __half2float(__ushort_as_half((unsigned short)((u[i >> 1] >> (16 * (i & 1))) & 0xffffu))) * inv_alpha;
-            }
-            if ((mb & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four rows of reads in flight at a time (registers)
-          }
-          asm volatile("s_nop 4");   // VALU-written accumulators -> MFMA
-        }
-      }
-
-      u32x4 bf[3][2];   // B fragments of three consecutive steps (two-step read-ahead)
-      auto ldb = [&](int s) {
+      const char* sb_next = smem + ((slot + 1) & 3) * STAGE;
+      constexpr int MID = NSTEP / 2;           // the chunk's one barrier sits here
+      auto step = [&](int s) __attribute__((always_inline)) {
         const int dx = s / (ROWS + 2), ir = s % (ROWS + 2);
-#pragma unroll
-        for (int pb = 0; pb < 2; ++pb) bf[s % 3][pb] = *reinterpret_cast<const u32x4*>(sb + rdb[dx][pb] + ir * ROWB);
-      };
-      ldb(0); ldb(1);
-      int dma_i = 0;
-#pragma unroll
-      for (int s = 0; s < NSTEP; ++s) {
-        const int dx = s / (ROWS + 2), ir = s % (ROWS + 2);
-        if (s + 2 < NSTEP) ldb(s + 2);
+        if (s + 2 < NSTEP) ldb(s + 2, sb); else ldb(s + 2 - NSTEP, sb_next);   // next chunk's stage is visible since MID
         __builtin_amdgcn_sched_barrier(0);
+        // DMA instructions of the prefetch: all after the barrier, spread evenly over the remaining steps
+        // (DMA j at step MID + 1 + j * (steps left) / NDMA), each in four parts between consecutive MFMAs
+        constexpr int LEFT = NSTEP - 1 - MID;
+        const int dma_i = s <= MID ? 0 : ((s - 1 - MID) * NDMA + LEFT - 1) / LEFT;                    // issued before this step
+        const int ndma_here = (s <= MID ? 0 : ((s - MID) * NDMA + LEFT - 1) / LEFT) - dma_i;          // 0, 1 or 2
+        int part = 0, mcount = 0;
+        // the interleaved epilogue: row ir-3 got its last MFMA one step ago (non-residual builds, last chunk, dx = 2)
+        const bool fin_here = !RES && c == NCH - 1 && dx == 2 && ir >= 3;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
           const int mb = ir - dy;
@@ -305,60 +353,81 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
-              for (int cb = 0; cb < CB; ++cb) mfma16(acc[mb][pb][cb], W[c][dy * 3 + dx][cb], bf[s % 3][pb], c < NA);
+              for (int cb = 0; cb < CB; ++cb) {
+                if (c == 0 && dx == 0 && dy == 0) mfma16_init(acc[mb][pb][cb], W[c][dy * 3 + dx][cb], bf[s % 3][pb], bias_q[cb], c < NA);
+                else mfma16(acc[mb][pb][cb], W[c][dy * 3 + dx][cb], bf[s % 3][pb], c < NA);
+                if (part < 4 * ndma_here) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  dma_part(part & 3, dma_i + (part >> 2), pA, pB, mulA, mulB, offs[tt], fill_base);
+                  ++part;
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+                ++mcount;
+                if (fin_here && mcount == 2) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  asm volatile("s_nop 7");   // the row's last MFMA (end of the previous step) -> VALU read
+                  finish_row(ir - 3);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }
+            if constexpr (RL) {
+              // + x / alpha at the centre tap: one more MFMA per pixel block with the identity fragment
+              if (c < 2 && dx == 1 && dy == 1 && (cg >> 1) == c) {
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) mfma16(acc[mb][pb][0], a_res, bf[s % 3][pb], false);
+              }
+            }
           }
         }
-        // this wave's DMA instructions of the prefetch are spread over the first 3/4 of the chunk
-        if (dma_i < NDMA && 4 * s * NDMA >= 3 * dma_i * NSTEP) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (tgt_next) dma_op(dma_i, pA, pB, mulA, mulB, offn, fill); else dma_op(dma_i, pA, pB, mulA, mulB, offc, fill);
-          ++dma_i;
-        }
         __builtin_amdgcn_sched_barrier(0);
-      }
-      // hand-over: the NEXT chunk's stage (issued one chunk ago) must have landed; what this chunk
-      // issued stays in flight.  vmcnt counts DMA, loads and stores together in issue order: right
-      // after an epilogue the tile's NSTORE stores sit between the two stages and are left in flight too.
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k >= part && k < 4 * ndma_here) dma_part(k & 3, dma_i + (k >> 2), pA, pB, mulA, mulB, offs[tt], fill_base);
+        if (fin_here && mcount < 2) { asm volatile("s_nop 7"); finish_row(ir - 3); }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      // two fully unrolled halves with the chunk's one hand-over between them (a barrier inside a conditional
+      // of the step loop would keep the loop from being unrolled)
+#pragma unroll
+      for (int s = 0; s <= MID; ++s) step(s);
+      // the NEXT chunk's stage (issued two chunks ago) must have landed, the two younger stages stay in flight -
+      // and every wave is past the previous chunk, whose slot is refilled from here on.  vmcnt counts DMA, loads
+      // and stores together in issue order: after a tile boundary the previous tile's NSTORE stores sit among the
+      // younger operations and stay in flight too.
       if (c == 0 && prev_full) wait_vm<(NDMA + NSTORE < 63 ? NDMA + NSTORE : 63)>();
       else wait_vm<NDMA>();
       __builtin_amdgcn_s_barrier();
-      slot = slot == 2 ? 0 : slot + 1;
+#pragma unroll
+      for (int s = MID + 1; s < NSTEP; ++s) step(s);
+      slot = (slot + 1) & 3;
     }
-    asm volatile("s_nop 15");  // last MFMA's result -> first VALU read in the epilogue
 
-    // ---------------- epilogue: activation, residuals, fp16 stores (no LDS use) ----------------
-    // lane (p, q) holds, per row mb and pixel block pb, channels cout0 + NV*q .. + NV-1 of pixel 16*pb + p.
-    // Residuals still read from memory are fetched RB rows at a time (all loads of a batch first: one exposed
-    // round trip per batch, not per row - nothing else runs on this SIMD).
-    {
-      const float alpha = a.alpha, gamma = a.gamma;
-      // the per-lane plane pointers depend only on kernel arguments: behind an opaque copy of q they are
-      // re-derived per tile instead of being carried (and spilled) across the MFMA loop
-      int qe = q;
-      asm volatile("" : "+v"(qe));
-      const int opl = cout0 / 16 + (CB == 2 ? (qe >> 1) : 0);
-      const size_t sub = CB == 2 ? (size_t)((qe & 1) << 4) : (size_t)(qe << 3);
-      char* outp = a.out + (size_t)opl * a.out_plane_bytes + sub;
-      const char* r1p = (a.res1 && !RL) ? a.res1 + (size_t)opl * a.r1_plane_bytes + sub : nullptr;
-      const char* r2p = a.res2 ? a.res2 + (size_t)opl * a.r2_plane_bytes + sub : nullptr;
-      typedef typename std::conditional<CB == 2, u32x4, u32x2>::type rvec;   // NV fp16 channels
+    if constexpr (!RES) {
+      asm volatile("s_nop 11");   // last MFMA's result -> VALU read
+      finish_row(ROWS - 1);
+      prev_full = (y0 + TH <= a.H) && (x0 + TW <= a.W);
+    } else {
+      // ---------------- epilogue with residual(s) read from memory ----------------
+      // fetched RB rows at a time (all loads of a batch first: one exposed round trip per batch, not per row -
+      // nothing else runs on this SIMD).  hipcc waits for these loads with a vmcnt that also drains the ring.
+      asm volatile("s_nop 11");   // last MFMA's result -> VALU read
+      const char* r1p = (a.res1 && !RL) ? a.res1 + (size_t)opl * a.r1_plane_bytes + sub + rec0 : nullptr;
+      const char* r2p = a.res2 ? a.res2 + (size_t)opl * a.r2_plane_bytes + sub + rec0 : nullptr;
       constexpr int RB = ROWS < 8 ? ROWS : 8;
 #pragma unroll
       for (int mb0 = 0; mb0 < ROWS; mb0 += RB) {
-        rvec u1[RES ? RB : 1][2], u2[RES ? RB : 1][2];
-        const bool any_res = RES && (r1p || r2p);
-        if constexpr (RES) if (any_res) {
+        rvec u1[RB][2], u2[RB][2];
+        const bool any_res = r1p || r2p;
+        if (any_res) {
 #pragma unroll
           for (int j = 0; j < RB; ++j)
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb) {
-              const int y = y0 + rg * ROWS + mb0 + j, x = x0 + 16 * pb + p;
-              const bool ok = (y < a.H) & (x < a.W);
-              const size_t rec = (((size_t)n * a.H + y) * a.W + x) * 32;
+              const bool ok = (y0 + rg * ROWS + mb0 + j < a.H) & x_ok[pb];
               // out-of-image lanes read the tile's first pixel instead (always inside) and are never stored
-              const size_t rc = ok ? rec : (((size_t)n * a.H + y0) * a.W + x0) * 32;
-              u1[j][pb] = *reinterpret_cast<const rvec*>((r1p ? r1p : r2p) + rc);
-              u2[j][pb] = *reinterpret_cast<const rvec*>((r2p ? r2p : r1p) + rc);
+              const size_t ro = ok ? (size_t)(mb0 + j) * row_bytes + pb * 512 : (size_t)0 - (size_t)(rg * ROWS) * row_bytes - (size_t)p * 32;
+              u1[j][pb] = *reinterpret_cast<const rvec*>((r1p ? r1p : r2p) + ro);
+              u2[j][pb] = *reinterpret_cast<const rvec*>((r2p ? r2p : r1p) + ro);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -367,19 +436,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
 #pragma unroll
           for (int pb = 0; pb < 2; ++pb) {
             const int mb = mb0 + j;
-            const int y = y0 + rg * ROWS + mb, x = x0 + 16 * pb + p;
-            const bool ok = (y < a.H) & (x < a.W);
-            const size_t rec = (((size_t)n * a.H + y) * a.W + x) * 32;
+            const bool ok = (y0 + rg * ROWS + mb < a.H) & x_ok[pb];
             float v[NV];
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
                 const float t = acc[mb][pb][cb][i], neg = t * slope_v[PR ? 4 * cb + i : 0];
-                v[4 * cb + i] = (PR ? (t >= 0.f ? t : neg) : fmaxf(t, neg)) * alpha;   // one slope in [0,1] unless PReLU
+                v[4 * cb + i] = (PR ? (t >= 0.f ? t : neg) : fmaxf(t, neg)) * alpha;
               }
             if (any_res) {
-              const rvec w1 = u1[RES ? j : 0][pb], w2 = u2[RES ? j : 0][pb];
+              const rvec w1 = u1[j][pb], w2 = u2[j][pb];
               const float m1 = r1p ? 1.f : 0.f, m2 = r2p ? 1.f : 0.f;   // an absent residual is read as the other one, times 0
 #pragma unroll
               for (int k = 0; k < NV; ++k) {
@@ -395,21 +462,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
 #pragma unroll
               for (int k = 0; k < NV; k += 2)
                 o[k >> 1] = (unsigned)__half_as_ushort(__float2half(v[k])) | ((unsigned)__half_as_ushort(__float2half(v[k + 1])) << 16);
-              __builtin_nontemporal_store(o, reinterpret_cast<rvec*>(outp + rec));
+              __builtin_nontemporal_store(o, reinterpret_cast<rvec*>(outp + mb * row_bytes + pb * 512));
             }
           }
         __builtin_amdgcn_sched_barrier(0);
       }
+      prev_full = false;
     }
-    // every store instruction of the tile was issued by this wave iff no row / pixel block lies wholly
-    // outside; residual loads make hipcc wait for (= drain) everything older anyway
-    prev_full = (y0 + TH <= a.H) && (x0 + TW <= a.W) && !(RES && ((a.res1 && !RL) || a.res2));
-    if (next_tile < 0) break;
-    tile = next_tile; ++kt; n = nn; y0 = ny0; x0 = nx0;
+    if (tl[1] < 0) break;
+    // rotate the tile window
+    ++kt;
 #pragma unroll
-    for (int j = 0; j < NDMA; ++j) offc[j] = offn[j];
-    next_tile = tile_of(kt + 1);
-    if (next_tile >= 0) { setup_tile(next_tile, nn, ny0, nx0); tile_offsets(nn, ny0, nx0, offn); }
+    for (int t = 0; t + 1 < NT; ++t) {
+      tl[t] = tl[t + 1]; tn[t] = tn[t + 1]; ty0[t] = ty0[t + 1]; tx0[t] = tx0[t + 1];
+#pragma unroll
+      for (int j = 0; j < NDMA; ++j) offs[t][j] = offs[t + 1][j];
+    }
+    tl[NT - 1] = tile_of(kt + NT - 1);
+    if (tl[NT - 1] >= 0) { setup_tile(tl[NT - 1], tn[NT - 1], ty0[NT - 1], tx0[NT - 1]); tile_offsets(tn[NT - 1], ty0[NT - 1], tx0[NT - 1], offs[NT - 1]); }
   }
   wait_vm<0>();   // the trailing (zero) prefetches must have landed before the workgroup's LDS is released
 }

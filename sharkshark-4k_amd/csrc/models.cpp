@@ -457,6 +457,7 @@ double bench_conv_layer(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, 
   ss4k_model_desc d{}; d.kind = SS4K_RRDBNET; d.dtype = dtype; d.scale = 2; d.num_feat = 64; d.num_block = 1; d.num_grow_ch = 32;
   Model m; m.ctx = ctx; m.desc = d;
   m.use_rs = (flags & 4096) != 0;   // 4096: the register-stationary kernel (conv_rs.hip) where the shape is built
+  m.rs_mask = 63;
   const int cin = cin0 + cin1;
   std::vector<float> blob((size_t)cout * cin * 9 + cout);
   uint32_t s = 12345;

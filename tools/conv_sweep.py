@@ -23,4 +23,4 @@ for name, c0, c1, co, fl in shapes:
             t[rs].append(ctx.bench_conv(_capi.F16, c0, c1, co, n, H, W, flags=fl | rs, iters=20))
     gf = 2 * 9 * (c0 + c1) * co * n * H * W / 1e9
     a, b = float(np.median(t[0])), float(np.median(t[4096]))
-    print(f"{name:20s} LDS-weights {a:7.1f} us = {gf / a * 1e-3:6.0f} TFLOP/s | register-stationary {b:7.1f} us = {gf / b * 1e-3:6.0f} TFLOP/s | x{a / b:.2f}")
+    print(f"{name:20s} LDS-weights {a:7.1f} us = {gf / a * 1e3:6.0f} TFLOP/s | register-stationary {b:7.1f} us = {gf / b * 1e3:6.0f} TFLOP/s | x{a / b:.2f}")
