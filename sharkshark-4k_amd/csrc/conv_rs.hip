@@ -29,6 +29,10 @@
 #include "common.h"
 #include <type_traits>
 
+#ifndef SS4K_RS_NBF
+#define SS4K_RS_NBF 3
+#endif
+
 namespace ss4k {
 namespace rs {
 
@@ -277,14 +281,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) bias_q[cb][i] = bias_v[4 * cb + i];
 
-  // B fragments of three consecutive steps (two-step read-ahead, running across chunk and tile boundaries)
-  u32x4 bf[3][2];
+  // B fragments of NBF consecutive steps (read-ahead of LA = NBF - 1 steps, running across chunk and tile
+  // boundaries; NBF divides the steps of a chunk so that the ring index of a step is static).  With four waves
+  // reading and the DMA writing, an LDS read is back after 150-250 cycles: a step is only 96-192 cycles of MFMAs.
+  constexpr int NBF = SS4K_RS_NBF;
+  constexpr int LA = NBF - 1;
+  static_assert(NSTEP % NBF == 0, "read-ahead ring must divide the steps of a chunk");
+  u32x4 bf[NBF][2];
   auto ldb = [&](int s, const char* sbase) __attribute__((always_inline)) {   // s: step inside the chunk whose stage starts at sbase
     const int dx = s / (ROWS + 2), ir = s % (ROWS + 2);
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb) bf[s % 3][pb] = *reinterpret_cast<const u32x4*>(sbase + rdb[dx][pb] + ir * ROWB);
+    for (int pb = 0; pb < 2; ++pb) bf[s % NBF][pb] = *reinterpret_cast<const u32x4*>(sbase + rdb[dx][pb] + ir * ROWB);
   };
-  ldb(0, smem); ldb(1, smem);
+#pragma unroll
+  for (int s = 0; s < LA; ++s) ldb(s, smem);
 
   while (true) {
     f32x4 acc[ROWS][2][CB];
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
       constexpr int MID = NSTEP / 2;           // the chunk's one barrier sits here
       auto step = [&](int s) __attribute__((always_inline)) {
         const int dx = s / (ROWS + 2), ir = s % (ROWS + 2);
-        if (s + 2 < NSTEP) ldb(s + 2, sb); else ldb(s + 2 - NSTEP, sb_next);   // next chunk's stage is visible since MID
+        if (s + LA < NSTEP) ldb(s + LA, sb); else ldb(s + LA - NSTEP, sb_next);   // next chunk's stage is visible since MID
         __builtin_amdgcn_sched_barrier(0);
         // DMA instructions of the prefetch: all after the barrier, spread evenly over the remaining steps
         // (DMA j at step MID + 1 + j * (steps left) / NDMA), each in four parts between consecutive MFMAs
@@ -354,8 +364,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
             for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
               for (int cb = 0; cb < CB; ++cb) {
-                if (c == 0 && dx == 0 && dy == 0) mfma16_init(acc[mb][pb][cb], W[c][dy * 3 + dx][cb], bf[s % 3][pb], bias_q[cb], c < NA);
-                else mfma16(acc[mb][pb][cb], W[c][dy * 3 + dx][cb], bf[s % 3][pb], c < NA);
+                if (c == 0 && dx == 0 && dy == 0) mfma16_init(acc[mb][pb][cb], W[c][dy * 3 + dx][cb], bf[s % NBF][pb], bias_q[cb], c < NA);
+                else mfma16(acc[mb][pb][cb], W[c][dy * 3 + dx][cb], bf[s % NBF][pb], c < NA);
                 if (part < 4 * ndma_here) {
                   __builtin_amdgcn_sched_barrier(0);
                   dma_part(part & 3, dma_i + (part >> 2), pA, pB, mulA, mulB, offs[tt], fill_base);
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
               // + x / alpha at the centre tap: one more MFMA per pixel block with the identity fragment
               if (c < 2 && dx == 1 && dy == 1 && (cg >> 1) == c) {
 #pragma unroll
-                for (int pb = 0; pb < 2; ++pb) mfma16(acc[mb][pb][0], a_res, bf[s % 3][pb], false);
+                for (int pb = 0; pb < 2; ++pb) mfma16(acc[mb][pb][0], a_res, bf[s % NBF][pb], false);
               }
             }
           }
