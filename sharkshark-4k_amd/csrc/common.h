@@ -96,6 +96,7 @@ struct ConvArgs {
   int ups2;                             // input is the nearest-x2 upsampling of an (H/2, W/2) tensor
   const void* wpk;                      // packed weights [group][chunk][dx,ks][dy][nb][lane][E]
   const void* wrs;                      // conv_rs.hip layout [group][cout group][chunk32][tap][cb][lane][8] or null
+  int rs_wide;                          // wrs is packed for the eight-wave variant of the shape
   const float* bias;                    // [cout_pad] virtual order
   const float* prelu;                   // [cout_pad] or null
   int act; float slope;
@@ -118,7 +119,7 @@ enum { DBG_NO_STORE = 1, DBG_NO_MMA = 2, DBG_NO_TILE_DMA = 4, DBG_NO_W_DMA = 8, 
 void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a, int dtype, hipStream_t st);
 int conv_cw(int dtype);  // channels per plane / K-chunk: 16
 // register-stationary-weights kernel (conv_rs.hip): fp16, plain epilogue, selected layer shapes
-bool rs_config(int nplanes, int cout_pad, int* nch, int* rows, int* cb);
+bool rs_config(int nplanes, int cout_pad, bool wide, int* nch, int* rows, int* cb, int* cg);
 void launch_conv3x3_rs(ss4k_ctx* ctx, const ConvArgs& a, hipStream_t st);
 inline int conv_rec_bytes(int dtype) { return dtype == SS4K_F16 ? 32 : 64; }  // bytes of one pixel's record in a plane
 
@@ -137,7 +138,7 @@ struct PackedConv {
 };
 PackedConv pack_conv3x3(const PackSpec& s, const float* w_oihw, const float* bias, const float* prelu);
 // conv_rs.hip weight order for a layer shape <nch, rows, cb> (fp16 only); same virtual cout order / bias as pack_conv3x3
-std::vector<uint8_t> pack_conv3x3_rs(const PackSpec& s, const float* w_oihw, int cout_pad, int nch, int rows, int cb);
+std::vector<uint8_t> pack_conv3x3_rs(const PackSpec& s, const float* w_oihw, int cout_pad, int nch, int cb, int cg);
 int virt_to_real_cout(const PackSpec& s, int v);
 
 }  // namespace ss4k

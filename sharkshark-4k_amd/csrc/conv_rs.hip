@@ -23,6 +23,8 @@
 //     32 couts, cin 160         (RDB conv4)   : <5, 8, 1>      2 row groups x 2 cout halves
 //     64 couts, cin  64 (trunk / tail / SRVGG): <2, 8, 2>      2 row groups x 2 cout halves
 //     64 couts, cin 192         (RDB conv5)   : <6, 16, 1>     every wave the whole tile, 16 couts each
+// (Eight-wave variants <NCH, 4, 1, CG = 2> of the 32-cout shapes - two waves per SIMD, 256 registers each - were
+// built and measured: 0.95-0.98x the LDS-weights kernel for conv1/conv2, register spills for conv3)
 // Data layout in HBM is conv_mfma.hip's ("planes" of 16 channels, 32-byte records), so the two kernels
 // are interchangeable per layer; the fp32 parity path, the first / last layers and the BSVD epilogues stay
 // on conv_mfma.hip.
@@ -44,9 +46,9 @@ constexpr int TH = 16, TW = 32, IN_H = TH + 2, IN_W = TW + 2;
 constexpr int PIXB = 64;                     // LDS bytes per halo pixel: 2 planes x 16 channels x fp16
 constexpr int ROWB = IN_W * PIXB;            // 2176
 constexpr int TILE_SLOTS = IN_H * IN_W * 4;  // 16-byte slots of a 32-channel halo stage (2448 = 38.25 KB)
-constexpr int NDMA = (TILE_SLOTS + 255) / 256;     // wave-level 1 KB LDS-DMA instructions per wave and stage (10)
-constexpr int STAGE = NDMA * 4 * 1024;       // stage padded to a whole number of DMA instructions per wave: every
-                                             // wave issues exactly NDMA per stage (exact counted waits, no EXEC masks)
+constexpr int STAGE_DMA = 40;                // wave-level 1 KB LDS-DMA instructions per stage (>= 2448 / 64 = 38.25)
+constexpr int STAGE = STAGE_DMA * 1024;      // stage padded so that 4 or 8 waves issue the same number each (exact
+                                             // counted waits, no EXEC masks)
 constexpr int NSTAGE = 4;                    // ring: one being read, three in flight (all 160 KB of the CU)
 constexpr int MAX_PLANES = 12;
 
@@ -100,22 +102,24 @@ __device__ __forceinline__ int swz(int col) { return ((col >> 2) & 1) << 1; }
 //     there (scaled by 1 / alpha) instead of being read from HBM a second time in the epilogue - at one wave
 //     per SIMD nothing would hide that latency.
 // RES: the epilogue reads residual(s) from memory (res1 unless RL, res2); built only where a network needs it.
-template <int NCH, int ROWS, int CB, bool PR, bool RL, bool RES>
-__global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
-  constexpr int RG = TH / ROWS, CG = 4 / RG, COUT_WG = CG * CB * 16;
+template <int NCH, int ROWS, int CB, int CG, bool PR, bool RL, bool RES>
+__global__ __launch_bounds__(64 * (TH / ROWS) * CG, (TH / ROWS) * CG / 4) void conv3x3_rs_kernel(const RsArgs a) {
+  constexpr int RG = TH / ROWS, NW = RG * CG, COUT_WG = CG * CB * 16;
+  constexpr int NDMA = STAGE_DMA / NW;        // DMA instructions per wave and stage (10 with four waves, 5 with eight)
+  static_assert(NW == 4 || NW == 8, "four waves (one per SIMD) or eight (two per SIMD)");
   constexpr int NV = CB * 4;                  // output channels per lane and pixel
   constexpr int NSTEP = 3 * (ROWS + 2);       // (tap column, input row) steps per K-chunk
-  constexpr int NSTORE = ROWS * 2;            // store instructions per wave and tile
   // K-chunks whose weight fragments live in AGPRs (<= 216 of the 256); the rest stay in VGPRs next to the
   // accumulators, B fragments and addresses
-  constexpr int NA = (216 / (36 * CB)) < NCH ? (216 / (36 * CB)) : NCH;
+  constexpr int AGPR_W = NW == 4 ? 216 : 144;   // two waves per SIMD share the 512-entry file: 256 each
+  constexpr int NA = (AGPR_W / (36 * CB)) < NCH ? (AGPR_W / (36 * CB)) : NCH;
   static_assert(NCH >= 2 && 2 * NCH <= MAX_PLANES, "the two-chunks-ahead prefetch needs at least two K-chunks per tile");
   static_assert(ROWS * 2 * CB * 4 + (NCH - NA) * 36 * CB <= 160, "VGPR budget: accumulators + VGPR-resident weights");
   static_assert(!RL || (CB == 1 && ROWS == 16), "RL is built for the conv5 shape: a wave owns one output plane of the whole tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;   // (kernel is launched with 64 * NW threads)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rg = wave % RG, cg = wave / RG;   // this wave's row group and cout group
   const int p = lane & 15, q = lane >> 4;
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
   int plan[NDMA];
 #pragma unroll
   for (int j = 0; j < NDMA; ++j) {
-    const int s = (wave + 4 * j) * 64 + lane;
+    const int s = (wave + NW * j) * 64 + lane;
     const int pix = s >> 2, qq = s & 3;
     const int row = pix / IN_W, col = pix - row * IN_W;
     plan[j] = (s < TILE_SLOTS) ? (row | (col << 8) | ((qq ^ swz(col)) << 16)) : 0xff;
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
     } else if (part == 2) {
       ds.src = ds.bsel + (size_t)ds.off * ds.mul + (size_t)((ds.dg & 1) << 4);
     } else {
-      dma16(ds.src, __builtin_amdgcn_readfirstlane(fill_base + j * 4096));
+      dma16(ds.src, __builtin_amdgcn_readfirstlane(fill_base + j * (NW * 1024)));
     }
   };
 
@@ -262,7 +266,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
   wait_vm<2 * NDMA>();     // chunk 0 has landed (this wave's pieces of chunks 1 and 2 are still in flight)
   __builtin_amdgcn_s_barrier();
   int slot = 0;            // ring slot of the chunk being computed
-  bool prev_full = false;  // the previous tile issued all NSTORE stores and no other vector-memory operation
 
   // residual through the matrix core (RL): A fragment of (1 / alpha) * I restricted to this wave's 16 channels
   // of x, which are half (cg & 1) of K-chunk cg >> 1:  A[m][k] = 1 / alpha  iff  k = 16 * (cg & 1) + m
@@ -400,12 +403,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
       // of the step loop would keep the loop from being unrolled)
 #pragma unroll
       for (int s = 0; s <= MID; ++s) step(s);
-      // the NEXT chunk's stage (issued two chunks ago) must have landed, the two younger stages stay in flight -
-      // and every wave is past the previous chunk, whose slot is refilled from here on.  vmcnt counts DMA, loads
-      // and stores together in issue order: after a tile boundary the previous tile's NSTORE stores sit among the
-      // younger operations and stay in flight too.
-      if (c == 0 && prev_full) wait_vm<(NDMA + NSTORE < 63 ? NDMA + NSTORE : 63)>();
-      else wait_vm<NDMA>();
+      // the NEXT chunk's stage (issued two chunks ago) must have landed, the younger stage stays in flight - and
+      // every wave is past the previous chunk, whose slot is refilled from here on.  vmcnt counts DMA, loads and
+      // stores together in issue order: after a tile boundary the previous tile's output stores are older than the
+      // stage left in flight, so this wait also covers them - half a chunk after they were issued, i.e. for free.
+      wait_vm<NDMA>();
       __builtin_amdgcn_s_barrier();
 #pragma unroll
       for (int s = MID + 1; s < NSTEP; ++s) step(s);
@@ -415,7 +417,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
     if constexpr (!RES) {
       asm volatile("s_nop 11");   // last MFMA's result -> VALU read
       finish_row(ROWS - 1);
-      prev_full = (y0 + TH <= a.H) && (x0 + TW <= a.W);
     } else {
       // ---------------- epilogue with residual(s) read from memory ----------------
       // fetched RB rows at a time (all loads of a batch first: one exposed round trip per batch, not per row -
@@ -477,7 +478,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
           }
         __builtin_amdgcn_sched_barrier(0);
       }
-      prev_full = false;
     }
     if (tl[1] < 0) break;
     // rotate the tile window
@@ -494,10 +494,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_rs_kernel(const RsArgs a) {
   wait_vm<0>();   // the trailing (zero) prefetches must have landed before the workgroup's LDS is released
 }
 
-template <int NCH, int ROWS, int CB, bool PR, bool RL = false, bool RES = false>
+template <int NCH, int ROWS, int CB, int CG, bool PR, bool RL = false, bool RES = false>
 static void launch_t(ss4k_ctx* ctx, const ConvArgs& c, hipStream_t st) {
   SS4K_REQUIRE(RES || ((RL || !c.res1) && !c.res2), "internal: conv3x3_rs build without residual support");
-  constexpr int RG = TH / ROWS, CG = 4 / RG, COUT_WG = CG * CB * 16;
+  constexpr int RG = TH / ROWS, NW = RG * CG, COUT_WG = CG * CB * 16;
   constexpr size_t lds = (size_t)NSTAGE * STAGE;
   RsArgs a{};
   const int nplanes = c.nchunks0 + c.nchunks1;
@@ -516,54 +516,54 @@ static void launch_t(ss4k_ctx* ctx, const ConvArgs& c, hipStream_t st) {
   a.slope = c.act == ACT_LRELU ? c.slope : 1.f; a.alpha = c.alpha; a.gamma = c.gamma;
   const int groups = c.cout_pad / COUT_WG;
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
-  const void* fn = reinterpret_cast<const void*>(&conv3x3_rs_kernel<NCH, ROWS, CB, PR, RL, RES>);
+  const void* fn = reinterpret_cast<const void*>(&conv3x3_rs_kernel<NCH, ROWS, CB, CG, PR, RL, RES>);
   if (ctx->lds_attr_set.insert(fn).second)
     SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int gx = std::min(ntiles, std::max(1, ctx->num_cu / groups));
-  hipLaunchKernelGGL((conv3x3_rs_kernel<NCH, ROWS, CB, PR, RL, RES>), dim3(gx, groups), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_rs_kernel<NCH, ROWS, CB, CG, PR, RL, RES>), dim3(gx, groups), dim3(64 * NW), lds, st, a);
   SS4K_HIP(hipGetLastError());
 }
 
 }  // namespace rs
 
-// Layer shapes the register-stationary kernel is built for: (32-channel chunks, couts) -> <NCH, ROWS, CB>
-bool rs_config(int nplanes, int cout_pad, int* nch, int* rows, int* cb) {
+// Layer shapes the register-stationary kernel is built for: (32-channel chunks, couts) -> <NCH, ROWS, CB, CG>
+// (CG = cout groups; waves = (16 / ROWS) * CG).  wide: reserved (eight-wave variants, not built).
+bool rs_config(int nplanes, int cout_pad, bool wide, int* nch, int* rows, int* cb, int* cg) {
   const int c = (nplanes + 1) / 2;
-  if (cout_pad == 32 && c >= 2 && c <= 4) { *nch = c; *rows = 4; *cb = 2; return true; }
-  if (cout_pad == 32 && c == 5) { *nch = 5; *rows = 8; *cb = 1; return true; }
-  if (cout_pad == 64 && c == 2) { *nch = 2; *rows = 8; *cb = 2; return true; }
-  if (cout_pad == 64 && c == 6) { *nch = 6; *rows = 16; *cb = 1; return true; }
+  (void)wide;
+  if (cout_pad == 32 && c >= 2 && c <= 4) { *nch = c; *rows = 4; *cb = 2; *cg = 1; return true; }
+  if (cout_pad == 32 && c == 5) { *nch = 5; *rows = 8; *cb = 1; *cg = 2; return true; }
+  if (cout_pad == 64 && c == 2) { *nch = 2; *rows = 8; *cb = 2; *cg = 2; return true; }
+  if (cout_pad == 64 && c == 6) { *nch = 6; *rows = 16; *cb = 1; *cg = 4; return true; }
   return false;
 }
 
-static bool cout_is_64(const ConvArgs& a) { return a.cout_pad == 64; }
-
 void launch_conv3x3_rs(ss4k_ctx* ctx, const ConvArgs& a, hipStream_t st) {
-  int nch, rows, cb;
-  SS4K_REQUIRE(rs_config(a.nchunks0 + a.nchunks1, a.cout_pad, &nch, &rows, &cb), "conv3x3_rs: unsupported layer shape");
+  int nch, rows, cb, cg;
+  SS4K_REQUIRE(rs_config(a.nchunks0 + a.nchunks1, a.cout_pad, a.rs_wide != 0, &nch, &rows, &cb, &cg), "conv3x3_rs: unsupported layer shape");
   SS4K_REQUIRE(a.wrs && a.epi == EPI_NHWC && !a.bsvd_resid && a.act != ACT_RELU6, "conv3x3_rs: unsupported epilogue");
   SS4K_REQUIRE(a.act != ACT_PRELU || (rows == 8 && cb == 2 && !a.res1 && !a.res2), "conv3x3_rs: PReLU is built for the 64->64 shape without residuals only");
   SS4K_REQUIRE(a.act != ACT_LRELU || (a.slope >= 0.f && a.slope <= 1.f), "conv3x3_rs: LeakyReLU slope must be in [0,1]");
   const bool res = a.res1 || a.res2;
-  SS4K_REQUIRE(!res || (cout_is_64(a)), "conv3x3_rs: residual epilogues are built for the 64-cout shapes only");
-  if (cb == 2 && rows == 4) {
-    if (nch == 2) rs::launch_t<2, 4, 2, false>(ctx, a, st);
-    else if (nch == 3) rs::launch_t<3, 4, 2, false>(ctx, a, st);
-    else rs::launch_t<4, 4, 2, false>(ctx, a, st);
-  } else if (rows == 8 && cb == 1) rs::launch_t<5, 8, 1, false>(ctx, a, st);
+  SS4K_REQUIRE(!res || a.cout_pad == 64, "conv3x3_rs: residual epilogues are built for the 64-cout shapes only");
+  if (rows == 4 && cg == 1) {
+    if (nch == 2) rs::launch_t<2, 4, 2, 1, false>(ctx, a, st);
+    else if (nch == 3) rs::launch_t<3, 4, 2, 1, false>(ctx, a, st);
+    else rs::launch_t<4, 4, 2, 1, false>(ctx, a, st);
+  } else if (rows == 8 && cb == 1) rs::launch_t<5, 8, 1, 2, false>(ctx, a, st);
   else if (rows == 8 && cb == 2) {
-    if (a.act == ACT_PRELU) rs::launch_t<2, 8, 2, true>(ctx, a, st);
-    else if (res) rs::launch_t<2, 8, 2, false, false, true>(ctx, a, st);
-    else rs::launch_t<2, 8, 2, false>(ctx, a, st);
+    if (a.act == ACT_PRELU) rs::launch_t<2, 8, 2, 2, true>(ctx, a, st);
+    else if (res) rs::launch_t<2, 8, 2, 2, false, false, true>(ctx, a, st);
+    else rs::launch_t<2, 8, 2, 2, false>(ctx, a, st);
   } else {
     // conv5 of an RDB: res1 is the conv's own input tensor (segment 0, 4 planes) and there is no activation
     const bool res_is_input = a.res1 && a.act == ACT_NONE && a.alpha != 0.f && a.nchunks0 == 4 && a.cout_pad == 64 &&
                               a.res1 + (size_t)a.r1_plane0 * a.r1_plane_bytes == a.in0 + (size_t)a.in0_plane0 * a.in0_plane_bytes &&
                               a.r1_plane_bytes == a.in0_plane_bytes && !a.ups2;
-    if (res_is_input && !a.res2) rs::launch_t<6, 16, 1, false, true, false>(ctx, a, st);
-    else if (res_is_input) rs::launch_t<6, 16, 1, false, true, true>(ctx, a, st);
-    else if (res) rs::launch_t<6, 16, 1, false, false, true>(ctx, a, st);
-    else rs::launch_t<6, 16, 1, false>(ctx, a, st);
+    if (res_is_input && !a.res2) rs::launch_t<6, 16, 1, 4, false, true, false>(ctx, a, st);
+    else if (res_is_input) rs::launch_t<6, 16, 1, 4, false, true, true>(ctx, a, st);
+    else if (res) rs::launch_t<6, 16, 1, 4, false, false, true>(ctx, a, st);
+    else rs::launch_t<6, 16, 1, 4, false>(ctx, a, st);
   }
 }
 

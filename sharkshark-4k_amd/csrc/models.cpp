@@ -113,12 +113,13 @@ int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool h
   upload(L.w, p.w.data(), p.w.size());
   upload(L.bias, p.bias.data(), p.bias.size() * 4);
   if (a) upload(L.prelu, p.prelu.data(), p.prelu.size() * 4);
-  int nch, rows, cb;
-  if (allow_rs && use_rs && desc.dtype == SS4K_F16 && rs_config(s.nchunks0 + s.nchunks1, p.cout_pad, &nch, &rows, &cb) &&
+  int nch, rows, cb, cg;
+  if (allow_rs && use_rs && desc.dtype == SS4K_F16 && rs_config(s.nchunks0 + s.nchunks1, p.cout_pad, rs_wide, &nch, &rows, &cb, &cg) &&
       (rs_mask >> rs_shape_bit(nch, p.cout_pad)) & 1) {
-    const std::vector<uint8_t> wr = pack_conv3x3_rs(s, w, p.cout_pad, nch, rows, cb);
+    const std::vector<uint8_t> wr = pack_conv3x3_rs(s, w, p.cout_pad, nch, cb, cg);
     upload(L.wrs, wr.data(), wr.size());
     weight_bytes += wr.size();
+    L.rs_wide = rs_wide;
   }
   L.has_prelu = a != nullptr;
   L.cout_real = cout; L.cout_pad = p.cout_pad; L.nchunks0 = s.nchunks0; L.nchunks1 = s.nchunks1;
@@ -173,6 +174,7 @@ void Model::build(const float* w, size_t n) {
   if (const char* e = std::getenv("SS4K_SUBBATCH")) sub_batch = std::atoi(e);   // A/B switch: frames per pass through the network
   if (const char* e = std::getenv("SS4K_NO_RS")) use_rs = !(e[0] == '1');        // A/B switch: LDS-weights kernel for every layer
   if (const char* e = std::getenv("SS4K_RS_MASK")) rs_mask = std::atoi(e);       // A/B switch: which layer shapes take conv_rs.hip
+  if (const char* e = std::getenv("SS4K_RS_W8")) rs_wide = e[0] == '1';          // A/B switch: eight-wave variants of the 32-cout shapes
   SS4K_REQUIRE(n == model_param_count(desc), "weight blob size does not match the model description");
   ParamCursor pc{w, n};
   if (desc.kind == SS4K_FSRCNN) {
@@ -252,7 +254,7 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
   if (in1) { a.in1 = in1->p; a.in1_plane_bytes = in1->plane_bytes; a.in1_plane0 = in1->plane0; a.nchunks1 = L.nchunks1; }
   SS4K_REQUIRE((in1 != nullptr) == (L.nchunks1 > 0), "internal: conv segment mismatch");
   a.N = N; a.H = H; a.W = W; a.ups2 = o.ups2;
-  a.wpk = L.w.ptr; a.wrs = L.wrs.ptr; a.bias = L.bias.as<float>(); a.prelu = L.has_prelu ? L.prelu.as<float>() : nullptr;
+  a.wpk = L.w.ptr; a.wrs = L.wrs.ptr; a.rs_wide = L.rs_wide ? 1 : 0; a.bias = L.bias.as<float>(); a.prelu = L.has_prelu ? L.prelu.as<float>() : nullptr;
   a.act = o.act; a.slope = o.slope; a.alpha = o.alpha; a.gamma = o.gamma;
   if (o.res1) { a.res1 = o.res1->p; a.r1_plane_bytes = o.res1->plane_bytes; a.r1_plane0 = o.res1->plane0; }
   if (o.res2) { a.res2 = o.res2->p; a.r2_plane_bytes = o.res2->plane_bytes; a.r2_plane0 = o.res2->plane0; }
@@ -457,7 +459,7 @@ double bench_conv_layer(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, 
   ss4k_model_desc d{}; d.kind = SS4K_RRDBNET; d.dtype = dtype; d.scale = 2; d.num_feat = 64; d.num_block = 1; d.num_grow_ch = 32;
   Model m; m.ctx = ctx; m.desc = d;
   m.use_rs = (flags & 4096) != 0;   // 4096: the register-stationary kernel (conv_rs.hip) where the shape is built
-  m.rs_mask = 63;
+  m.rs_mask = 63; m.rs_wide = (flags & 8192) != 0;
   const int cin = cin0 + cin1;
   std::vector<float> blob((size_t)cout * cin * 9 + cout);
   uint32_t s = 12345;
@@ -481,7 +483,7 @@ double bench_conv_layer(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, 
   }
   ConvOpts o; o.act = ACT_LRELU; o.slope = 0.2f; o.out = O;
   if ((flags & 2048) && cout <= cin0) { o.act = ACT_NONE; o.alpha = 0.2f; o.res1 = &X; }  // conv5 of an RDB: x5 * 0.2 + x
-  m.dbg = flags & ~(2048 | 4096);
+  m.dbg = flags & ~(2048 | 4096 | 8192);
   DevBuf dbgb; dbgb.ensure(1024 * 16 * 8); SS4K_HIP(hipMemsetAsync(dbgb.ptr, 0, 1024 * 16 * 8, st)); m.dbg_buf = dbgb.as<unsigned long long>();
   for (int i = 0; i < 3; ++i) m.conv(li, X, cin1 ? &G : nullptr, n, h, w, o, st);
   hipEvent_t e0, e1; SS4K_HIP(hipEventCreate(&e0)); SS4K_HIP(hipEventCreate(&e1));

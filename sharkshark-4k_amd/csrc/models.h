@@ -11,6 +11,7 @@ struct Tens { char* p; size_t plane_bytes; int plane0; };
 struct ConvLayer {
   DevBuf w, bias, prelu;
   DevBuf wrs;              // conv_rs.hip weight order (fp16 layers of a supported shape, else empty)
+  bool rs_wide = false;    // ... packed for the eight-wave variant
   bool has_prelu = false;
   int cout_real = 0, cout_pad = 0, cin_real = 0, nchunks0 = 0, nchunks1 = 0;
 };
@@ -51,6 +52,7 @@ struct Model {
   void out_shape(int n, int h, int w, int* oc, int* oh, int* ow) const;
   int in_channels() const;
   int rs_mask = 32;        // layer shapes routed to conv_rs.hip (bit per shape, models.cpp rs_shape_bit); default: RDB conv5
+  bool rs_wide = false;    // eight-wave variants of the 32-cout RS shapes (SS4K_RS_W8=1: A/B switch)
   bool use_rs = true;      // route eligible fp16 layers to the register-stationary kernel (SS4K_NO_RS=1: A/B switch)
   ~Model() {
     for (auto& l : layers) { l.w.release(); l.bias.release(); l.prelu.release(); l.wrs.release(); }

@@ -94,11 +94,11 @@ PackedConv pack_conv3x3(const PackSpec& s, const float* w, const float* bias, co
 //   (= plane 2c + (kq >> 1), channel 8*(kq & 1) + e of that plane).  Row m of block cb of cout group cg is
 //   virtual cout  g*COUT_WG + cg*cb_count*16 + (cb_count == 2 ? 8*(m >> 2) + 4*cb + (m & 3) : m)  so that
 //   result lane (pixel, q) holds cb_count*4 CONSECUTIVE channels (16- or 8-byte stores).
-std::vector<uint8_t> pack_conv3x3_rs(const PackSpec& s, const float* w, int cout_pad, int nch, int rows, int cbn) {
+std::vector<uint8_t> pack_conv3x3_rs(const PackSpec& s, const float* w, int cout_pad, int nch, int cbn, int CG) {
   SS4K_REQUIRE(s.dtype == SS4K_F16, "pack_conv3x3_rs: fp16 only");
   const int nplanes = s.nchunks0 + s.nchunks1;
   SS4K_REQUIRE((int)s.cin_map.size() == nplanes * 16 && nplanes <= 2 * nch, "pack_conv3x3_rs: cin_map size");
-  const int RG = 16 / rows, CG = 4 / RG, COUT_WG = CG * cbn * 16;
+  const int COUT_WG = CG * cbn * 16;
   SS4K_REQUIRE(cout_pad % COUT_WG == 0, "pack_conv3x3_rs: cout_pad");
   const int groups = cout_pad / COUT_WG;
   std::vector<uint8_t> out((size_t)groups * CG * nch * 9 * cbn * 64 * 8 * 2, 0);

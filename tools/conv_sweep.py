@@ -17,10 +17,11 @@ shapes = [("conv1  64->32", 64, 0, 32, 0), ("conv2  96->32", 64, 32, 32, 0), ("c
           ("conv4 160->32", 64, 96, 32, 0), ("conv5 192->64 (+x)", 64, 128, 64, 2048), ("trunk  64->64", 64, 0, 64, 0)]
 print(f"{n} frames of {H}x{W}, median of {rounds} interleaved rounds x 20 launches")
 for name, c0, c1, co, fl in shapes:
-    t = {0: [], 4096: []}
+    t = {0: [], 4096: [], 4096 + 8192: []}
     for r in range(rounds):
-        for rs in (0, 4096):
+        for rs in (0, 4096, 4096 + 8192):
             t[rs].append(ctx.bench_conv(_capi.F16, c0, c1, co, n, H, W, flags=fl | rs, iters=20))
     gf = 2 * 9 * (c0 + c1) * co * n * H * W / 1e9
-    a, b = float(np.median(t[0])), float(np.median(t[4096]))
-    print(f"{name:20s} LDS-weights {a:7.1f} us = {gf / a * 1e3:6.0f} TFLOP/s | register-stationary {b:7.1f} us = {gf / b * 1e3:6.0f} TFLOP/s | x{a / b:.2f}")
+    a, b, c = float(np.median(t[0])), float(np.median(t[4096])), float(np.median(t[4096 + 8192]))
+    print(f"{name:20s} LDS-weights {a:7.1f} us = {gf / a * 1e3:6.0f} TFLOP/s | register-stationary {b:7.1f} us = {gf / b * 1e3:6.0f} TFLOP/s | x{a / b:.2f}"
+          f" | eight-wave RS {c:7.1f} us = {gf / c * 1e3:6.0f} TFLOP/s | x{a / c:.2f}")
