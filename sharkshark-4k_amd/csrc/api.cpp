@@ -89,23 +89,53 @@ struct Upscaler {
     int oc, H, W; sr->out_shape(n, lh, lw, &oc, &H, &W);
     hr.ensure((size_t)P * H * W * 4);
     float* hrp = hr.as<float>();
+    SS4K_REQUIRE(P <= STATS_MAX_PLANES, "too many frames in one job");
+    st_hr.ensure(P * 8); st_lr.ensure(P * 8); st_acc.ensure(sizeof(double) * 2 * P);
+    const int mh = H / 8, mw = W / 8;
+    const bool color = mh > 8 && H > 64 && W > 64;  // local colour match, :201-218
+    // the reference's guard looks at the height only; for HR widths of 65..71 its 17-tap reflect pad (8)
+    // reaches the 8-pixel-wide map and torch raises - so does this build
+    SS4K_REQUIRE(!color || mw > 8, "local colour match: HR width / 8 must exceed the 17-tap blur's reflect padding (torch raises here too)");
+    const bool resize = cfg.out_h > 0 && cfg.lr_hr_resize && !(cfg.out_h == H && cfg.out_w == W);
     const double tm0 = now_ms();
+    if (!taps_on) sr->out_stats_acc = st_acc.as<double>();   // statistics of hr ride along with its producer where it can
     sr->forward(lrp, hrp, n, lh, lw, st);
     enq_model_ms = now_ms() - tm0; enq_denoise_ms = 0;
+    sr->out_stats_acc = nullptr;
+    if (!taps_on) {
+      // ---- fused path: the HR tensor is written once by the network, then read by the statistics (unless they rode
+      // along), by the area reduction and by ONE tail pass; every per-element expression is the unfused path's
+      if (sr->out_stats_done) op_plane_stats_finish(st_acc.as<double>(), st_hr.as<float>(), P, H * W, st);
+      else op_plane_stats(st_acc.as<double>(), hrp, st_hr.as<float>(), P, H * W, st);
+      op_plane_stats(st_acc.as<double>(), lrp, st_lr.as<float>(), P, lh * lw, st);
+      const float* diff = nullptr;
+      if (color) {
+        const size_t sm = (size_t)P * mh * mw * 4;
+        lb.ensure(sm); hb.ensure(sm); lbb.ensure(sm); hbb.ensure(sm);
+        op_area(lrp, lb.as<float>(), P, lh, lw, mh, mw, st);
+        op_area_normalized(hrp, hb.as<float>(), P, H, W, mh, mw, st_hr.as<float>(), st_lr.as<float>(), st);
+        op_depthwise_reflect(lb.as<float>(), lbb.as<float>(), k_blur17.as<float>(), P, mh, mw, 17, 0, nullptr, 0, 0, st);
+        op_depthwise_reflect(hb.as<float>(), hbb.as<float>(), k_blur17.as<float>(), P, mh, mw, 17, 0, nullptr, 0, 0, st);
+        op_sub(hbb.as<float>(), lbb.as<float>(), hb.as<float>(), (size_t)P * mh * mw, st);
+        diff = hb.as<float>();
+      }
+      if (!resize) {
+        // normalise, - diff, clamp, * 255 -> uint8 NHWC in one read of hr
+        op_tail_fused(hrp, out, diff, n, 3, H, W, mh, mw, st_hr.as<float>(), st_lr.as<float>(), st);
+      } else {
+        // normalise, - diff, clamp in place (bicubic reads 16 neighbours of the finished tensor), then bicubic -> uint8
+        op_tail_fused(hrp, nullptr, diff, n, 3, H, W, mh, mw, st_hr.as<float>(), st_lr.as<float>(), st);
+        op_bicubic_u8(hrp, out, n, 3, H, W, cfg.out_h, cfg.out_w, st);
+      }
+      return;
+    }
+    // ---- unfused path (parity taps enabled): one kernel per torch call of the reference
     save_tap(0, lrp, n, 3, lh, lw, st); save_tap(1, hrp, n, 3, H, W, st);
-    st_hr.ensure(P * 8); st_lr.ensure(P * 8);
-    SS4K_REQUIRE(P <= STATS_MAX_PLANES, "too many frames in one job");
-    st_acc.ensure(sizeof(double) * 2 * P);
     op_plane_stats(st_acc.as<double>(), hrp, st_hr.as<float>(), P, H * W, st);
     op_plane_stats(st_acc.as<double>(), lrp, st_lr.as<float>(), P, lh * lw, st);
     op_normalize(hrp, st_hr.as<float>(), st_lr.as<float>(), P, H * W, st);
     save_tap(2, hrp, n, 3, H, W, st);
-    const int mh = H / 8, mw = W / 8;
-    bool clamped = false;
-    if (mh > 8 && H > 64 && W > 64) {  // local colour match, :201-218
-      // the reference's guard looks at the height only; for HR widths of 65..71 its 17-tap reflect pad (8)
-      // reaches the 8-pixel-wide map and torch raises - so does this build
-      SS4K_REQUIRE(mw > 8, "local colour match: HR width / 8 must exceed the 17-tap blur's reflect padding (torch raises here too)");
+    if (color) {
       const size_t sm = (size_t)P * mh * mw * 4;
       lb.ensure(sm); hb.ensure(sm); lbb.ensure(sm); hbb.ensure(sm);
       op_area(lrp, lb.as<float>(), P, lh, lw, mh, mw, st);
@@ -113,17 +143,14 @@ struct Upscaler {
       op_depthwise_reflect(lb.as<float>(), lbb.as<float>(), k_blur17.as<float>(), P, mh, mw, 17, 0, nullptr, 0, 0, st);
       op_depthwise_reflect(hb.as<float>(), hbb.as<float>(), k_blur17.as<float>(), P, mh, mw, 17, 0, nullptr, 0, 0, st);
       op_sub(hbb.as<float>(), lbb.as<float>(), hb.as<float>(), (size_t)P * mh * mw, st);
-      // hr -= diff, then clamp(0,1) (:217,:220): one pass over the HR tensor unless the unclamped
-      // value is being tapped
-      clamped = !taps_on;
-      op_bilinear(hb.as<float>(), hrp, P, mh, mw, H, W, /*subtract_from_out=*/1, clamped ? 1 : 0, st);
+      op_bilinear(hb.as<float>(), hrp, P, mh, mw, H, W, /*subtract_from_out=*/1, 0, st);   // hr -= diff (:217)
     }
     save_tap(3, hrp, n, 3, H, W, st);
-    if (!clamped) op_clamp01(hrp, (size_t)P * H * W, st);
+    op_clamp01(hrp, (size_t)P * H * W, st);
     const float* fin = hrp; int FH = H, FW = W;
     // always bicubic (quirk, :224-231).  At equal size align_corners=False bicubic has taps (0,1,0,0):
     // the identity on already clamped values, so that pass is skipped
-    if (cfg.out_h > 0 && cfg.lr_hr_resize && !(cfg.out_h == H && cfg.out_w == W)) {
+    if (resize) {
       FH = cfg.out_h; FW = cfg.out_w;
       hr2.ensure((size_t)P * FH * FW * 4);
       op_bicubic(hrp, hr2.as<float>(), P, H, W, FH, FW, 1, st);
@@ -181,6 +208,16 @@ struct Upscaler {
     st_acc.ensure(sizeof(double) * 2 * P);
     op_plane_stats(st_acc.as<double>(), hrp, st_hr.as<float>(), P, H * W, st);
     op_plane_stats(st_acc.as<double>(), lr_before, st_lr.as<float>(), P, lh * lw, st);
+    if (!taps_on) {
+      // fused tail: normalise -> clamp -> [bicubic] -> uint8 without writing the normalised tensor (same expressions)
+      const bool rs_ = cfg.out_h > 0 && !(cfg.out_h == H && cfg.out_w == W);
+      if (!rs_) op_tail_fused(hrp, out, nullptr, n, 3, H, W, 1, 1, st_hr.as<float>(), st_lr.as<float>(), st);
+      else {
+        op_tail_fused(hrp, nullptr, nullptr, n, 3, H, W, 1, 1, st_hr.as<float>(), st_lr.as<float>(), st);
+        op_bicubic_u8(hrp, out, n, 3, H, W, cfg.out_h, cfg.out_w, st);
+      }
+      return;
+    }
     op_normalize(hrp, st_hr.as<float>(), st_lr.as<float>(), P, H * W, st);
     save_tap(2, hrp, n, 3, H, W, st);
     op_clamp01(hrp, (size_t)P * H * W, st);

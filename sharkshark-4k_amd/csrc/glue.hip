@@ -16,6 +16,14 @@ static inline dim3 grid1d(size_t n, int block = 256) {
   return dim3((unsigned)std::max<size_t>(g, 1));
 }
 
+// channel-statistics normalisation, hr = (hr - mean_hr) / (std_hr + 1e-8) * std_lr + mean_lr (fsrcnn_upscaler.py:198-199):
+// ONE expression shared by the stand-alone pass and by every kernel that applies it on the fly
+struct NormCoef { float mh, sh, ml, sl; };
+__device__ __forceinline__ NormCoef norm_coef(const float* __restrict__ st_hr, const float* __restrict__ st_lr, int pl) {
+  return NormCoef{st_hr[2 * pl], st_hr[2 * pl + 1] + 1e-8f, st_lr[2 * pl], st_lr[2 * pl + 1]};
+}
+__device__ __forceinline__ float norm_px(float v, const NormCoef& k) { return (v - k.mh) / k.sh * k.sl + k.ml; }
+
 // ------------------------------------------------------------------ u8 NHWC -> f32 NCHW (/255)
 __global__ void k_u8nhwc_to_f32nchw(const uint8_t* __restrict__ in, float* __restrict__ out, int n, int h,
                                     int w, int c) {
@@ -34,10 +42,14 @@ void op_u8nhwc_to_f32nchw(const uint8_t* in, float* out, int n, int h, int w, in
 __device__ __forceinline__ int a_start(int i, int in, int out) { return (int)floorf((float)(i * in) / out); }
 __device__ __forceinline__ int a_end(int i, int in, int out) { return (int)ceilf((float)((i + 1) * in) / out); }
 
-// one block row per output row (blockIdx.y = oy, blockIdx.z = plane): no per-element divisions
+// one block row per output row (blockIdx.y = oy, blockIdx.z = plane): no per-element divisions.
+// NORM: the input is read through the channel-statistics normalisation (the normalised tensor is never written)
+template <bool NORM>
 __global__ void k_area(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int oh,
-                       int ow) {
+                       int ow, const float* __restrict__ st_hr, const float* __restrict__ st_lr) {
   const int oy = blockIdx.y, pl = blockIdx.z;
+  NormCoef nk{};
+  if constexpr (NORM) nk = norm_coef(st_hr, st_lr, pl);
   const int y0 = a_start(oy, h, oh), y1 = a_end(oy, h, oh);
   const float* src = in + (size_t)pl * h * w;
   float* dst = out + ((size_t)pl * oh + oy) * ow;
@@ -45,7 +57,7 @@ __global__ void k_area(const float* __restrict__ in, float* __restrict__ out, in
     const int x0 = a_start(ox, w, ow), x1 = a_end(ox, w, ow);
     float sum = 0.f;
     for (int y = y0; y < y1; ++y)
-      for (int x = x0; x < x1; ++x) sum += src[(size_t)y * w + x];
+      for (int x = x0; x < x1; ++x) sum += NORM ? norm_px(src[(size_t)y * w + x], nk) : src[(size_t)y * w + x];
     dst[ox] = sum / (float)(y1 - y0) / (float)(x1 - x0);
   }
 }
@@ -56,7 +68,12 @@ void op_area(const float* in, float* out, int planes, int h, int w, int oh, int 
     return;
   }
   SS4K_REQUIRE(oh <= 65535 && planes <= 65535, "area: grid limits");
-  hipLaunchKernelGGL(k_area, grid_rows(ow, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow); SS4K_LAUNCH_OK();
+  hipLaunchKernelGGL(k_area<false>, grid_rows(ow, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow, nullptr, nullptr); SS4K_LAUNCH_OK();
+}
+void op_area_normalized(const float* in, float* out, int planes, int h, int w, int oh, int ow, const float* st_hr, const float* st_lr,
+                        hipStream_t st) {
+  SS4K_REQUIRE(oh <= 65535 && planes <= 65535, "area: grid limits");
+  hipLaunchKernelGGL(k_area<true>, grid_rows(ow, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow, st_hr, st_lr); SS4K_LAUNCH_OK();
 }
 
 // ------------------------------------------------------------------ per-plane mean / unbiased std
@@ -90,23 +107,29 @@ __global__ void k_stats_final(const double* __restrict__ acc, float* __restrict_
   stats[2 * p] = (float)mean;
   stats[2 * p + 1] = (float)sqrt(var);
 }
+void op_plane_stats_finish(const double* acc, float* stats, int planes, int hw, hipStream_t st) {
+  hipLaunchKernelGGL(k_stats_final, dim3((planes + 63) / 64), dim3(64), 0, st, acc, stats, planes, hw); SS4K_LAUNCH_OK();
+}
 void op_plane_stats(double* acc, const float* in, float* stats, int planes, int hw, hipStream_t st) {
   SS4K_REQUIRE(planes <= STATS_MAX_PLANES, "plane_stats: too many planes");
   SS4K_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 2 * planes, st));
   int gx = (hw + 256 * 16 - 1) / (256 * 16);
   gx = std::max(1, std::min(gx, 512));
   hipLaunchKernelGGL(k_stats_partial, dim3(gx, planes), dim3(256), 0, st, in, acc, hw); SS4K_LAUNCH_OK();
-  hipLaunchKernelGGL(k_stats_final, dim3((planes + 63) / 64), dim3(64), 0, st, acc, stats, planes, hw); SS4K_LAUNCH_OK();
+  op_plane_stats_finish(acc, stats, planes, hw, st);
 }
 
-// hr = (hr - mean_hr) / (std_hr + 1e-8) * std_lr + mean_lr   (fsrcnn_upscaler.py:198-199, :312-313)
+// hr = (hr - mean_hr) / (std_hr + 1e-8) * std_lr + mean_lr   (fsrcnn_upscaler.py:198-199, :312-313).
+// One expression, used by the stand-alone pass and by every consumer that applies it on the fly: the fused and
+// the unfused service paths produce bit-identical frames.
+
 __global__ void k_normalize(float* __restrict__ x, const float* __restrict__ st_hr, const float* __restrict__ st_lr,
                             int planes, int hw) {
   const int pl = blockIdx.y;
-  const float mh = st_hr[2 * pl], sh = st_hr[2 * pl + 1] + 1e-8f, ml = st_lr[2 * pl], sl = st_lr[2 * pl + 1];
+  const NormCoef k = norm_coef(st_hr, st_lr, pl);
   float* p = x + (size_t)pl * hw;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)hw; i += (size_t)gridDim.x * blockDim.x)
-    p[i] = (p[i] - mh) / sh * sl + ml;
+    p[i] = norm_px(p[i], k);
 }
 void op_normalize(float* x, const float* st_hr, const float* st_lr, int planes, int hw, hipStream_t st) {
   int gx = std::max(1, std::min((hw + 255) / 256, 1024));
@@ -246,6 +269,95 @@ void op_bicubic(const float* in, float* out, int planes, int h, int w, int oh, i
   hipLaunchKernelGGL(k_bicubic, grid_rows(ow, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow, clamp01); SS4K_LAUNCH_OK();
 }
 
+// ------------------------------------------------------------------ fused tails of the service path
+// One pass from the network's raw fp32 output to the next tensor of the path, applying in the reference's order
+//   [normalise (:198-199)] -> [- bilinear(diff) (:214-217)] -> clamp(0,1) (:220) -> [* 255, truncate to uint8 NHWC (:232-233)]
+// with exactly the per-element expressions of the stand-alone kernels (k_normalize, k_bilinear, k_clamp01,
+// k_f32nchw_to_u8nhwc), so the frames are bit-identical to the unfused path.
+// U8: write uint8 NHWC (three planes of a pixel by one thread); else write the clamped float back in place.
+template <bool NORM, bool DIFF, bool U8>
+__global__ void k_tail_fused(float* __restrict__ hr, uint8_t* __restrict__ out, const float* __restrict__ diff, int n, int c, int h, int w,
+                             int dh, int dw, const float* __restrict__ st_hr, const float* __restrict__ st_lr) {
+  const int oy = blockIdx.y, img = blockIdx.z;
+  // bilinear, align_corners=False: same arithmetic as k_bilinear
+  const float sy = (float)dh / h, sx = (float)dw / w;
+  float fy = sy * (oy + 0.5f) - 0.5f; if (fy < 0) fy = 0;
+  const int y0 = (int)fy, y1 = y0 + (y0 < dh - 1 ? 1 : 0);
+  const float ly = fy - y0, hy = 1.f - ly;
+  for (int ox = blockIdx.x * blockDim.x + threadIdx.x; ox < w; ox += gridDim.x * blockDim.x) {
+    float fx = sx * (ox + 0.5f) - 0.5f; if (fx < 0) fx = 0;
+    const int x0 = (int)fx, x1 = x0 + (x0 < dw - 1 ? 1 : 0);
+    const float lx = fx - x0, hx = 1.f - lx;
+    for (int k = 0; k < c; ++k) {
+      const int pl = img * c + k;
+      const size_t idx = ((size_t)pl * h + oy) * w + ox;
+      float v = hr[idx];
+      if constexpr (NORM) v = norm_px(v, norm_coef(st_hr, st_lr, pl));
+      if constexpr (DIFF) {
+        const float* r0 = diff + ((size_t)pl * dh + y0) * dw; const float* r1 = diff + ((size_t)pl * dh + y1) * dw;
+        const float d = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
+        v = v - d;
+      }
+      v = fminf(fmaxf(v, 0.f), 1.f);
+      if constexpr (U8) out[(((size_t)img * h + oy) * w + ox) * c + k] = (uint8_t)(fminf(fmaxf(v, 0.f), 1.f) * 255.f);
+      else hr[idx] = v;
+    }
+  }
+}
+void op_tail_fused(float* hr, uint8_t* out_u8, const float* diff, int n, int c, int h, int w, int dh, int dw, const float* st_hr,
+                   const float* st_lr, hipStream_t st) {
+  SS4K_REQUIRE(h <= 65535 && n <= 65535, "fused tail: grid limits");
+  const dim3 g = grid_rows(w, h, n);
+  const bool norm = st_hr != nullptr, df = diff != nullptr, u8 = out_u8 != nullptr;
+#define SS4K_TAIL(N_, D_, U_) hipLaunchKernelGGL((k_tail_fused<N_, D_, U_>), g, dim3(256), 0, st, hr, out_u8, diff, n, c, h, w, dh, dw, st_hr, st_lr)
+  if (norm && df && u8) SS4K_TAIL(true, true, true); else if (norm && df) SS4K_TAIL(true, true, false);
+  else if (norm && u8) SS4K_TAIL(true, false, true); else if (norm) SS4K_TAIL(true, false, false);
+  else if (df && u8) SS4K_TAIL(false, true, true); else if (df) SS4K_TAIL(false, true, false);
+  else if (u8) SS4K_TAIL(false, false, true); else SS4K_TAIL(false, false, false);
+#undef SS4K_TAIL
+  SS4K_LAUNCH_OK();
+}
+
+// bicubic (A = -0.75, align_corners=False: k_bicubic's arithmetic) of an already clamped tensor, then
+// clamp(0,1) * 255 truncated to uint8 NHWC: the resized float tensor is never written
+__global__ void k_bicubic_u8(const float* __restrict__ in, uint8_t* __restrict__ out, int n, int c, int h, int w, int oh, int ow) {
+  const int oy = blockIdx.y, img = blockIdx.z;
+  const float sy = (float)h / oh, sx = (float)w / ow;
+  const float fy = sy * (oy + 0.5f) - 0.5f, fly = floorf(fy);
+  const int iy = (int)fly;
+  float cy[4];
+  cubic_coeffs(fy - fly, cy);
+  int yi[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) yi[a] = min(max(iy - 1 + a, 0), h - 1);
+  for (int ox = blockIdx.x * blockDim.x + threadIdx.x; ox < ow; ox += gridDim.x * blockDim.x) {
+    const float fx = sx * (ox + 0.5f) - 0.5f, flx = floorf(fx);
+    const int ix = (int)flx;
+    float cx[4]; int xi[4];
+    cubic_coeffs(fx - flx, cx);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) xi[b] = min(max(ix - 1 + b, 0), w - 1);
+    for (int k = 0; k < c; ++k) {
+      const float* src = in + (size_t)(img * c + k) * h * w;
+      float acc = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const float* rowp = src + (size_t)yi[a] * w;
+        float row = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) row += cx[b] * rowp[xi[b]];
+        acc += cy[a] * row;
+      }
+      acc = fminf(fmaxf(acc, 0.f), 1.f);
+      out[(((size_t)img * oh + oy) * ow + ox) * c + k] = (uint8_t)(fminf(fmaxf(acc, 0.f), 1.f) * 255.f);
+    }
+  }
+}
+void op_bicubic_u8(const float* in, uint8_t* out, int n, int c, int h, int w, int oh, int ow, hipStream_t st) {
+  SS4K_REQUIRE(oh <= 65535 && n <= 65535, "bicubic: grid limits");
+  hipLaunchKernelGGL(k_bicubic_u8, grid_rows(ow, oh, n), dim3(256), 0, st, in, out, n, c, h, w, oh, ow); SS4K_LAUNCH_OK();
+}
+
 // ------------------------------------------------------------------ elementwise helpers
 __global__ void k_sub(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -326,13 +438,14 @@ template void op_pack_input<__half>(const float*, __half*, int, int, int, int, i
 // fp32 NCHW planes plus the nearest-upsampled network input.
 // One thread per LR pixel and colour: the r*r channels of that colour are one contiguous run of its
 // record(s), read with 16-byte loads, and leave as r rows of r floats (16-byte stores for r = 4).
-template <typename T, int R>
-__global__ void k_ps_nchw_addbase(const T* __restrict__ src, float* __restrict__ out, const float* __restrict__ base,
-                                  int n, int h, int w, int cq) {
+template <typename T, int R, bool STATS>
+__global__ __launch_bounds__(256) void k_ps_nchw_addbase(const T* __restrict__ src, float* __restrict__ out, const float* __restrict__ base,
+                                  int n, int h, int w, int cq, double* __restrict__ acc) {
   constexpr int CW = 16, RR = R * R;
   const int y = blockIdx.y, img = blockIdx.z;
   const int OH = h * R, OW = w * R;
   const size_t npix = (size_t)n * h * w;
+  double ps[4] = {0, 0, 0, 0}, pq[4] = {0, 0, 0, 0};   // per colour (cq <= 4) partial sum / sum of squares of this thread
   for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) {
     const size_t pix = ((size_t)img * h + y) * w + x;
     for (int c = 0; c < cq; ++c) {
@@ -347,28 +460,56 @@ __global__ void k_ps_nchw_addbase(const T* __restrict__ src, float* __restrict__
       }
       const float b = base[(((size_t)img * cq + c) * h + y) * w + x];
       float* o = out + (((size_t)img * cq + c) * OH + (size_t)y * R) * OW + (size_t)x * R;
+      float f[RR];
+#pragma unroll
+      for (int k = 0; k < RR; ++k) f[k] = (float)v[k] + b;
 #pragma unroll
       for (int dy = 0; dy < R; ++dy) {
-        if constexpr (R == 4) {
-          *reinterpret_cast<float4*>(o + (size_t)dy * OW) = make_float4((float)v[dy * 4] + b, (float)v[dy * 4 + 1] + b,
-                                                                        (float)v[dy * 4 + 2] + b, (float)v[dy * 4 + 3] + b);
-        } else {
-          *reinterpret_cast<float2*>(o + (size_t)dy * OW) = make_float2((float)v[dy * 2] + b, (float)v[dy * 2 + 1] + b);
-        }
+        if constexpr (R == 4) *reinterpret_cast<float4*>(o + (size_t)dy * OW) = make_float4(f[dy * 4], f[dy * 4 + 1], f[dy * 4 + 2], f[dy * 4 + 3]);
+        else *reinterpret_cast<float2*>(o + (size_t)dy * OW) = make_float2(f[dy * 2], f[dy * 2 + 1]);
       }
+      if constexpr (STATS) {
+#pragma unroll
+        for (int k = 0; k < RR; ++k) { const double d = f[k]; ps[c] += d; pq[c] += d * d; }
+      }
+    }
+  }
+  if constexpr (STATS) {
+    // plane statistics of the tensor being written (fsrcnn_upscaler.py:192-197) ride along: fp64 partials per
+    // workgroup, one atomic pair per colour - the separate read pass over the HR tensor is gone
+    __shared__ double ss[4][4], sq[4][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int c = 0; c < cq; ++c) {
+      double s_ = ps[c], q_ = pq[c];
+      for (int off = 32; off > 0; off >>= 1) { s_ += __shfl_down(s_, off, 64); q_ += __shfl_down(q_, off, 64); }
+      if (lane == 0) { ss[c][wv] = s_; sq[c][wv] = q_; }
+    }
+    __syncthreads();
+    if (threadIdx.x < cq) {
+      const int c = threadIdx.x;
+      double S = 0, Q = 0;
+      for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { S += ss[c][i]; Q += sq[c][i]; }
+      atomicAdd(&acc[2 * (img * cq + c)], S);
+      atomicAdd(&acc[2 * (img * cq + c) + 1], Q);
     }
   }
 }
 template <typename T>
-void op_ps_nchw_addbase(const T* src, float* out, const float* base, int n, int h, int w, int r, int cq, hipStream_t st) {
+void op_ps_nchw_addbase(const T* src, float* out, const float* base, int n, int h, int w, int r, int cq, double* stats_acc, hipStream_t st) {
   SS4K_REQUIRE(h <= 65535 && n <= 65535, "pixel shuffle tail: grid limits");
-  if (r == 4) { hipLaunchKernelGGL((k_ps_nchw_addbase<T, 4>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq); }
-  else if (r == 2) { hipLaunchKernelGGL((k_ps_nchw_addbase<T, 2>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq); }
-  else throw Error(SS4K_EINVAL, "SRVGG: upscale must be 2 or 4");
+  SS4K_REQUIRE(!stats_acc || cq <= 4, "pixel shuffle tail: statistics for at most 4 colours");
+  if (stats_acc) SS4K_HIP(hipMemsetAsync(stats_acc, 0, sizeof(double) * 2 * n * cq, st));
+  if (r == 4) {
+    if (stats_acc) { hipLaunchKernelGGL((k_ps_nchw_addbase<T, 4, true>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq, stats_acc); }
+    else { hipLaunchKernelGGL((k_ps_nchw_addbase<T, 4, false>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq, stats_acc); }
+  } else if (r == 2) {
+    if (stats_acc) { hipLaunchKernelGGL((k_ps_nchw_addbase<T, 2, true>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq, stats_acc); }
+    else { hipLaunchKernelGGL((k_ps_nchw_addbase<T, 2, false>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq, stats_acc); }
+  } else throw Error(SS4K_EINVAL, "SRVGG: upscale must be 2 or 4");
   SS4K_LAUNCH_OK();
 }
-template void op_ps_nchw_addbase<float>(const float*, float*, const float*, int, int, int, int, int, hipStream_t);
-template void op_ps_nchw_addbase<__half>(const __half*, float*, const float*, int, int, int, int, int, hipStream_t);
+template void op_ps_nchw_addbase<float>(const float*, float*, const float*, int, int, int, int, int, double*, hipStream_t);
+template void op_ps_nchw_addbase<__half>(const __half*, float*, const float*, int, int, int, int, int, double*, hipStream_t);
 
 // BSVD stream mode: the ShiftConv input of frame t (bsvd/model.py:42-53,95-138) takes channels
 // [0, fold) from frame t+1, [fold, 2*fold) from frame t-1 (zeros past either end of the stream) and

@@ -314,6 +314,7 @@ void Model::pack_in(const float* in, const Tens& dst, int nplanes, int n, int c,
 
 void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_t st) {
   SS4K_REQUIRE(n > 0 && h > 0 && w > 0, "forward: empty input");
+  out_stats_done = false;
   const bool f16 = desc.dtype == SS4K_F16;
   if (desc.kind != SS4K_FSRCNN) {
     // the conv kernel indexes the pixels of a plane with 32 bits: split batches whose largest internal
@@ -327,6 +328,7 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
     int max_n = std::max(1, (int)(2147483647.0 / plane1));
     if (sub_batch > 0) max_n = std::min(max_n, sub_batch);
     if (n > max_n) {
+      out_stats_acc = nullptr;   // per-plane accumulation is not offered across a split batch: the caller makes its own pass
       for (int i = 0; i < n; i += max_n) {
         const int nn = std::min(max_n, n - i);
         forward(in + (size_t)i * in_channels() * h * w, out + (size_t)i * oc * oh * ow, nn, h, w, st);
@@ -399,8 +401,10 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
     Tens Z = act(3, px, layers[li].cout_pad);
     { ConvOpts o; o.out = Z; conv(li++, cur, nullptr, n, h, w, o, st); }
     if (plan_only) return;
-    if (f16) op_ps_nchw_addbase<__half>(reinterpret_cast<const __half*>(Z.p), out, in, n, h, w, desc.scale, 3, st);
-    else op_ps_nchw_addbase<float>(reinterpret_cast<const float*>(Z.p), out, in, n, h, w, desc.scale, 3, st);
+    // the service may ask for the output's plane statistics to be accumulated while it is written
+    double* sacc = out_stats_acc; out_stats_acc = nullptr; out_stats_done = sacc != nullptr;
+    if (f16) op_ps_nchw_addbase<__half>(reinterpret_cast<const __half*>(Z.p), out, in, n, h, w, desc.scale, 3, sacc, st);
+    else op_ps_nchw_addbase<float>(reinterpret_cast<const float*>(Z.p), out, in, n, h, w, desc.scale, 3, sacc, st);
     return;
   }
   // ---- BSVD, one frame per call -----------------------------------------------------------

@@ -44,6 +44,10 @@ struct Model {
   bool plan_only = false;
   std::vector<size_t> plan_bytes;
   size_t workspace_bytes(int n, int h, int w);
+  // one-shot request of the caller (the service): accumulate sum / sum of squares per output plane into this buffer
+  // while the output is written (networks whose tail can do it set out_stats_done; the batch must not be split)
+  double* out_stats_acc = nullptr;
+  bool out_stats_done = false;
   int dbg = 0;  // ablation build selector forwarded to the conv kernel (bench only)
   unsigned long long* dbg_buf = nullptr;
 

@@ -503,3 +503,35 @@ def test_stream_dispatcher_over_two_hip_services():
     finally:
         for s_ in svcs:
             s_.stop()
+
+
+# ------------------------------------------------------------------------------ fused service tails
+@pytest.mark.parametrize("name", [n for n in CASES if n.startswith("svc_")])
+def test_fused_tails_are_bit_identical_to_the_unfused_path(ctx, name):
+    """Without parity taps the service runs fused tails (statistics riding along with the producer, normalisation
+    applied on the fly by its consumers, clamp / bicubic / uint8 in one pass).  Every per-element expression is
+    shared with the one-kernel-per-torch-call path the taps use, so the frames must be IDENTICAL - and both are
+    checked against the frames the reference produced."""
+    g = load_golden(name)
+    frames = dev(g["frames"])
+    up_f, keep_f = _hip_service_from_manifest(ctx, CASES[name])
+    up_u, keep_u = _hip_service_from_manifest(ctx, CASES[name])
+    up_u.enable_taps(True)
+    for job, key in enumerate(("out1", "out2")):
+        a, b = up_f(frames), up_u(frames)
+        assert torch.equal(a, b), f"{name} job {job}: fused and unfused frames differ in {int((a != b).sum())} bytes"
+        assert_u8_close(a, g[key], what=f"{name} fused job {job}")
+
+
+def test_fused_tails_full_size_identical(ctx):
+    """Same at the shipped default's size (SRVGG x4 on 720p, bicubic to 1440p, colour match on) in fp16, where the
+    statistics come out of the PixelShuffle tail's accumulators: mean / std may differ in the last fp64 bits of
+    the sum, so frames are compared within 1 LSB and must be almost everywhere identical."""
+    sr = factory.build_model_esrgan(ctx, "realesr-general-x4v3", weights="synthetic", dtype="f16", seed=3)
+    up_f = _capi.Upscaler(ctx, sr, (720, 1280), (1440, 2560), True, False, None, 0.5)
+    up_u = _capi.Upscaler(ctx, sr, (720, 1280), (1440, 2560), True, False, None, 0.5)
+    up_u.enable_taps(True)
+    frames = torch.from_numpy(smooth_u8(12, (2, 720, 1280, 3))).cuda()
+    a, b = up_f(frames), up_u(frames)
+    d = (a.int() - b.int()).abs()
+    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-4, (int(d.max()), float((d > 0).float().mean()))
