@@ -1,0 +1,36 @@
+#!/bin/bash
+# Run ON THE GPU BOX (gpurun): collects the round's rocprofv3 evidence into gpurun_out/<tag>/ ; the summaries are then
+# copied into profiles/ (tracked).  usage: bash tools/collect_profiles.sh r02a
+# PMC counters go in their own runs with --kernel-trace only (never with sys/hip traces: gpurun refuses that).
+set -u
+TAG=${1:-r02}
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/$TAG; mkdir -p $O
+B="python3 bench.py --no-cpu-baseline --no-also"
+# 1. headline: per-kernel stats + the bench line printed under the profiler
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/st -- $B --steps 5 --warmup 2 > $O/bench_under_rocprof.log 2>&1
+cp $(find $O/st -name "*kernel_stats.csv" | head -1) $O/${TAG}_rrdbnet_x2_720p_batch4_kernel_stats.csv
+grep '^{' $O/bench_under_rocprof.log | tail -1 > $O/${TAG}_bench_line_under_rocprof.json
+rm -rf $O/st
+# 2. headline: fabric traffic of the conv launches (separate passes)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B --steps 2 --warmup 1 --no-roofline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B --steps 2 --warmup 1 --no-roofline > /dev/null 2>&1
+python3 tools/pmc_traffic.py $O/fetch $O/write $O/${TAG}_conv3x3_pmc_traffic.json 4 > /dev/null
+rm -rf $O/fetch $O/write
+# 3. headline: SQ counters (matrix-pipe share, LDS conflicts, wait shares) and L2 hit rate, per kernel
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS \
+  --kernel-trace --output-format csv -d $O/sq -- $B --steps 1 --warmup 1 --no-roofline > /dev/null 2>&1
+python3 tools/pmc_summary.py $O/sq $O/${TAG}_rrdbnet_sq_counters.json > /dev/null
+rm -rf $O/sq
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/tcc -- $B --steps 1 --warmup 1 --no-roofline > /dev/null 2>&1
+python3 tools/pmc_summary.py $O/tcc $O/${TAG}_rrdbnet_tcc_counters.json > /dev/null
+rm -rf $O/tcc
+# 4. the other workloads: per-kernel stats
+for wl in fsrcnn pipeline srvgg rrdbnet_x4; do
+  extra=""; [ $wl = rrdbnet_x4 ] && extra="--batch 1"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/st -- python3 bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-also --no-roofline $extra > $O/bench_$wl.log 2>&1
+  cp $(find $O/st -name "*kernel_stats.csv" | head -1) $O/${TAG}_${wl}_kernel_stats.csv
+  rm -rf $O/st
+done
+ls -la $O
