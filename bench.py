@@ -33,8 +33,10 @@ from sharkshark4k_amd.upscale import model as factory  # noqa: E402
 
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16
 F32_VECTOR_PEAK_TFLOPS = 157.3
-PMC_TRAFFIC_FILE = "r01j_conv3x3_pmc_traffic.json"  # refreshed whenever the conv kernel changes (tools/pmc_traffic.py)
-CONV_KERNEL_NAME = "ss4k::conv3x3_kernel<__half,NB> (implicit-GEMM 3x3 conv, v_mfma_f32_32x32x16_f16)"
+PMC_TRAFFIC_FILE = "r02a_conv3x3_pmc_traffic.json"  # refreshed whenever the conv kernel changes (tools/pmc_traffic.py)
+CONV_KERNEL_NAME = ("3x3 implicit-GEMM conv, all launches of a step: ss4k::conv3x3_kernel<__half,NB> (LDS weights, "
+                    "v_mfma_f32_32x32x16_f16) + ss4k::rs::conv3x3_rs_kernel<6,16,1,4> (register-stationary weights, "
+                    "v_mfma_f32_16x16x32_f16; conv5 of every RDB)")
 
 WORKLOADS = {
     "rrdbnet": "RealESRGAN RRDBNet x2 (23 blocks) 720p->1440p fp16 [BASELINE configs[2]]",
