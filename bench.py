@@ -218,13 +218,19 @@ def conv_roofline(ctx, up, frames, out, psteps=3):
         up(frames, out)
     torch.cuda.synchronize()
     launches, ms, flops = ctx.prof_read()
+    sec_ms = ctx.prof_read_section_ms()
     ctx.prof_enable(False)
-    if launches <= 0 or ms <= 0:
+    if launches <= 0 or ms <= 0 or sec_ms <= 0:
         return None
-    ach = flops / (ms * 1e-3) / 1e12
+    # frame lanes: an even job may run as two concurrent launch chains (half of the frames each), so the per-launch
+    # durations overlap.  The rate is therefore taken over the conv SECTION of each forward - wall time on the caller's
+    # stream from its first conv launch to the end of its last, launch boundaries included: algorithmic FLOPs of all
+    # launches / section time = FLOPs per launch / (average launch duration / launches in flight).  With one chain the
+    # section time is the sum of the launch durations plus the boundaries between them.
+    ach = flops / (sec_ms * 1e-3) / 1e12
     return {"achieved": ach, "frac": ach / MFMA_F16_DENSE_PEAK_TFLOPS, "launches_per_step": launches / psteps,
             "avg_launch_us": 1000.0 * ms / launches, "algorithmic_gflop_per_launch": flops / launches / 1e9,
-            "conv_ms_per_step": ms / psteps}
+            "concurrent_launches": ms / sec_ms, "conv_ms_per_step": sec_ms / psteps}
 
 
 def host_cpu():
@@ -305,9 +311,11 @@ def main():
                                   "unit": "TFLOP/s", "frac": rl["frac"], "traffic": traffic,
                                   "traffic_unit": "bytes per launch (L2<->fabric, PMC)", "traffic_source": traffic_src,
                                   "kernel": CONV_KERNEL_NAME,
-                                  "launches_per_step": rl["launches_per_step"], "frames_per_launch": args.batch,
+                                  "launches_per_step": rl["launches_per_step"],
                                   "avg_launch_us": rl["avg_launch_us"],
                                   "algorithmic_gflop_per_launch": rl["algorithmic_gflop_per_launch"],
+                                  "concurrent_launches": rl["concurrent_launches"],
+                                  "frames_per_launch": args.batch * 351.0 / rl["launches_per_step"],
                                   "kernel_time_share_of_step": rl["conv_ms_per_step"] / (1000.0 * elapsed / args.steps)}
         elif args.workload == "fsrcnn":
             ach = flops_per_frame * fps / world / 1e12

@@ -174,6 +174,11 @@ int ss4k_op_f32nchw_to_u8nhwc(ss4k_ctx* ctx, const float* in_dev, uint8_t* out_d
 int ss4k_prof_enable(ss4k_ctx* ctx, int enable);
 int ss4k_prof_reset(ss4k_ctx* ctx);
 int ss4k_prof_read(ss4k_ctx* ctx, int64_t* launches, double* total_ms, double* flops);
+/* Conv sections: wall time, on the caller's stream, from the first conv launch of every network forward to the end
+ * of its last one (launch boundaries included).  A job's frames may go through the conv layers as two CONCURRENT launch
+ * chains (frame lanes): the per-launch times of ss4k_prof_read then overlap, and sum(FLOPs) / section time is the rate
+ * the chip sustained; total_ms / section_ms = average number of conv launches in flight. */
+int ss4k_prof_read_section_ms(ss4k_ctx* ctx, double* section_ms);
 
 #ifdef __cplusplus
 }

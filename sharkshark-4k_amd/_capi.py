@@ -27,7 +27,7 @@ SYMBOLS = [
     "ss4k_upscaler_reset", "ss4k_upscaler_out_shape", "ss4k_upscaler_last_enqueue_ms", "ss4k_model_workspace_bytes", "ss4k_upscale_frames", "ss4k_upscaler_enable_taps",
     "ss4k_upscaler_read_tap", "ss4k_op_u8nhwc_to_f32nchw", "ss4k_op_area_resize", "ss4k_op_bicubic_resize",
     "ss4k_op_bilinear_resize", "ss4k_op_depthwise_reflect", "ss4k_op_plane_stats", "ss4k_op_f32nchw_to_u8nhwc",
-    "ss4k_prof_enable", "ss4k_prof_reset", "ss4k_prof_read",
+    "ss4k_prof_enable", "ss4k_prof_reset", "ss4k_prof_read", "ss4k_prof_read_section_ms",
 ]
 DEV_SYMBOLS = ["ss4k_bench_conv"]  # include/ss4k_dev.h: libss4k_hip_dev.so only (SS4K_LIB=.../libss4k_hip_dev.so)
 
@@ -92,6 +92,7 @@ def lib() -> C.CDLL:
     L.ss4k_prof_enable.argtypes = [vp, i]
     L.ss4k_prof_reset.argtypes = [vp]
     L.ss4k_prof_read.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ss4k_prof_read_section_ms.argtypes = [vp, C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -142,6 +143,12 @@ class Context:
         n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
         _check(lib().ss4k_prof_read(self._h, C.byref(n), C.byref(ms), C.byref(fl)))
         return n.value, ms.value, fl.value
+
+    def prof_read_section_ms(self) -> float:
+        """Wall time of the profiled forwards' conv sections (first conv launch to the end of the last, caller's stream)."""
+        ms = C.c_double()
+        _check(lib().ss4k_prof_read_section_ms(self._h, C.byref(ms)))
+        return ms.value
 
     def bench_conv(self, dtype, cin0, cin1, cout, n, h, w, flags=0, iters=20) -> float:
         if not hasattr(lib(), "ss4k_bench_conv"):

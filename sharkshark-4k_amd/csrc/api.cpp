@@ -271,6 +271,10 @@ void ss4k_ctx_destroy(ss4k_ctx* c) {
   for (auto& kv : c->scratch) kv.second.release();
   for (auto& e : c->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : c->prof_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (auto& e : c->prof_sections) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (c->lane_stream_) (void)hipStreamDestroy(c->lane_stream_);
+  if (c->fork_event) (void)hipEventDestroy(c->fork_event);
+  if (c->done_event) (void)hipEventDestroy(c->done_event);
   delete c;
 }
 int ss4k_ctx_device(const ss4k_ctx* c) { return c ? c->device : -1; }
@@ -426,10 +430,17 @@ static void prof_collect(ss4k_ctx* c) {
     c->prof_pool.push_back(e);
   }
   c->prof_events.clear();
+  for (auto& e : c->prof_sections) {
+    SS4K_HIP(hipEventSynchronize(e.b));
+    float ms = 0; SS4K_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+    c->prof_section_ms += ms;
+    c->prof_pool.push_back(e);
+  }
+  c->prof_sections.clear();
 }
 int ss4k_prof_enable(ss4k_ctx* c, int en) { if (!c) return SS4K_EINVAL; c->prof = en != 0; return SS4K_OK; }
 int ss4k_prof_reset(ss4k_ctx* c) {
-  return guard([&] { SS4K_REQUIRE(c, "NULL ctx"); prof_collect(c); c->prof_ms = 0; c->prof_flops = 0; c->prof_launches = 0; });
+  return guard([&] { SS4K_REQUIRE(c, "NULL ctx"); prof_collect(c); c->prof_ms = 0; c->prof_section_ms = 0; c->prof_flops = 0; c->prof_launches = 0; });
 }
 int ss4k_prof_read(ss4k_ctx* c, int64_t* launches, double* ms, double* flops) {
   return guard([&] {
@@ -438,6 +449,13 @@ int ss4k_prof_read(ss4k_ctx* c, int64_t* launches, double* ms, double* flops) {
     if (launches) *launches = c->prof_launches;
     if (ms) *ms = c->prof_ms;
     if (flops) *flops = c->prof_flops;
+  });
+}
+int ss4k_prof_read_section_ms(ss4k_ctx* c, double* section_ms) {
+  return guard([&] {
+    SS4K_REQUIRE(c && section_ms, "NULL argument");
+    prof_collect(c);
+    *section_ms = c->prof_section_ms;
   });
 }
 

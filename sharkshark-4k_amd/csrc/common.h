@@ -65,6 +65,30 @@ struct ss4k_ctx {
   int64_t prof_launches = 0;
   std::set<const void*> lds_attr_set;  // kernels whose dynamic-LDS limit was raised on this device
   double prof_ms = 0, prof_flops = 0;
+  // frame lanes (models.h): the second launch chain's stream and the fork / join events, shared by every model of the
+  // context (models run one after the other on the caller's stream); created on first use
+  hipStream_t lane_stream_ = nullptr;
+  hipEvent_t fork_event = nullptr, done_event = nullptr;
+  hipStream_t lane_stream() {
+    if (!lane_stream_ && hipStreamCreateWithFlags(&lane_stream_, hipStreamNonBlocking) != hipSuccess)
+      throw ss4k::Error(SS4K_EHIP, "hipStreamCreateWithFlags failed");
+    return lane_stream_;
+  }
+  static hipEvent_t untimed_event(hipEvent_t& e) {
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) throw ss4k::Error(SS4K_EHIP, "hipEventCreateWithFlags failed");
+    return e;
+  }
+  hipEvent_t lane_fork() { return untimed_event(fork_event); }
+  hipEvent_t lane_done() { return untimed_event(done_event); }
+  // conv sections (bench): wall time on the caller's stream from a forward's first conv launch to the end of its last
+  std::vector<ss4k::ProfEvent> prof_sections;
+  double prof_section_ms = 0;
+  ss4k::ProfEvent prof_get_events() {
+    ss4k::ProfEvent pe{};
+    if (!prof_pool.empty()) { pe = prof_pool.back(); prof_pool.pop_back(); pe.flops = 0; return pe; }
+    if (hipEventCreate(&pe.a) != hipSuccess || hipEventCreate(&pe.b) != hipSuccess) throw ss4k::Error(SS4K_EHIP, "hipEventCreate failed");
+    return pe;
+  }
   const char* zero_page() {
     auto& b = scratch["zero_page"];
     if (!b.ptr) { b.ensure(256); (void)hipMemset(b.ptr, 0, 256); }
@@ -93,6 +117,9 @@ struct ConvArgs {
   const char* in1; size_t in1_plane_bytes; int in1_plane0, nchunks1;  // optional segment 1 (dense concat is free)
   const char* zero_page;                // >= 64 zero bytes: DMA source for the zero padding
   int N, H, W;                          // conv grid (== output grid before SUB2/PS2)
+  int n0;                               // first frame of this launch inside the tensors (frame lanes: a job's frames split
+                                        // over concurrent launches); N counts this launch's frames
+  float grid_share;                     // size the persistent grid for this share of the chip's workgroup slots (0 = all)
   int ups2;                             // input is the nearest-x2 upsampling of an (H/2, W/2) tensor
   const void* wpk;                      // packed weights [group][chunk][dx,ks][dy][nb][lane][E]
   const void* wrs;                      // conv_rs.hip layout [group][cout group][chunk32][tap][cb][lane][8] or null

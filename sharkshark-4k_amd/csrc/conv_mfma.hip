@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
   auto setup_tile = [&](int tile, int& n, int& y0, int& x0) {
     const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
     const int ty = tyn % a.tiles_y;
-    n = tyn / a.tiles_y; y0 = ty * TH; x0 = tx * TW;
+    n = a.n0 + tyn / a.tiles_y; y0 = ty * TH; x0 = tx * TW;
 #pragma unroll
     for (int j = 0; j < DMA_PER_WAVE; ++j) {
       const int iy = y0 - 1 + (plan[j] & 0xff), ix = x0 - 1 + ((plan[j] >> 8) & 0xff);
@@ -812,7 +812,7 @@ static void launch_t(ss4k_ctx* ctx, const ConvArgs& a0, int groups, hipStream_t 
   const void* fn = reinterpret_cast<const void*>(&conv3x3_kernel<T, NB, MB, NW, DBG, EK>);
   if (ctx->lds_attr_set.insert(fn).second)  // per context = per device
     SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int gx = std::min(ntiles, std::max(1, ctx->num_cu * per_cu / groups));
+  int gx = std::min(ntiles, std::max(1, (int)(ctx->num_cu * per_cu / groups * (a.grid_share > 0.f ? a.grid_share : 1.f))));
   hipLaunchKernelGGL((conv3x3_kernel<T, NB, MB, NW, DBG, EK>), dim3(gx, groups), dim3(64 * NW), lds, st, a);
   SS4K_HIP(hipGetLastError());
 }

@@ -61,7 +61,7 @@ struct RsArgs {
   char* out; size_t out_plane_bytes;
   const char* res1; size_t r1_plane_bytes;
   const char* res2; size_t r2_plane_bytes;
-  int N, H, W, ups2, tiles_x, tiles_y, reverse;
+  int N, n0, H, W, ups2, tiles_x, tiles_y, reverse;   // n0: first frame of this launch (frame lanes)
   float slope, alpha, gamma;       // slope: LeakyReLU slope, 1 = no activation (PReLU: per channel, `prelu`)
 };
 
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64 * (TH / ROWS) * CG, (TH / ROWS) * CG / 4) void c
   auto setup_tile = [&](int tile, int& n, int& y0, int& x0) __attribute__((always_inline)) {
     const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
     const int ty = tyn % a.tiles_y;
-    n = tyn / a.tiles_y; y0 = ty * TH; x0 = tx * TW;
+    n = a.n0 + tyn / a.tiles_y; y0 = ty * TH; x0 = tx * TW;
   };
 
   // ---- this wave's weight slice -> registers (A fragments: lane (m, kq) holds cout row m, k = 8kq..8kq+7)
@@ -510,7 +510,7 @@ static void launch_t(ss4k_ctx* ctx, const ConvArgs& c, hipStream_t st) {
   a.out = c.out + (size_t)c.out_plane0 * c.out_plane_bytes; a.out_plane_bytes = c.out_plane_bytes;
   a.res1 = c.res1 ? c.res1 + (size_t)c.r1_plane0 * c.r1_plane_bytes : nullptr; a.r1_plane_bytes = c.r1_plane_bytes;
   a.res2 = c.res2 ? c.res2 + (size_t)c.r2_plane0 * c.r2_plane_bytes : nullptr; a.r2_plane_bytes = c.r2_plane_bytes;
-  a.N = c.N; a.H = c.H; a.W = c.W; a.ups2 = c.ups2; a.reverse = c.reverse;
+  a.N = c.N; a.n0 = c.n0; a.H = c.H; a.W = c.W; a.ups2 = c.ups2; a.reverse = c.reverse;
   a.tiles_x = (c.W + TW - 1) / TW;
   a.tiles_y = (c.H + TH - 1) / TH;
   a.slope = c.act == ACT_LRELU ? c.slope : 1.f; a.alpha = c.alpha; a.gamma = c.gamma;
@@ -519,7 +519,7 @@ static void launch_t(ss4k_ctx* ctx, const ConvArgs& c, hipStream_t st) {
   const void* fn = reinterpret_cast<const void*>(&conv3x3_rs_kernel<NCH, ROWS, CB, CG, PR, RL, RES>);
   if (ctx->lds_attr_set.insert(fn).second)
     SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int gx = std::min(ntiles, std::max(1, ctx->num_cu / groups));
+  int gx = std::min(ntiles, std::max(1, (int)(ctx->num_cu / groups * (c.grid_share > 0.f ? c.grid_share : 1.f))));
   hipLaunchKernelGGL((conv3x3_rs_kernel<NCH, ROWS, CB, CG, PR, RL, RES>), dim3(gx, groups), dim3(64 * NW), lds, st, a);
   SS4K_HIP(hipGetLastError());
 }

@@ -175,6 +175,9 @@ void Model::build(const float* w, size_t n) {
   if (const char* e = std::getenv("SS4K_NO_RS")) use_rs = !(e[0] == '1');        // A/B switch: LDS-weights kernel for every layer
   if (const char* e = std::getenv("SS4K_RS_MASK")) rs_mask = std::atoi(e);       // A/B switch: which layer shapes take conv_rs.hip
   if (const char* e = std::getenv("SS4K_RS_W8")) rs_wide = e[0] == '1';          // A/B switch: eight-wave variants of the 32-cout shapes
+  // frame lanes (models.h): 0 / unset = choose per shape from two timed calls of each mode, 1 = off, 2 = always on
+  if (const char* e = std::getenv("SS4K_LANES")) lanes_mode = std::max(0, std::min(2, std::atoi(e)));
+  if (const char* e = std::getenv("SS4K_LANE_GRID")) lane_grid_share = (float)std::atof(e);   // A/B switch: grid of a lane's launch as a share of the chip's slots
   SS4K_REQUIRE(n == model_param_count(desc), "weight blob size does not match the model description");
   ParamCursor pc{w, n};
   if (desc.kind == SS4K_FSRCNN) {
@@ -263,8 +266,81 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
   a.cout_real = L.cout_real; a.cout_pad = L.cout_pad;
   a.dbg = dbg; a.dbg_buf = dbg_buf;
   a.reverse = (flip_walk && (launch_parity ^= 1)) ? 1 : 0;
-  a.flops = 2.0 * 9.0 * L.cin_real * L.cout_real * (double)N * H * W * (o.epi == EPI_NHWC_SUB2 ? 0.25 : 1.0);
-  launch_conv3x3(ctx, a, desc.dtype, st);
+  const double flops = 2.0 * 9.0 * L.cin_real * L.cout_real * (double)H * W * (o.epi == EPI_NHWC_SUB2 ? 0.25 : 1.0);
+  if (ctx->prof && !section_open) {   // conv section of this forward: first conv launch ... end of the last one, on the caller's stream
+    section = ctx->prof_get_events();
+    SS4K_HIP(hipEventRecord(section.a, st));
+    section_open = true;
+  }
+  if (cur_lanes <= 1 || N != cur_n) {
+    a.flops = flops * N;
+    launch_conv3x3(ctx, a, desc.dtype, st);
+    return;
+  }
+  // frame lanes: lane l takes frames [N*l/2, N*(l+1)/2): lane 0 on the caller's stream, lane 1 on the context's lane stream
+  if (!forked) {
+    SS4K_HIP(hipEventRecord(ctx->lane_fork(), st));
+    SS4K_HIP(hipStreamWaitEvent(ctx->lane_stream(), ctx->lane_fork(), 0));
+    forked = true;
+  }
+  for (int l = 0; l < 2; ++l) {
+    a.n0 = N * l / 2; a.N = N * (l + 1) / 2 - a.n0;
+    a.grid_share = lane_grid_share;
+    a.flops = flops * a.N;
+    launch_conv3x3(ctx, a, desc.dtype, l == 0 ? st : ctx->lane_stream());
+  }
+}
+
+// Called at the top of a conv network's forward: one launch chain or two?  Both give bit-identical tensors.
+// Two chains win when a launch is short next to its fixed costs (launch boundary, prologue, the partly filled last round
+// of tiles): up to 4 frames of 720p per job here; they lose nothing-to-1 % on bigger jobs, and they rely on the two HIP
+// streams being served concurrently by the hardware queues.  So, unless forced by SS4K_LANES, the choice is MEASURED per
+// (n, h, w): calls 0-1 run two chains, calls 2-3 one, the second call of each pair is timed with events on the
+// caller's stream (no host synchronisation: the events are polled on later calls), and the faster mode is kept.
+void Model::lanes_begin(int n, int h, int w, hipStream_t st) {
+  cur_lanes = 1; cur_n = n; forked = false; tune_timed = nullptr;
+  if (plan_only || lanes_mode == 1 || n % 2 != 0 || desc.dtype != SS4K_F16 || dbg) return;
+  if (lanes_mode == 2) { cur_lanes = 2; return; }
+  LaneTune* t = nullptr;
+  for (auto& e : lane_tune) if (e.n == n && e.h == h && e.w == w) t = &e;
+  if (!t) { lane_tune.push_back(LaneTune{}); t = &lane_tune.back(); t->n = n; t->h = h; t->w = w; }
+  if (t->decided) { cur_lanes = t->decided; return; }
+  const int k = t->calls++;
+  if (k < 4) {
+    cur_lanes = k < 2 ? 2 : 1;
+    if (k & 1) {   // second call of the pair: timed
+      auto& ev = t->ev[k >> 1];
+      SS4K_HIP(hipEventCreate(&ev[0])); SS4K_HIP(hipEventCreate(&ev[1]));
+      SS4K_HIP(hipEventRecord(ev[0], st));
+      tune_timed = ev[1];
+    }
+    return;
+  }
+  cur_lanes = 2;
+  if (hipEventQuery(t->ev[0][1]) == hipSuccess && hipEventQuery(t->ev[1][1]) == hipSuccess) {
+    float ms2 = 0, ms1 = 0;
+    SS4K_HIP(hipEventElapsedTime(&ms2, t->ev[0][0], t->ev[0][1]));
+    SS4K_HIP(hipEventElapsedTime(&ms1, t->ev[1][0], t->ev[1][1]));
+    t->decided = ms2 < 0.99f * ms1 ? 2 : 1;
+    t->ms[0] = ms2; t->ms[1] = ms1;
+    for (auto& pr : t->ev) for (auto& e : pr) { (void)hipEventDestroy(e); e = nullptr; }
+    cur_lanes = t->decided;
+  }
+}
+
+// the caller's stream continues only after both chains: called before any non-conv work on the tensors and at the end
+void Model::lanes_join(hipStream_t st, bool end_of_forward) {
+  if (forked) {
+    SS4K_HIP(hipEventRecord(ctx->lane_done(), ctx->lane_stream()));
+    SS4K_HIP(hipStreamWaitEvent(st, ctx->lane_done(), 0));
+    forked = false;
+  }
+  if (section_open) {
+    SS4K_HIP(hipEventRecord(section.b, st));
+    ctx->prof_sections.push_back(section);
+    section_open = false;
+  }
+  if (end_of_forward && tune_timed) { SS4K_HIP(hipEventRecord(tune_timed, st)); tune_timed = nullptr; }
 }
 
 size_t Model::workspace_bytes(int n, int h, int w) {
@@ -344,6 +420,7 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
     fsrcnn_forward(ctx, fsw, desc.scale, in, out, n, h, w, acts[0].as<float>(), acts[1].as<float>(), st);
     return;
   }
+  lanes_begin(n, h, w, st);
   // plane index of channel c inside a tensor
   auto plane_of = [&](const Tens& t, int channel) { return Tens{t.p, t.plane_bytes, t.plane0 + channel / cw()}; };
   auto nchw_out = [&]() { return Tens{reinterpret_cast<char*>(out), 0, 0}; };
@@ -384,6 +461,7 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
     { ConvOpts o; o.ups2 = 1; o.act = ACT_LRELU; o.slope = 0.2f; o.out = U2; conv(li++, U1, nullptr, n, 4 * H, 4 * W, o, st); }
     { ConvOpts o; o.act = ACT_LRELU; o.slope = 0.2f; o.out = U3; conv(li++, U2, nullptr, n, 4 * H, 4 * W, o, st); }
     { ConvOpts o; o.epi = EPI_NCHW_F32; o.out = nchw_out(); conv(li++, U3, nullptr, n, 4 * H, 4 * W, o, st); }
+    lanes_join(st, true);
     return;
   }
   if (desc.kind == SS4K_SRVGG) {
@@ -400,6 +478,7 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
     }
     Tens Z = act(3, px, layers[li].cout_pad);
     { ConvOpts o; o.out = Z; conv(li++, cur, nullptr, n, h, w, o, st); }
+    lanes_join(st, true);
     if (plan_only) return;
     // the service may ask for the output's plane statistics to be accumulated while it is written
     double* sacc = out_stats_acc; out_stats_acc = nullptr; out_stats_done = sacc != nullptr;
@@ -429,6 +508,7 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
     auto bibuf = [&](const Tens& t, int c, int N, int H, int W, const Tens& outT) {
       if (!desc.bsvd_stream) { conv(li++, masked(t, c), nullptr, N, H, W, relu6(outT), st); return; }
       const int lead = shifted_planes(c);
+      lanes_join(st, false);   // the time shift reads neighbouring frames
       Tens S = act(14, (size_t)N * H * W, lead * cw());
       if (!plan_only) op_temporal_shift(t.p + (size_t)t.plane0 * t.plane_bytes, S.p, lead, N, (size_t)H * W, rec() / 16, cw(), c / 8, st);
       const Tens rest{t.p, t.plane_bytes, t.plane0 + lead};
@@ -453,6 +533,7 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
       if (blk == 0) { o.out = MID; } else { o.epi = EPI_NCHW_F32; o.out = nchw_out(); }
       conv(li++, O0, nullptr, n, h, w, o, st); }                                       // outc.convblock.3 + residual
   }
+  lanes_join(st, true);
 }
 
 

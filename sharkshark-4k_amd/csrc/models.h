@@ -48,6 +48,21 @@ struct Model {
   // while the output is written (networks whose tail can do it set out_stats_done; the batch must not be split)
   double* out_stats_acc = nullptr;
   bool out_stats_done = false;
+  // frame lanes: the frames of a job are independent, so an even batch can go through the conv layers as TWO concurrent
+  // launch chains - lane 0 on the caller's stream, lane 1 on the context's lane stream, each working on its own half of
+  // the frames of the same tensors, every launch still sized for the whole chip.  The hardware dispatcher then fills any
+  // CU one chain leaves free (launch boundary, prologue, the partly filled last round of tiles) with waiting workgroups
+  // of the other chain.  Frames are bit-identical to the single-chain path.
+  int lanes_mode = 0;          // 0: measured per shape (lanes_begin), 1: one chain, 2: two chains
+  float lane_grid_share = 1.f; // grid of a lane's launch as a share of the chip's workgroup slots (measured: 1.0 is best)
+  int cur_lanes = 1, cur_n = 0;
+  bool forked = false;
+  struct LaneTune { int n, h, w, calls = 0, decided = 0; hipEvent_t ev[2][2] = {}; float ms[2] = {}; };
+  std::vector<LaneTune> lane_tune;
+  hipEvent_t tune_timed = nullptr;
+  ProfEvent section{}; bool section_open = false;   // bench: wall time of a forward's conv launches
+  void lanes_begin(int n, int h, int w, hipStream_t st);
+  void lanes_join(hipStream_t st, bool end_of_forward);
   int dbg = 0;  // ablation build selector forwarded to the conv kernel (bench only)
   unsigned long long* dbg_buf = nullptr;
 
@@ -62,6 +77,7 @@ struct Model {
     for (auto& l : layers) { l.w.release(); l.bias.release(); l.prelu.release(); l.wrs.release(); }
     for (auto& a : acts) a.release();
     fs_blob.release();
+    for (auto& t : lane_tune) for (auto& pr : t.ev) for (auto e : pr) if (e) (void)hipEventDestroy(e);
   }
 
   int add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec spec, bool has_prelu_after, bool allow_rs = false);

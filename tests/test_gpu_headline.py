@@ -198,3 +198,40 @@ def test_rrdbnet_fp16_full_gain_weights(ctx):
     p = psnr(y16, want, peak=peak)
     print(f"fp16 vs oracle with gain-1.0 RDB weights: output peak {peak:.3g}, PSNR {p:.1f} dB")
     assert p > 40.0, f"PSNR {p:.1f} dB at output peak {peak:.3g}"
+
+
+# ------------------------------------------------------------------------------ frame lanes (two concurrent launch chains)
+@pytest.mark.parametrize("kind", ["rrdbnet", "bsvd", "srvgg"])
+def test_frame_lanes_bit_identical(ctx, monkeypatch, kind):
+    """An even fp16 batch may go through the conv layers as two concurrent launch chains (csrc/models.h, frame lanes).
+    One chain (SS4K_LANES=1), two chains (=2) and the measured choice (unset: calls 0-1 two chains, 2-3 one, then the
+    faster) must give bit-identical tensors, call after call, for every conv network."""
+    def build():
+        if kind == "rrdbnet":
+            t = W.rrdbnet_table(5, scale=2, num_block=2)
+            return _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=2), W.flatten(t, W.rrdbnet_keys(2)))
+        if kind == "bsvd":
+            return _capi.Model(ctx, _capi.make_desc(_capi.BSVD, _capi.F16, scale=1), W.flatten(W.bsvd_table(3), W.bsvd_keys()))
+        t = W.srvgg_table(2, num_feat=64, num_conv=4)
+        return _capi.Model(ctx, _capi.make_desc(_capi.SRVGG, _capi.F16, scale=4, num_feat=64, num_block=4), W.flatten(t, W.srvgg_keys(4)))
+    cin = 4 if kind == "bsvd" else 3
+    x = torch.rand(4, cin, 72, 104, generator=torch.Generator().manual_seed(11)).cuda()
+    outs = {}
+    for mode in ("1", "2", None):
+        if mode is None:
+            monkeypatch.delenv("SS4K_LANES", raising=False)
+        else:
+            monkeypatch.setenv("SS4K_LANES", mode)
+        m = build()
+        ys = [m(x).clone() for _ in range(7)]   # the measured choice switches modes over its first calls
+        torch.cuda.synchronize()
+        for y in ys[1:]:
+            assert torch.equal(ys[0], y), f"{kind}: lanes mode {mode}: output changed between calls"
+        outs[mode] = ys[0]
+    assert torch.isfinite(outs["1"]).all()
+    assert torch.equal(outs["1"], outs["2"]), f"{kind}: two launch chains changed the result"
+    assert torch.equal(outs["1"], outs[None]), f"{kind}: measured lane choice changed the result"
+    # an odd batch always takes one chain and equals the even batch's first frames
+    monkeypatch.setenv("SS4K_LANES", "2")
+    m = build()
+    assert torch.equal(m(x[:3]), outs["1"][:3])
