@@ -9,6 +9,7 @@
 //   tail  = conv1x1(12->56)+PReLU -> ConvTranspose 9x9 stride s   (fused, exact-fp32 MFMA: k_fs_tail)
 #include "common.h"
 #include "glue.h"
+#include <cstdlib>
 
 namespace ss4k {
 
@@ -262,6 +263,215 @@ __global__ __launch_bounds__(256) void k_fs_tail(const float* __restrict__ in12,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Production tail: the same two products on the fp16 matrix rate, and the overlap-add in REGISTERS.
+//
+// Arithmetic.  Every fp32 operand is split x = hi + 2^-11 * lo with hi and lo BOTH fp16 (hi = x with its low 13
+// mantissa bits cleared, lo = (x - hi) * 2048: exact in fp32 and at hi's magnitude, so no fp16 subnormals), and a
+// product is three v_mfma_f32_32x32x16_f16: hi*hi into one fp32 accumulator, hi*lo + lo*hi into a second one that is
+// scaled by 2^-11 at the end; the dropped lo*lo term is 2^-22 of |x||w|.  22 significand bits per operand and fp32
+// accumulation: the result agrees with the exact-fp32 kernel above to ~5e-7 of the output peak (tools/fs_time.py,
+// test_fsrcnn_split_tail_vs_exact), far inside the path's 1e-3 / 1e-4 tolerance, at 36 + 6 MFMAs of 32 cycles per 32
+// pixels instead of 84 + 12 of 64.  Operands must stay inside the fp16 range (|x| < 65504; image-range networks are
+// orders of magnitude below).
+//
+// Overlap-add.  With the matrix time gone the ring version is bound by its LDS read-add-write rounds, two barriers and
+// the hand-over pass per row (~1200 vector / LDS instructions per wave and row).  Here a wave owns 32 LR columns of
+// which 32 - 2*HALO are interior, and nothing is shared between waves after the operand tables are built:
+//   * along x, output column S*x' + r of kernel row ky is  sum_d T[ky][S*d + r + 4] of pixel x' - d : lane x' collects
+//     from lanes x' -+ 1, 2 with DPP wave shifts folded into the adds (v_add_f32_dpp wave_shl / wave_shr: 7 adds per
+//     kernel row at S = 2, 5 at S = 4);
+//   * along y, a lane keeps the five output rows it is still adding to (rows S*y - 4 + 2j + hh: lane half hh owns the
+//     rows of its kernel-row parity) in 5 x S registers; S/2 of them are complete after each LR row and leave for HBM
+//     straight from the registers (one 8 / 16-byte store per lane and row).
+// Deterministic by construction (no atomics, fixed order).
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2v __attribute__((ext_vector_type(2)));
+struct HiLo { f16x8v hi, lo; };
+// two fp32 values -> packed fp16 hi pair and packed fp16 lo pair
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  const float h0 = __uint_as_float(__float_as_uint(x0) & 0xFFFFE000u), h1 = __uint_as_float(__float_as_uint(x1) & 0xFFFFE000u);
+  const fp16x2v ph = __builtin_amdgcn_cvt_pkrtz(h0, h1);                              // exact: 11 significand bits
+  const fp16x2v pl = __builtin_amdgcn_cvt_pkrtz((x0 - h0) * 2048.f, (x1 - h1) * 2048.f);
+  hi = __builtin_bit_cast(uint32_t, ph); lo = __builtin_bit_cast(uint32_t, pl);
+}
+__device__ __forceinline__ float dpp_shl1(float v) {   // lane i <- lane i + 1 (0 past the wave)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_shr1(float v) {   // lane i <- lane i - 1
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+
+template <int S> struct FsTailGeo { static constexpr int HALO = S == 2 ? 2 : 1, CI = 32 - 2 * HALO; };
+
+template <int S>
+__global__ __launch_bounds__(256) void k_fs_tail_r(const float* __restrict__ in12, float* __restrict__ out,
+                                                   const float* __restrict__ we, const float* __restrict__ be,
+                                                   const float* __restrict__ ae, const float* __restrict__ wd, float bias,
+                                                   int planes, int h, int w, int bands) {
+  constexpr int HALO = FsTailGeo<S>::HALO, CI = FsTailGeo<S>::CI, JSTEP = S / 2;
+  extern __shared__ __attribute__((aligned(16))) float fs_lds[];
+  // A operands, fragment order: [tap block 3][k-step 4][lane 64] x 8 fp16, hi then lo tables; expand [2][64] x 8
+  uint4* wd_hi = reinterpret_cast<uint4*>(fs_lds);   // 768 fragments of 16 B
+  uint4* wd_lo = wd_hi + 768;
+  uint4* we_hi = wd_lo + 768;                        // 128
+  uint4* we_lo = we_hi + 128;
+  float* bea = reinterpret_cast<float*>(we_lo + 128);  // [64] bias, [64] PReLU slope of the (padded) expand channels
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, hh = lane >> 5;
+  const int wstrips = (w + CI - 1) / CI, strips = (wstrips + 3) / 4;
+  const int strip = blockIdx.x % strips, band = (blockIdx.x / strips) % bands, plane = blockIdx.x / (strips * bands);
+  const int rpb = (h + bands - 1) / bands, ylo = band * rpb, yhi = min(h, ylo + rpb);
+  if (plane >= planes || ylo >= yhi) return;
+
+  // Tap slot r of block tb sits in half hs = (r>>2)&1 of the accumulator; half 0 carries the 45 taps with even ky,
+  // half 1 the 36 with odd ky, each in (ky, kx) order (as k_fs_tail).  k = 8*kq + j of k-step s is channel
+  // 32*(s>>1) + (i&3) + 8*(i>>2) + 4*kq with i = 8*(s&1) + j: the channel that accumulator register i of block s>>1
+  // holds in lane half kq, so the first product's accumulators are the second one's B operand as they stand.
+  for (int e = tid; e < 768; e += 256) {
+    const int tb = e >> 8, s4 = (e >> 6) & 3, l = e & 63;
+    const int r = l & 31, kq = l >> 5, hs = (r >> 2) & 1, is = (r & 3) + 4 * (r >> 3), ord = tb * 16 + is;
+    const int ky = 2 * (ord / 9) + hs, kx = ord % 9;
+    uint32_t vh[4], vl[4];
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      float v[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int i = 8 * (s4 & 1) + j + t, c = 32 * (s4 >> 1) + (i & 3) + 8 * (i >> 2) + 4 * kq;
+        v[t] = (ord < (hs ? 36 : 45) && c < 56) ? wd[(ky * 9 + kx) * 56 + c] : 0.f;
+      }
+      split2(v[0], v[1], vh[j >> 1], vl[j >> 1]);
+    }
+    wd_hi[e] = make_uint4(vh[0], vh[1], vh[2], vh[3]); wd_lo[e] = make_uint4(vl[0], vl[1], vl[2], vl[3]);
+  }
+  if (tid < 128) {
+    const int b = tid >> 6, l = tid & 63, ch = 32 * b + (l & 31), kq = l >> 5;
+    uint32_t vh[4], vl[4];
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      float v[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { const int kin = 8 * kq + j + t; v[t] = (ch < 56 && kin < 12) ? we[kin * 56 + ch] : 0.f; }
+      split2(v[0], v[1], vh[j >> 1], vl[j >> 1]);
+    }
+    we_hi[tid] = make_uint4(vh[0], vh[1], vh[2], vh[3]); we_lo[tid] = make_uint4(vl[0], vl[1], vl[2], vl[3]);
+  }
+  if (tid < 64) { bea[tid] = tid < 56 ? be[tid] : 0.f; bea[64 + tid] = tid < 56 ? ae[tid] : 1.f; }
+  __syncthreads();
+  const int ws = strip * 4 + wave;   // this wave's strip of CI interior columns; nothing below synchronises
+  if (ws >= wstrips) return;
+
+  const size_t plane_px = (size_t)h * w, total = (size_t)planes * plane_px;
+  const int OW = S * w, OH = S * h;
+  float* oplane = out + (size_t)plane * OH * OW;
+  const int px = ws * CI - HALO + p;
+  const bool col_ok = px >= 0 && px < w;
+  const bool interior = p >= HALO && p < 32 - HALO && px < w;
+  // this lane's 8 input channels of its pixel (half 0: channels 0-7, half 1: 8-11 + zeros), fetched one row ahead
+  auto load_x = [&](int yy, float4& a0, float4& a1) {
+    a0 = a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (yy >= 0 && yy < h && col_ok) {
+      const float4* src = reinterpret_cast<const float4*>(in12) + (size_t)plane * plane_px + (size_t)yy * w + px;
+      if (hh == 0) { a0 = src[0]; a1 = src[total]; } else a0 = src[2 * total];
+    }
+  };
+  typedef float fvS __attribute__((ext_vector_type(S)));
+  fvS V[5];   // output rows S*y - 4 + 2j + hh under construction, this lane's S columns of each
+#pragma unroll
+  for (int j = 0; j < 5; ++j) V[j] = fvS(0.f);
+  float4 n0, n1;
+  load_x(ylo - 2, n0, n1);
+  constexpr float LO = 1.f / 2048.f;
+  const f32x16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int y = ylo - 2; y < yhi + 2; ++y) {
+    const bool row_ok = y >= 0 && y < h;  // wave-uniform
+    const float4 g0 = n0, g1 = n1;
+    load_x(y + 1, n0, n1);
+    if (row_ok) {
+      uint4 xh, xl;
+      split2(g0.x, g0.y, xh.x, xl.x); split2(g0.z, g0.w, xh.y, xl.y); split2(g1.x, g1.y, xh.z, xl.z); split2(g1.z, g1.w, xh.w, xl.w);
+      const f16x8v bxh = __builtin_bit_cast(f16x8v, xh), bxl = __builtin_bit_cast(f16x8v, xl);
+      // E' = PReLU(We * X + be), split again: B operands of the four k-steps of the second product
+      uint4 ebh[4], ebl[4];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        f32x16v E1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 bv = *reinterpret_cast<const float4*>(&bea[32 * b + 8 * k + 4 * hh]);
+          E1[4 * k] = bv.x; E1[4 * k + 1] = bv.y; E1[4 * k + 2] = bv.z; E1[4 * k + 3] = bv.w;
+        }
+        const f16x8v ah = __builtin_bit_cast(f16x8v, we_hi[b * 64 + lane]), al = __builtin_bit_cast(f16x8v, we_lo[b * 64 + lane]);
+        E1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bxh, E1, 0, 0, 0);
+        f32x16v E2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bxl, zero16, 0, 0, 0);
+        E2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bxh, E2, 0, 0, 0);
+        float ev[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 sl = *reinterpret_cast<const float4*>(&bea[64 + 32 * b + 8 * k + 4 * hh]);
+          const float sv[4] = {sl.x, sl.y, sl.z, sl.w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float v = fmaf(E2[4 * k + t], LO, E1[4 * k + t]);
+            ev[4 * k + t] = col_ok ? prelu(v, sv[t]) : 0.f;   // a column outside the image contributes nothing
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          uint32_t hq[4], lq[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) split2(ev[8 * q + 2 * t], ev[8 * q + 2 * t + 1], hq[t], lq[t]);
+          ebh[2 * b + q] = make_uint4(hq[0], hq[1], hq[2], hq[3]); ebl[2 * b + q] = make_uint4(lq[0], lq[1], lq[2], lq[3]);
+        }
+      }
+      f32x16v T[3];
+#pragma unroll
+      for (int tb = 0; tb < 3; ++tb) {
+        f32x16v T1 = zero16, T2 = zero16;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const f16x8v ah = __builtin_bit_cast(f16x8v, wd_hi[(tb * 4 + s4) * 64 + lane]), al = __builtin_bit_cast(f16x8v, wd_lo[(tb * 4 + s4) * 64 + lane]);
+          const f16x8v bh = __builtin_bit_cast(f16x8v, ebh[s4]), bl = __builtin_bit_cast(f16x8v, ebl[s4]);
+          T1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, T1, 0, 0, 0);
+          T2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, T2, 0, 0, 0);
+          T2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, T2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T[tb][i] = fmaf(T2[i], LO, T1[i]);
+      }
+      // horizontal overlap-add in registers, then into the rows under construction
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        float t[9];
+#pragma unroll
+        for (int kx = 0; kx < 9; ++kx) { const int ord = 9 * j + kx; t[kx] = T[ord >> 4][ord & 15]; }
+        if constexpr (S == 2) {
+          V[j][0] += dpp_shl1(dpp_shl1(t[0]) + t[2]) + t[4] + dpp_shr1(dpp_shr1(t[8]) + t[6]);
+          V[j][1] += dpp_shl1(dpp_shl1(t[1]) + t[3]) + t[5] + dpp_shr1(t[7]);
+        } else {
+          V[j][0] += dpp_shl1(t[0]) + t[4] + dpp_shr1(t[8]);
+          V[j][1] += dpp_shl1(t[1]) + t[5];
+          V[j][2] += dpp_shl1(t[2]) + t[6];
+          V[j][3] += dpp_shl1(t[3]) + t[7];
+        }
+      }
+    }
+    // rows j < S/2 are complete: they leave from the registers, the others move up
+#pragma unroll
+    for (int j = 0; j < JSTEP; ++j) {
+      const int Y = S * y - 4 + 2 * j + hh;
+      if (interior && Y >= S * ylo && Y < S * yhi) {
+        fvS o = V[j];
+#pragma unroll
+        for (int e = 0; e < S; ++e) o[e] += bias;
+        *reinterpret_cast<fvS*>(&oplane[(size_t)Y * OW + (size_t)S * px]) = o;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) V[j] = j + JSTEP < 5 ? V[j + JSTEP] : fvS(0.f);
+  }
+}
+
 void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const float* in, float* out, int planes, int h,
                     int w, float* ws12a, float* ws12b, hipStream_t st) {
   const size_t total = (size_t)planes * h * w;
@@ -275,18 +485,21 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
     hipLaunchKernelGGL(k_fs_map<FS_MAP_R>, mgrid, block, 0, st, cur, nxt, W.w_map[l], W.b_map[l], W.a_map[l], planes, h, w);
     std::swap(cur, nxt);
   }
-  const int strips = (w + FS_CI - 1) / FS_CI;
+  // SS4K_FS_EXACT=1: the exact-fp32 MFMA tail with the LDS ring (A/B switch and the reference of the split-precision test)
+  static const bool exact = [] { const char* e = std::getenv("SS4K_FS_EXACT"); return e && e[0] == '1'; }();
+  SS4K_REQUIRE(factor == 2 || factor == 4, "FSRCNN: scale must be 2 or 4");
+  const int ci = exact ? FS_CI : 4 * (factor == 2 ? FsTailGeo<2>::CI : FsTailGeo<4>::CI);   // interior LR columns per workgroup
+  const int strips = (w + ci - 1) / ci;
   // one round of workgroups at three per CU; every band re-does 4 halo rows
   const int bands = std::max(1, std::min((h + 15) / 16, 3 * ctx->num_cu / std::max(1, planes * strips)));
   const dim3 tgrid((unsigned)(planes * bands * strips));
   auto launch_tail = [&](auto kern, int S) {
-    const size_t lds = (size_t)(6144 + 768 + 128 + 16 * (S * 128 + 8)) * 4;
+    const size_t lds = exact ? (size_t)(6144 + 768 + 128 + 16 * (S * 128 + 8)) * 4 : (size_t)(2 * 768 + 2 * 128) * 16 + 128 * 4;
     hipLaunchKernelGGL(kern, tgrid, block, lds, st, cur, out, W.w_expand, W.b_expand, W.a_expand, W.w_deconv, W.b_deconv,
                        planes, h, w, bands);
   };
-  if (factor == 2) launch_tail(k_fs_tail<2>, 2);
-  else if (factor == 4) launch_tail(k_fs_tail<4>, 4);
-  else throw Error(SS4K_EINVAL, "FSRCNN: scale must be 2 or 4");
+  if (factor == 2) { if (exact) launch_tail(k_fs_tail<2>, 2); else launch_tail(k_fs_tail_r<2>, 2); }
+  else { if (exact) launch_tail(k_fs_tail<4>, 4); else launch_tail(k_fs_tail_r<4>, 4); }
   SS4K_HIP(hipGetLastError());
 }
 

@@ -15,7 +15,9 @@ flat = W.flatten(W.rrdbnet_table(0, scale=2), W.rrdbnet_keys(23))
 ups = {}
 for v in variants:
     # variant syntax: <mode>[g<share>]: mode 0 = measured choice, 1 = one chain, 2 = two chains; g = grid share of a lane's launch
-    g = v.split("g")
+    m = v.split("m")
+    os.environ["SS4K_RS_MASK"] = m[1] if len(m) > 1 else "32"   # layer shapes on the register-stationary kernel (models.cpp rs_shape_bit)
+    g = m[0].split("g")
     os.environ["SS4K_LANES"] = g[0]
     os.environ["SS4K_LANE_GRID"] = g[1] if len(g) > 1 else "1.0"
     sr = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2), flat)
