@@ -305,7 +305,7 @@ __device__ __forceinline__ float dpp_shr1(float v) {   // lane i <- lane i - 1
 template <int S> struct FsTailGeo { static constexpr int HALO = S == 2 ? 2 : 1, CI = 32 - 2 * HALO; };
 
 template <int S>
-__global__ __launch_bounds__(256) void k_fs_tail_r(const float* __restrict__ in12, float* __restrict__ out,
+__global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ in12, float* __restrict__ out,
                                                    const float* __restrict__ we, const float* __restrict__ be,
                                                    const float* __restrict__ ae, const float* __restrict__ wd, float bias,
                                                    int planes, int h, int w, int bands) {
@@ -476,6 +476,12 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
                     int w, float* ws12a, float* ws12b, hipStream_t st) {
   const size_t total = (size_t)planes * h * w;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  // SS4K_FS_EXACT=1: the exact-fp32 MFMA tail with the LDS ring (A/B switch and the reference of the split-precision test)
+  const char* exact_env = std::getenv("SS4K_FS_EXACT");   // read per call: the tests flip it
+  const bool exact = exact_env && exact_env[0] == '1';
+  // (an fp16-split MFMA head - 16x16x32, the first product's accumulators feeding the 1x1 shrink - was built and measured:
+  // 0.56 ms against this kernel's 0.62 per 12 planes of 720p; PReLU + re-splitting the 56-channel map costs ~7 vector
+  // instructions per value, as many as the whole exact vector-ALU chain: not kept)
   hipLaunchKernelGGL(k_fs_head, grid, block, 0, st, in, ws12a, W.w_feat, W.b_feat, W.a_feat, W.w_shrink, W.b_shrink,
                      W.a_shrink, planes, h, w);
   constexpr int FS_MAP_R = 4;
@@ -485,8 +491,6 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
     hipLaunchKernelGGL(k_fs_map<FS_MAP_R>, mgrid, block, 0, st, cur, nxt, W.w_map[l], W.b_map[l], W.a_map[l], planes, h, w);
     std::swap(cur, nxt);
   }
-  // SS4K_FS_EXACT=1: the exact-fp32 MFMA tail with the LDS ring (A/B switch and the reference of the split-precision test)
-  static const bool exact = [] { const char* e = std::getenv("SS4K_FS_EXACT"); return e && e[0] == '1'; }();
   SS4K_REQUIRE(factor == 2 || factor == 4, "FSRCNN: scale must be 2 or 4");
   const int ci = exact ? FS_CI : 4 * (factor == 2 ? FsTailGeo<2>::CI : FsTailGeo<4>::CI);   // interior LR columns per workgroup
   const int strips = (w + ci - 1) / ci;

@@ -65,6 +65,29 @@ def test_fsrcnn_golden(ctx, factor, tag):
     assert_close(m(dev(g["x"])), g["y"], what=f"fsrcnn x{factor} {tag}")
 
 
+@pytest.mark.parametrize("factor", [2, 4])
+def test_fsrcnn_split_tail_vs_exact(ctx, monkeypatch, factor):
+    """The production tail computes its two products on the fp16 matrix rate from hi/lo-split operands (three MFMAs per
+    product, fp32 accumulation) and overlap-adds in registers; SS4K_FS_EXACT=1 selects the exact-fp32 MFMA tail with the
+    LDS ring.  On the real T91 checkpoint values the two agree to a few 1e-6 of the output peak - two orders inside the
+    path's tolerance (rtol 1e-3 / atol 1e-4), which both also meet against the oracle."""
+    table = _t91(factor)
+    m = factory.build_model_fsrcnn(ctx, factor=factor, weights=table)
+    x = torch.rand(3, 1, 150, 333, generator=torch.Generator().manual_seed(4))   # ragged: several wave strips, partial last one
+    monkeypatch.setenv("SS4K_FS_EXACT", "1")
+    exact = m(x.cuda()).cpu()
+    monkeypatch.delenv("SS4K_FS_EXACT")
+    split = m(x.cuda()).cpu()
+    peak = float(exact.abs().max())
+    err = float((split - exact).abs().max())
+    print(f"fsrcnn x{factor} T91: split-fp16 tail vs exact-fp32 tail max |diff| {err:.3g} = {err / peak:.2e} of the output peak {peak:.3g}")
+    assert err <= 2e-5 * max(1.0, peak)
+    with torch.no_grad():
+        want = onets.fsrcnn(x, table, factor)
+    assert_close(split, want, what=f"fsrcnn x{factor} split tail vs oracle")
+    assert_close(exact, want, what=f"fsrcnn x{factor} exact tail vs oracle")
+
+
 @pytest.mark.parametrize("shape", [(1, 1, 5, 7), (3, 1, 33, 65), (2, 1, 64, 31)])
 def test_fsrcnn_ragged_shapes(ctx, shape):
     table = W.fsrcnn_table(seed=9)
