@@ -61,6 +61,42 @@ __global__ void k_area(const float* __restrict__ in, float* __restrict__ out, in
     dst[ox] = sum / (float)(y1 - y0) / (float)(x1 - x0);
   }
 }
+// Whole-number windows of KX = 4 or 8 columns (the service's HR -> H/8 map, x2 -> lr_shape reductions): the same sums in
+// the same order (rows outer, columns inner), the window's columns fetched as 16-byte loads - the scalar form issues KX
+// four-byte loads per row whose lanes sit 4*KX bytes apart
+template <bool NORM, int KX>
+__global__ void k_area_whole(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int oh, int ow, int ky,
+                             const float* __restrict__ st_hr, const float* __restrict__ st_lr) {
+  const int oy = blockIdx.y, pl = blockIdx.z;
+  NormCoef nk{};
+  if constexpr (NORM) nk = norm_coef(st_hr, st_lr, pl);
+  const float* src = in + ((size_t)pl * h + (size_t)oy * ky) * w;
+  float* dst = out + ((size_t)pl * oh + oy) * ow;
+  for (int ox = blockIdx.x * blockDim.x + threadIdx.x; ox < ow; ox += gridDim.x * blockDim.x) {
+    float sum = 0.f;
+    for (int y = 0; y < ky; ++y) {
+      const float4* rp = reinterpret_cast<const float4*>(src + (size_t)y * w + (size_t)ox * KX);
+#pragma unroll
+      for (int q = 0; q < KX / 4; ++q) {
+        const float4 v = rp[q];
+        sum += NORM ? norm_px(v.x, nk) : v.x; sum += NORM ? norm_px(v.y, nk) : v.y;
+        sum += NORM ? norm_px(v.z, nk) : v.z; sum += NORM ? norm_px(v.w, nk) : v.w;
+      }
+    }
+    dst[ox] = sum / (float)ky / (float)KX;
+  }
+}
+template <bool NORM>
+static bool area_whole(const float* in, float* out, int planes, int h, int w, int oh, int ow, const float* st_hr, const float* st_lr,
+                       hipStream_t st) {
+  if (h % oh || w % ow || (reinterpret_cast<uintptr_t>(in) & 15)) return false;
+  const int ky = h / oh, kx = w / ow;
+  const dim3 g((unsigned)std::min((ow + 255) / 256, 64), (unsigned)oh, (unsigned)planes);
+  if (kx == 4) hipLaunchKernelGGL((k_area_whole<NORM, 4>), g, dim3(256), 0, st, in, out, planes, h, w, oh, ow, ky, st_hr, st_lr);
+  else if (kx == 8) hipLaunchKernelGGL((k_area_whole<NORM, 8>), g, dim3(256), 0, st, in, out, planes, h, w, oh, ow, ky, st_hr, st_lr);
+  else return false;
+  return true;
+}
 static inline dim3 grid_rows(int ow, int oh, int planes) { return dim3((unsigned)std::min((ow + 255) / 256, 64), (unsigned)oh, (unsigned)planes); }
 void op_area(const float* in, float* out, int planes, int h, int w, int oh, int ow, hipStream_t st) {
   if (h == oh && w == ow) {
@@ -68,11 +104,13 @@ void op_area(const float* in, float* out, int planes, int h, int w, int oh, int 
     return;
   }
   SS4K_REQUIRE(oh <= 65535 && planes <= 65535, "area: grid limits");
+  if (area_whole<false>(in, out, planes, h, w, oh, ow, nullptr, nullptr, st)) { SS4K_LAUNCH_OK(); return; }
   hipLaunchKernelGGL(k_area<false>, grid_rows(ow, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow, nullptr, nullptr); SS4K_LAUNCH_OK();
 }
 void op_area_normalized(const float* in, float* out, int planes, int h, int w, int oh, int ow, const float* st_hr, const float* st_lr,
                         hipStream_t st) {
   SS4K_REQUIRE(oh <= 65535 && planes <= 65535, "area: grid limits");
+  if (area_whole<true>(in, out, planes, h, w, oh, ow, st_hr, st_lr, st)) { SS4K_LAUNCH_OK(); return; }
   hipLaunchKernelGGL(k_area<true>, grid_rows(ow, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow, st_hr, st_lr); SS4K_LAUNCH_OK();
 }
 
@@ -81,6 +119,18 @@ __global__ void k_stats_partial(const float* __restrict__ in, double* __restrict
   const int pl = blockIdx.y;
   const float* src = in + (size_t)pl * hw;
   double s = 0.0, q = 0.0;
+  if ((hw & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    // 16-byte loads, four independent fp64 chains (the sums are order-free: the partials meet in atomics anyway)
+    double s4[4] = {0, 0, 0, 0}, q4[4] = {0, 0, 0, 0};
+    const float4* s16 = reinterpret_cast<const float4*>(src);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)hw / 4; i += (size_t)gridDim.x * blockDim.x) {
+      const float4 v = s16[i];
+      const double d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s4[k] += d[k]; q4[k] += d[k] * d[k]; }
+    }
+    s = (s4[0] + s4[1]) + (s4[2] + s4[3]); q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+  } else
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)hw; i += (size_t)gridDim.x * blockDim.x) {
     const double v = src[i];
     s += v; q += v * v;
@@ -304,11 +354,78 @@ __global__ void k_tail_fused(float* __restrict__ hr, uint8_t* __restrict__ out, 
     }
   }
 }
+// the same pass with four consecutive pixels per thread (w % 4 == 0): 16-byte loads of each plane, one 12-byte store of
+// the four uint8 NHWC pixels (or a 16-byte store per plane); per-element expressions and their order are k_tail_fused's
+template <bool NORM, bool DIFF, bool U8>
+__global__ void k_tail_fused4(float* __restrict__ hr, uint8_t* __restrict__ out, const float* __restrict__ diff, int n, int h, int w,
+                              int dh, int dw, const float* __restrict__ st_hr, const float* __restrict__ st_lr) {
+  constexpr int C = 3;
+  const int oy = blockIdx.y, img = blockIdx.z;
+  const float sy = (float)dh / h, sx = (float)dw / w;
+  float fy = sy * (oy + 0.5f) - 0.5f; if (fy < 0) fy = 0;
+  const int y0 = (int)fy, y1 = y0 + (y0 < dh - 1 ? 1 : 0);
+  const float ly = fy - y0, hy = 1.f - ly;
+  for (int ox4 = blockIdx.x * blockDim.x + threadIdx.x; ox4 < w / 4; ox4 += gridDim.x * blockDim.x) {
+    int x0[4], x1[4]; float lx[4], hx[4];
+    if constexpr (DIFF) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float fx = sx * (4 * ox4 + j + 0.5f) - 0.5f; if (fx < 0) fx = 0;
+        x0[j] = (int)fx; x1[j] = x0[j] + (x0[j] < dw - 1 ? 1 : 0);
+        lx[j] = fx - x0[j]; hx[j] = 1.f - lx[j];
+      }
+    }
+    uint32_t b[C][4];
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      const int pl = img * C + k;
+      float4* p = reinterpret_cast<float4*>(hr + ((size_t)pl * h + oy) * w) + ox4;
+      const float4 in4 = *p;
+      float v[4] = {in4.x, in4.y, in4.z, in4.w};
+      NormCoef nk{};
+      if constexpr (NORM) nk = norm_coef(st_hr, st_lr, pl);
+      const float* r0 = nullptr; const float* r1 = nullptr;
+      if constexpr (DIFF) { r0 = diff + ((size_t)pl * dh + y0) * dw; r1 = diff + ((size_t)pl * dh + y1) * dw; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (NORM) v[j] = norm_px(v[j], nk);
+        if constexpr (DIFF) {
+          const float d = hy * (hx[j] * r0[x0[j]] + lx[j] * r0[x1[j]]) + ly * (hx[j] * r1[x0[j]] + lx[j] * r1[x1[j]]);
+          v[j] = v[j] - d;
+        }
+        v[j] = fminf(fmaxf(v[j], 0.f), 1.f);
+        if constexpr (U8) b[k][j] = (uint32_t)(uint8_t)(fminf(fmaxf(v[j], 0.f), 1.f) * 255.f);
+      }
+      if constexpr (!U8) *p = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if constexpr (U8) {
+      // bytes 3*j + k of the twelve: pixel j, plane k
+      uint32_t wds[3] = {0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < C; ++k) { const int byte = 3 * j + k; wds[byte >> 2] |= b[k][j] << (8 * (byte & 3)); }
+      uint32_t* o = reinterpret_cast<uint32_t*>(out + (((size_t)img * h + oy) * w + 4 * (size_t)ox4) * C);
+      o[0] = wds[0]; o[1] = wds[1]; o[2] = wds[2];
+    }
+  }
+}
 void op_tail_fused(float* hr, uint8_t* out_u8, const float* diff, int n, int c, int h, int w, int dh, int dw, const float* st_hr,
                    const float* st_lr, hipStream_t st) {
   SS4K_REQUIRE(h <= 65535 && n <= 65535, "fused tail: grid limits");
   const dim3 g = grid_rows(w, h, n);
   const bool norm = st_hr != nullptr, df = diff != nullptr, u8 = out_u8 != nullptr;
+  if (c == 3 && (w & 3) == 0 && (reinterpret_cast<uintptr_t>(hr) & 15) == 0 && (reinterpret_cast<uintptr_t>(out_u8) & 3) == 0) {
+    const dim3 g4 = grid_rows(w / 4, h, n);
+#define SS4K_TAIL4(N_, D_, U_) hipLaunchKernelGGL((k_tail_fused4<N_, D_, U_>), g4, dim3(256), 0, st, hr, out_u8, diff, n, h, w, dh, dw, st_hr, st_lr)
+    if (norm && df && u8) SS4K_TAIL4(true, true, true); else if (norm && df) SS4K_TAIL4(true, true, false);
+    else if (norm && u8) SS4K_TAIL4(true, false, true); else if (norm) SS4K_TAIL4(true, false, false);
+    else if (df && u8) SS4K_TAIL4(false, true, true); else if (df) SS4K_TAIL4(false, true, false);
+    else if (u8) SS4K_TAIL4(false, false, true); else SS4K_TAIL4(false, false, false);
+#undef SS4K_TAIL4
+    SS4K_LAUNCH_OK();
+    return;
+  }
 #define SS4K_TAIL(N_, D_, U_) hipLaunchKernelGGL((k_tail_fused<N_, D_, U_>), g, dim3(256), 0, st, hr, out_u8, diff, n, c, h, w, dh, dw, st_hr, st_lr)
   if (norm && df && u8) SS4K_TAIL(true, true, true); else if (norm && df) SS4K_TAIL(true, true, false);
   else if (norm && u8) SS4K_TAIL(true, false, true); else if (norm) SS4K_TAIL(true, false, false);
