@@ -90,7 +90,7 @@ struct Upscaler {
     hr.ensure((size_t)P * H * W * 4);
     float* hrp = hr.as<float>();
     SS4K_REQUIRE(P <= STATS_MAX_PLANES, "too many frames in one job");
-    st_hr.ensure(P * 8); st_lr.ensure(P * 8); st_acc.ensure(sizeof(double) * 2 * P);
+    st_hr.ensure(P * 8); st_lr.ensure(P * 8); st_acc.ensure(sizeof(double) * 2 * P * STATS_SLOTS);
     const int mh = H / 8, mw = W / 8;
     const bool color = mh > 8 && H > 64 && W > 64;  // local colour match, :201-218
     // the reference's guard looks at the height only; for HR widths of 65..71 its 17-tap reflect pad (8)
@@ -205,7 +205,7 @@ struct Upscaler {
     save_tap(1, hrp, n, 3, H, W, st);
     st_hr.ensure(P * 8); st_lr.ensure(P * 8);
     SS4K_REQUIRE(P <= STATS_MAX_PLANES, "too many frames in one job");
-    st_acc.ensure(sizeof(double) * 2 * P);
+    st_acc.ensure(sizeof(double) * 2 * P * STATS_SLOTS);
     op_plane_stats(st_acc.as<double>(), hrp, st_hr.as<float>(), P, H * W, st);
     op_plane_stats(st_acc.as<double>(), lr_before, st_lr.as<float>(), P, lh * lw, st);
     if (!taps_on) {
@@ -404,7 +404,7 @@ int ss4k_op_depthwise_reflect(ss4k_ctx* c, const float* in, float* out, int p, i
 int ss4k_op_plane_stats(ss4k_ctx* c, const float* in, float* stats, int p, int hw, void* s) {
   return guard([&] {
     SS4K_REQUIRE(c && in && stats, "NULL argument");
-    op_plane_stats(c->buf("stats_acc", sizeof(double) * 2 * STATS_MAX_PLANES).as<double>(), in, stats, p, hw, (hipStream_t)s);
+    op_plane_stats(c->buf("stats_acc", sizeof(double) * 2 * STATS_MAX_PLANES * STATS_SLOTS).as<double>(), in, stats, p, hw, (hipStream_t)s);
   });
 }
 int ss4k_op_f32nchw_to_u8nhwc(ss4k_ctx* c, const float* in, uint8_t* out, int n, int ch, int h, int w, void* s) {

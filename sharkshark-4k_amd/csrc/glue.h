@@ -9,6 +9,10 @@ void op_area(const float* in, float* out, int planes, int h, int w, int oh, int 
 // acc: 2 * planes doubles of scratch owned by the caller (each upscaler owns its own, so two upscalers
 // of one context never share partial sums), planes <= STATS_MAX_PLANES
 constexpr int STATS_MAX_PLANES = 4096;
+// the fp64 partial sums of a plane are spread over this many slots ([slot][plane][2], acc buffers hold STATS_SLOTS * 2 * planes
+// doubles): thousands of workgroups adding into ONE address pair per plane serialise in the memory-side atomic units
+// (measured: the statistics pass ran at 1.4 TB/s, the PixelShuffle tail doubled its time when the sums rode along)
+constexpr int STATS_SLOTS = 32;
 void op_plane_stats(double* acc, const float* in, float* stats, int planes, int hw, hipStream_t st);
 void op_plane_stats_finish(const double* acc, float* stats, int planes, int hw, hipStream_t st);
 void op_area_normalized(const float* in, float* out, int planes, int h, int w, int oh, int ow, const float* st_hr, const float* st_lr,

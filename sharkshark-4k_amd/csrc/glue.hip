@@ -143,14 +143,17 @@ __global__ void k_stats_partial(const float* __restrict__ in, double* __restrict
   if (threadIdx.x == 0) {
     double S = 0, Q = 0;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { S += ss[i]; Q += sq[i]; }
-    atomicAdd(&acc[2 * pl], S);
-    atomicAdd(&acc[2 * pl + 1], Q);
+    double* a = acc + ((size_t)(blockIdx.x % STATS_SLOTS) * gridDim.y + pl) * 2;
+    atomicAdd(&a[0], S);
+    atomicAdd(&a[1], Q);
   }
 }
 __global__ void k_stats_final(const double* __restrict__ acc, float* __restrict__ stats, int planes, int hw) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= planes) return;
-  const double n = (double)hw, S = acc[2 * p], Q = acc[2 * p + 1];
+  double S = 0, Q = 0;
+  for (int s = 0; s < STATS_SLOTS; ++s) { S += acc[((size_t)s * planes + p) * 2]; Q += acc[((size_t)s * planes + p) * 2 + 1]; }
+  const double n = (double)hw;
   const double mean = S / n;
   double var = (Q - S * S / n) / (n - 1.0);  // Bessel-corrected, torch.std default (fsrcnn_upscaler.py:193)
   if (var < 0) var = 0;
@@ -162,9 +165,9 @@ void op_plane_stats_finish(const double* acc, float* stats, int planes, int hw, 
 }
 void op_plane_stats(double* acc, const float* in, float* stats, int planes, int hw, hipStream_t st) {
   SS4K_REQUIRE(planes <= STATS_MAX_PLANES, "plane_stats: too many planes");
-  SS4K_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 2 * planes, st));
+  SS4K_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 2 * planes * STATS_SLOTS, st));
   int gx = (hw + 256 * 16 - 1) / (256 * 16);
-  gx = std::max(1, std::min(gx, 512));
+  gx = std::max(1, std::min(gx, 128));
   hipLaunchKernelGGL(k_stats_partial, dim3(gx, planes), dim3(256), 0, st, in, acc, hw); SS4K_LAUNCH_OK();
   op_plane_stats_finish(acc, stats, planes, hw, st);
 }
@@ -470,8 +473,68 @@ __global__ void k_bicubic_u8(const float* __restrict__ in, uint8_t* __restrict__
     }
   }
 }
+// the same resize at exactly 2 : 1 (the x4 network's output brought to the x2 frame size, fsrcnn_upscaler.py:223-231):
+// every sample sits at t = 0.5 of input columns 2*ox - 1 .. 2*ox + 2, so four adjacent outputs share ten input columns of
+// each of their four rows - two 16-byte loads and two clamped edge loads instead of sixteen 4-byte ones, and one 12-byte
+// store of the four uint8 NHWC pixels.  Coefficients, products and their order are k_bicubic_u8's.
+__global__ void k_bicubic_u8_half(const float* __restrict__ in, uint8_t* __restrict__ out, int n, int h, int w, int oh, int ow) {
+  constexpr int C = 3;
+  const int oy = blockIdx.y, img = blockIdx.z;
+  const float sy = (float)h / oh, sx = (float)w / ow;
+  const float fy = sy * (oy + 0.5f) - 0.5f, fly = floorf(fy);
+  const int iy = (int)fly;
+  float cy[4];
+  cubic_coeffs(fy - fly, cy);
+  int yi[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) yi[a] = min(max(iy - 1 + a, 0), h - 1);
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ow / 4; t += gridDim.x * blockDim.x) {
+    float cx[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float fx = sx * (4 * t + j + 0.5f) - 0.5f;
+      cubic_coeffs(fx - floorf(fx), cx[j]);
+    }
+    const int xl = max(8 * t - 1, 0), xr = min(8 * t + 8, w - 1);
+    uint32_t b[C][4];
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      const float* src = in + (size_t)(img * C + k) * h * w;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const float* rowp = src + (size_t)yi[a] * w;
+        const float4 m0 = *reinterpret_cast<const float4*>(rowp + 8 * t), m1 = *reinterpret_cast<const float4*>(rowp + 8 * t + 4);
+        const float col[10] = {rowp[xl], m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, rowp[xr]};   // columns 8t-1 .. 8t+8
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float row = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) row += cx[j][q] * col[2 * j + q];
+          acc[j] += cy[a] * row;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = fminf(fmaxf(acc[j], 0.f), 1.f);
+        b[k][j] = (uint32_t)(uint8_t)(fminf(fmaxf(v, 0.f), 1.f) * 255.f);
+      }
+    }
+    uint32_t wds[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < C; ++k) { const int byte = 3 * j + k; wds[byte >> 2] |= b[k][j] << (8 * (byte & 3)); }
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + (((size_t)img * oh + oy) * ow + 4 * (size_t)t) * C);
+    o[0] = wds[0]; o[1] = wds[1]; o[2] = wds[2];
+  }
+}
 void op_bicubic_u8(const float* in, uint8_t* out, int n, int c, int h, int w, int oh, int ow, hipStream_t st) {
   SS4K_REQUIRE(oh <= 65535 && n <= 65535, "bicubic: grid limits");
+  if (c == 3 && h == 2 * oh && w == 2 * ow && (ow & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0) {
+    hipLaunchKernelGGL(k_bicubic_u8_half, grid_rows(ow / 4, oh, n), dim3(256), 0, st, in, out, n, h, w, oh, ow); SS4K_LAUNCH_OK();
+    return;
+  }
   hipLaunchKernelGGL(k_bicubic_u8, grid_rows(ow, oh, n), dim3(256), 0, st, in, out, n, c, h, w, oh, ow); SS4K_LAUNCH_OK();
 }
 
@@ -606,8 +669,9 @@ __global__ __launch_bounds__(256) void k_ps_nchw_addbase(const T* __restrict__ s
       const int c = threadIdx.x;
       double S = 0, Q = 0;
       for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { S += ss[c][i]; Q += sq[c][i]; }
-      atomicAdd(&acc[2 * (img * cq + c)], S);
-      atomicAdd(&acc[2 * (img * cq + c) + 1], Q);
+      double* a = acc + ((size_t)((blockIdx.x + blockIdx.y) % STATS_SLOTS) * (gridDim.z * cq) + img * cq + c) * 2;
+      atomicAdd(&a[0], S);
+      atomicAdd(&a[1], Q);
     }
   }
 }
@@ -615,7 +679,7 @@ template <typename T>
 void op_ps_nchw_addbase(const T* src, float* out, const float* base, int n, int h, int w, int r, int cq, double* stats_acc, hipStream_t st) {
   SS4K_REQUIRE(h <= 65535 && n <= 65535, "pixel shuffle tail: grid limits");
   SS4K_REQUIRE(!stats_acc || cq <= 4, "pixel shuffle tail: statistics for at most 4 colours");
-  if (stats_acc) SS4K_HIP(hipMemsetAsync(stats_acc, 0, sizeof(double) * 2 * n * cq, st));
+  if (stats_acc) SS4K_HIP(hipMemsetAsync(stats_acc, 0, sizeof(double) * 2 * n * cq * STATS_SLOTS, st));
   if (r == 4) {
     if (stats_acc) { hipLaunchKernelGGL((k_ps_nchw_addbase<T, 4, true>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq, stats_acc); }
     else { hipLaunchKernelGGL((k_ps_nchw_addbase<T, 4, false>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq, stats_acc); }

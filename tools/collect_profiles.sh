@@ -8,15 +8,19 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG; mkdir -p $O
 B="python3 bench.py --no-cpu-baseline --no-also"
-# 1. headline: per-kernel stats + the bench line printed under the profiler
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/st -- $B --steps 5 --warmup 2 > $O/bench_under_rocprof.log 2>&1
+# 1. headline: per-kernel stats + the bench line printed under the profiler + how many conv launches are in flight
+#    (frame lanes: two concurrent launch chains; the choice is measured by the library over its first calls)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/st -- $B --steps 8 --warmup 6 > $O/bench_under_rocprof.log 2>&1
 cp $(find $O/st -name "*kernel_stats.csv" | head -1) $O/${TAG}_rrdbnet_x2_720p_batch4_kernel_stats.csv
 grep '^{' $O/bench_under_rocprof.log | tail -1 > $O/${TAG}_bench_line_under_rocprof.json
+python3 tools/trace_overlap.py $O/st 0.5 > $O/${TAG}_rrdbnet_lanes_overlap.txt
 rm -rf $O/st
+# the counter passes serialise kernels: two chains are forced (SS4K_LANES=2) so that every launch carries 2 frames
+export SS4K_LANES=2
 # 2. headline: fabric traffic of the conv launches (separate passes)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B --steps 2 --warmup 1 --no-roofline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B --steps 2 --warmup 1 --no-roofline > /dev/null 2>&1
-python3 tools/pmc_traffic.py $O/fetch $O/write $O/${TAG}_conv3x3_pmc_traffic.json 4 > /dev/null
+python3 tools/pmc_traffic.py $O/fetch $O/write $O/${TAG}_conv3x3_pmc_traffic.json 2 > /dev/null
 rm -rf $O/fetch $O/write
 # 3. headline: SQ counters (matrix-pipe share, LDS conflicts, wait shares) and L2 hit rate, per kernel
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS \
@@ -26,11 +30,17 @@ rm -rf $O/sq
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/tcc -- $B --steps 1 --warmup 1 --no-roofline > /dev/null 2>&1
 python3 tools/pmc_summary.py $O/tcc $O/${TAG}_rrdbnet_tcc_counters.json > /dev/null
 rm -rf $O/tcc
+unset SS4K_LANES
 # 4. the other workloads: per-kernel stats
 for wl in fsrcnn pipeline srvgg rrdbnet_x4; do
   extra=""; [ $wl = rrdbnet_x4 ] && extra="--batch 1"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/st -- python3 bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-also --no-roofline $extra > $O/bench_$wl.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/st -- python3 bench.py --workload $wl --steps 8 --warmup 6 --no-cpu-baseline --no-also --no-roofline $extra > $O/bench_$wl.log 2>&1
   cp $(find $O/st -name "*kernel_stats.csv" | head -1) $O/${TAG}_${wl}_kernel_stats.csv
   rm -rf $O/st
 done
+# 5. FSRCNN: SQ counters of its kernels
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS \
+  --kernel-trace --output-format csv -d $O/sqf -- python3 bench.py --workload fsrcnn --steps 1 --warmup 1 --no-cpu-baseline --no-also --no-roofline > /dev/null 2>&1
+python3 tools/pmc_summary.py $O/sqf $O/${TAG}_fsrcnn_sq_counters.json > /dev/null
+rm -rf $O/sqf
 ls -la $O
