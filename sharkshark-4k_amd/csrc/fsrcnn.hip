@@ -472,6 +472,169 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Production mapping stage: the four conv3x3(12->12)+PReLU layers in ONE kernel on the fp16 matrix rate (hi/lo-split
+// operands, three v_mfma_f32_16x16x32_f16 per product: see the tail above), intermediates never leaving the CU.
+//
+// A workgroup marches down a strip of 48 columns (40 interior + the 4 of halo each side that four layers need) of one band
+// of rows; wave s IS layer s.  At step t layer s computes its output row t - 2s from three rows of layer s-1 (a ring
+// of four rows per layer in LDS, written one step earlier) and stores it - already split into fp16 hi / lo, 16
+// channel slots (12 real) per pixel = 64 bytes - into the ring of layer s+1; layer 3 stores fp32 to HBM.  One
+// barrier per step, 51 KB of LDS, three workgroups per CU.
+// GEMM shape per 16 pixels: D[16 cout x 16 px] += W[16 x 32] * X[32 x 16], K = 2 taps x 16 channel slots, five K-steps
+// for the nine taps; the B operand of a lane is 16 bytes of one pixel of one tap, read from the ring where the
+// producing layer left it (no conversion on the consumer side).  Zero padding of every layer = zero records
+// outside the image (rows and columns), which is also what the never-written ring borders hold.
+constexpr int FM_U = 3, FM_COLS = 16 * FM_U, FM_HALO = 4, FM_CI = FM_COLS - 2 * FM_HALO, FM_RW = FM_COLS + 2;
+constexpr int FM_ROWB = FM_RW * 64, FM_STAGEB = 4 * FM_ROWB, FM_LDS = 4 * FM_STAGEB;
+struct FsMapW { const float* w[4]; const float* b[4]; const float* a[4]; };
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ in, float* __restrict__ out, const FsMapW W,
+                                                     int planes, int h, int w, int bands) {
+  extern __shared__ __attribute__((aligned(16))) char fm_ring[];
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+  const int st = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's layer
+  const int strips = (w + FM_CI - 1) / FM_CI;
+  const int strip = blockIdx.x % strips, band = (blockIdx.x / strips) % bands, plane = blockIdx.x / (strips * bands);
+  const int rpb = (h + bands - 1) / bands, ylo = band * rpb, yhi = min(h, ylo + rpb);
+  if (plane >= planes || ylo >= yhi) return;
+  const int x0 = strip * FM_CI;
+  for (int e = tid; e < FM_LDS / 16; e += 256) reinterpret_cast<uint4*>(fm_ring)[e] = make_uint4(0u, 0u, 0u, 0u);
+
+  // A operands of this wave's layer: row m = lane & 15 is the output channel, k = 8*q + j of K-step ks is tap
+  // 2*ks + (q >> 1), channel slot 8*(q & 1) + j
+  uint4 ah[5], al[5];
+  {
+    const float* wm = W.w[st];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      uint32_t vh[4], vl[4];
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        float v[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          const int tap = 2 * ks + (q >> 1), ch = 8 * (q & 1) + j + t2;
+          v[t2] = (tap < 9 && ch < 12 && n < 12) ? wm[(tap * 12 + ch) * 12 + n] : 0.f;
+        }
+        split2(v[0], v[1], vh[j >> 1], vl[j >> 1]);
+      }
+      ah[ks] = make_uint4(vh[0], vh[1], vh[2], vh[3]); al[ks] = make_uint4(vl[0], vl[1], vl[2], vl[3]);
+    }
+  }
+  // epilogue constants of the channels this lane holds (4q .. 4q+3), and its B-operand addressing per K-step:
+  // pixel column (n + dx + 1) of the ring row, 16-byte slot (q & 1) [hi] / 2 + (q & 1) [lo], slots XOR-swizzled by the column
+  f32x4v bia, slo;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int c = 4 * q + i; bia[i] = c < 12 ? W.b[st][c] : 0.f; slo[i] = c < 12 ? W.a[st][c] : 1.f; }
+  int col_hi[5], col_lo[5], dyi[5];
+#pragma unroll
+  for (int ks = 0; ks < 5; ++ks) {
+    const int tap = min(2 * ks + (q >> 1), 8);   // the tenth tap does not exist: its weights are zero, read the ninth's pixel
+    const int dy = tap / 3, dx = tap % 3, cc = n + dx;   // ring column of unit 0 (image column x0 - 8 + n + dx - 1)
+    const int sw = (cc >> 2) & 3;
+    dyi[ks] = dy;
+    col_hi[ks] = cc * 64 + (((q & 1) ^ sw) << 4);
+    col_lo[ks] = cc * 64 + (((2 + (q & 1)) ^ sw) << 4);
+  }
+  // where this lane's output lands in the next ring: column n + 1 of unit 0, slot q >> 1 (hi) / 2 + (q >> 1) (lo), bytes 8*(q&1)
+  const int wsw = ((n + 1) >> 2) & 3;
+  const int wr_hi = (n + 1) * 64 + ((((q >> 1)) ^ wsw) << 4) + 8 * (q & 1);
+  const int wr_lo = (n + 1) * 64 + (((2 + (q >> 1)) ^ wsw) << 4) + 8 * (q & 1);
+
+  const size_t plane_px = (size_t)h * w, total = (size_t)planes * plane_px;
+  const float4* in4 = reinterpret_cast<const float4*>(in) + (size_t)plane * plane_px;
+  float4* out4 = reinterpret_cast<float4*>(out) + (size_t)plane * plane_px;
+  // input loader: thread tid < 144 moves channel group g = tid / 48 of ring column c = tid % 48 (+1) of one input row
+  const int lg = tid / FM_COLS, lc = tid % FM_COLS, lx = x0 - FM_HALO + lc;
+  const bool loader = tid < 3 * FM_COLS, lcol_ok = lx >= 0 && lx < w;
+  const int lsw = ((lc + 1) >> 2) & 3;
+  const int ld_hi = (lc + 1) * 64 + (((lg >> 1) ^ lsw) << 4) + 8 * (lg & 1);
+  const int ld_lo = (lc + 1) * 64 + (((2 + (lg >> 1)) ^ lsw) << 4) + 8 * (lg & 1);
+  auto load_row = [&](int r) -> float4 {   // relative row r = image row ylo - 4 + r
+    const int y = ylo - 4 + r;
+    if (loader && lcol_ok && y >= 0 && y < h) return in4[lg * total + (size_t)y * w + lx];
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto store_row = [&](int r, const float4& v) {
+    if (!loader) return;
+    uint32_t h0, h1, l0, l1;
+    split2(v.x, v.y, h0, l0); split2(v.z, v.w, h1, l1);
+    char* row = fm_ring + (r & 3) * FM_ROWB;   // ring of layer 0
+    *reinterpret_cast<uint2*>(row + ld_hi) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(row + ld_lo) = make_uint2(l0, l1);
+  };
+  __syncthreads();   // rings are zero
+  store_row(0, load_row(0)); store_row(1, load_row(1));
+  float4 nxt = load_row(2);
+  __syncthreads();
+  constexpr float LO = 1.f / 2048.f;
+  const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int nsteps = (yhi - ylo) + 4 + 6;   // layer 3 reaches relative row (yhi - ylo) + 3 at step that + 6
+  for (int t = 0; t < nsteps; ++t) {
+    // input row t + 2 goes into layer 0's ring while rows t - 1 .. t + 1 are being read; row t + 3 is fetched
+    store_row(t + 2, nxt);
+    nxt = load_row(t + 3);
+    const int r = t - 2 * st;   // this layer's output row (wave-uniform)
+    if (r >= 0 && r <= (yhi - ylo) + 3 + (3 - st)) {
+      const int y = ylo - 4 + r;
+      const bool row_in = y >= 0 && y < h;
+      const char* src = fm_ring + st * FM_STAGEB;
+      const char* ph[5]; const char* pl[5];   // this step's B-operand addresses of unit 0 (units are 1 KB apart)
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) {
+        const int rowoff = ((r - 1 + dyi[ks]) & 3) * FM_ROWB;
+        ph[ks] = src + rowoff + col_hi[ks]; pl[ks] = src + rowoff + col_lo[ks];
+      }
+      char* dst = fm_ring + (st + 1) * FM_STAGEB + (r & 3) * FM_ROWB;   // (layer 3 writes to HBM instead)
+#pragma unroll
+      for (int u = 0; u < FM_U; ++u) {
+        f32x4v v = zero4;
+        const int x = x0 - FM_HALO + 16 * u + n;
+        if (row_in) {   // wave-uniform
+          f32x4v d1 = bia, d2 = zero4;
+          // all ten operand reads of the unit first (left to itself hipcc waits for every pair right before its MFMAs)
+          uint4 fh[5], fl[5];
+#pragma unroll
+          for (int ks = 0; ks < 5; ++ks) {
+            fh[ks] = *reinterpret_cast<const uint4*>(ph[ks] + u * 1024);
+            fl[ks] = *reinterpret_cast<const uint4*>(pl[ks] + u * 1024);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ks = 0; ks < 5; ++ks) {
+            const f16x8v bh = __builtin_bit_cast(f16x8v, fh[ks]), bl = __builtin_bit_cast(f16x8v, fl[ks]);
+            const f16x8v wh = __builtin_bit_cast(f16x8v, ah[ks]), wl = __builtin_bit_cast(f16x8v, al[ks]);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh, d1, 0, 0, 0);
+            d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, d2, 0, 0, 0);
+            d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, d2, 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = prelu(fmaf(d2[i], LO, d1[i]), slo[i]);
+          const int xu = x0 - FM_HALO + 16 * u;   // wave-uniform: only units that straddle the image edge mask
+          if (xu < 0 || xu + 15 >= w) {
+            const bool ok = x >= 0 && x < w;       // a column outside the image is zero padding for the next layer
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ok ? v[i] : 0.f;
+          }
+        }
+        if (st < 3) {
+          if (q < 3) {
+            uint32_t h0, h1, l0, l1;
+            split2(v[0], v[1], h0, l0); split2(v[2], v[3], h1, l1);
+            *reinterpret_cast<uint2*>(dst + u * 1024 + wr_hi) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(dst + u * 1024 + wr_lo) = make_uint2(l0, l1);
+          }
+        } else if (row_in && q < 3 && y >= ylo && y < yhi && x >= x0 && x < x0 + FM_CI && x < w) {
+          out4[q * total + (size_t)y * w + x] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const float* in, float* out, int planes, int h,
                     int w, float* ws12a, float* ws12b, hipStream_t st) {
   const size_t total = (size_t)planes * h * w;
@@ -487,8 +650,21 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
   constexpr int FS_MAP_R = 4;
   const dim3 mgrid((unsigned)(((size_t)planes * ((h + FS_MAP_R - 1) / FS_MAP_R) * w + 255) / 256));
   float* cur = ws12a; float* nxt = ws12b;
-  for (int l = 0; l < 4; ++l) {
-    hipLaunchKernelGGL(k_fs_map<FS_MAP_R>, mgrid, block, 0, st, cur, nxt, W.w_map[l], W.b_map[l], W.a_map[l], planes, h, w);
+  if (exact) {
+    for (int l = 0; l < 4; ++l) {
+      hipLaunchKernelGGL(k_fs_map<FS_MAP_R>, mgrid, block, 0, st, cur, nxt, W.w_map[l], W.b_map[l], W.a_map[l], planes, h, w);
+      std::swap(cur, nxt);
+    }
+  } else {
+    FsMapW mw;
+    for (int l = 0; l < 4; ++l) { mw.w[l] = W.w_map[l]; mw.b[l] = W.b_map[l]; mw.a[l] = W.a_map[l]; }
+    const int mstrips = (w + FM_CI - 1) / FM_CI;
+    // at most one round of workgroups at three per CU (a second, partly filled round costs a whole march); every band
+    // re-does 8 halo rows plus 6 steps of pipeline fill
+    const int mbands = std::max(1, std::min((h + 31) / 32, 3 * ctx->num_cu / std::max(1, planes * mstrips)));
+    const void* fn = reinterpret_cast<const void*>(&k_fs_maps4);
+    if (ctx->lds_attr_set.insert(fn).second) SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, FM_LDS));
+    hipLaunchKernelGGL(k_fs_maps4, dim3((unsigned)(planes * mbands * mstrips)), block, FM_LDS, st, cur, nxt, mw, planes, h, w, mbands);
     std::swap(cur, nxt);
   }
   SS4K_REQUIRE(factor == 2 || factor == 4, "FSRCNN: scale must be 2 or 4");
