@@ -33,7 +33,7 @@ from sharkshark4k_amd.upscale import model as factory  # noqa: E402
 
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16
 F32_VECTOR_PEAK_TFLOPS = 157.3
-PMC_TRAFFIC_FILE = "r02a_conv3x3_pmc_traffic.json"  # refreshed whenever the conv kernel changes (tools/pmc_traffic.py)
+PMC_TRAFFIC_FILE = "r02b_conv3x3_pmc_traffic.json"  # refreshed whenever the conv kernel changes (tools/pmc_traffic.py)
 CONV_KERNEL_NAME = ("3x3 implicit-GEMM conv, all launches of a step: ss4k::conv3x3_kernel<__half,NB> (LDS weights, "
                     "v_mfma_f32_32x32x16_f16) + ss4k::rs::conv3x3_rs_kernel<6,16,1,4> (register-stationary weights, "
                     "v_mfma_f32_16x16x32_f16; conv5 of every RDB)")
@@ -306,7 +306,10 @@ def main():
                 # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
                 with open(pmc) as f:
                     pj = json.load(f)
-                traffic, traffic_src = pj["traffic_bytes_per_launch"], f"profiles/{PMC_TRAFFIC_FILE} (" + pj["correction"] + ")"
+                # the committed passes ran with two launch chains forced (2 frames per launch): scale to this run's launches
+                fpl = args.batch * 351.0 / rl["launches_per_step"]
+                traffic = pj["traffic_bytes_per_launch"] * fpl / pj["frames_per_launch"]
+                traffic_src = f"profiles/{PMC_TRAFFIC_FILE} (" + pj["correction"] + f"; {pj['frames_per_launch']} frames per launch in the counter passes)"
             result["roofline"] = {"bound": "mfma", "achieved": rl["achieved"], "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
                                   "unit": "TFLOP/s", "frac": rl["frac"], "traffic": traffic,
                                   "traffic_unit": "bytes per launch (L2<->fabric, PMC)", "traffic_source": traffic_src,
