@@ -235,3 +235,21 @@ def test_frame_lanes_bit_identical(ctx, monkeypatch, kind):
     monkeypatch.setenv("SS4K_LANES", "2")
     m = build()
     assert torch.equal(m(x[:3]), outs["1"][:3])
+
+
+def test_tile_height_builds_bit_identical(ctx, monkeypatch):
+    """The 32-cout body layers run on 16-row or 20-row tiles (csrc/conv_mfma.hip: whichever cuts the image rows with less
+    waste, SS4K_MB=4/5 forces one): tiles only partition the pixels, so the network output must not change by a bit -
+    including ragged heights where the last tile row of either shape is partly outside the image."""
+    t = W.rrdbnet_table(8, scale=2, num_block=2)
+    m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=2), W.flatten(t, W.rrdbnet_keys(2)))
+    for shape in ((2, 3, 120, 136), (1, 3, 92, 200), (3, 3, 80, 72)):   # body grids 60x68, 46x100, 40x36
+        x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[2])).cuda()
+        monkeypatch.setenv("SS4K_MB", "4")
+        a = m(x).clone()
+        monkeypatch.setenv("SS4K_MB", "5")
+        b = m(x).clone()
+        monkeypatch.delenv("SS4K_MB")
+        c = m(x).clone()
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b) and torch.equal(a, c), f"{shape}: tile height changed the result"
