@@ -900,7 +900,9 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
     // stage is 1.17 instead of 1.20 too) AND there is still at least one tile in flight per workgroup slot (a 1-frame 720p job
     // on one chain has 360 such tiles for 512 slots: measured -1.3 %; 4- and 2-frame jobs: +1.7 % / +2.2 % on the whole network).
     // Same kernel, one more build, bit-identical results; SS4K_MB=4/5 is the A/B switch (tools/env_ab.py).  24-row tiles
-    // (six rows per wave) were built and measured too: +0.2 % over 20-row ones at 4 frames, -1.8 % at 2: not kept.
+    // (six rows per wave) were built and measured too: +0.2 % over 20-row ones at 4 frames, -1.8 % at 2: not kept; 40-row
+    // tiles on eight waves (one workgroup per CU, 17 % fewer L2->LDS bytes): +0.3 %; 8-row tiles at three workgroups per
+    // CU: -5.3 % (-5.9 % on 1-frame jobs).
     const char* mb_e = std::getenv("SS4K_MB");   // read per launch
     const auto waste = [&](int th) { return (double)((a.H + th - 1) / th * th) / a.H; };
     // tiles in flight: a frame lane's launch (grid_share set) shares the chip with the other chain's launch
