@@ -120,6 +120,7 @@ struct ConvArgs {
   int n0;                               // first frame of this launch inside the tensors (frame lanes: a job's frames split
                                         // over concurrent launches); N counts this launch's frames
   float grid_share;                     // size the persistent grid for this share of the chip's workgroup slots (0 = all)
+  int mb_override;                      // 0: tile height of the 32-cout layers by image height; 4 / 5: rows per wave forced (A/B)
   int ups2;                             // input is the nearest-x2 upsampling of an (H/2, W/2) tensor
   const void* wpk;                      // packed weights [group][chunk][dx,ks][dy][nb][lane][E]
   const void* wrs;                      // conv_rs.hip layout [group][cout group][chunk32][tap][cb][lane][8] or null

@@ -32,7 +32,6 @@
 // Nearest-x2 upsampled input, stride-2 subsampling, PixelShuffle(2) and the NCHW fp32 hand-off are
 // address modes of the DMA source / the epilogue store, not extra passes.
 #include "common.h"
-#include <cstdlib>
 
 #ifndef SS4K_ROLL
 #define SS4K_ROLL(MB) ((MB) >= 4)
@@ -899,16 +898,15 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
     // ones (360 rows = 18 x 20 but 22.5 x 16: the last 16-row tile row computes 8 rows of nothing; the halo overhead of a
     // stage is 1.17 instead of 1.20 too) AND there is still at least one tile in flight per workgroup slot (a 1-frame 720p job
     // on one chain has 360 such tiles for 512 slots: measured -1.3 %; 4- and 2-frame jobs: +1.7 % / +2.2 % on the whole network).
-    // Same kernel, one more build, bit-identical results; SS4K_MB=4/5 is the A/B switch (tools/env_ab.py).  24-row tiles
+    // Same kernel, one more build, bit-identical results; SS4K_MB=4/5 (read when a model is built) is the A/B switch (tools/env_ab.py).  24-row tiles
     // (six rows per wave) were built and measured too: +0.2 % over 20-row ones at 4 frames, -1.8 % at 2: not kept; 40-row
     // tiles on eight waves (one workgroup per CU, 17 % fewer L2->LDS bytes): +0.3 %; 8-row tiles at three workgroups per
     // CU: -5.3 % (-5.9 % on 1-frame jobs).
-    const char* mb_e = std::getenv("SS4K_MB");   // read per launch
     const auto waste = [&](int th) { return (double)((a.H + th - 1) / th * th) / a.H; };
     // tiles in flight: a frame lane's launch (grid_share set) shares the chip with the other chain's launch
     const long long tiles20 = (long long)a.N * ((a.H + 19) / 20) * a.tiles_x * (a.grid_share > 0.f ? 2 : 1);
     const bool mb5 = dtype == SS4K_F16 && nb == 1 && ek == EK_PLAIN &&
-                     (mb_e ? std::atoi(mb_e) == 5 : (waste(20) < waste(16) - 1e-9 && tiles20 >= 2LL * ctx->num_cu));
+                     (a.mb_override ? a.mb_override == 5 : (waste(20) < waste(16) - 1e-9 && tiles20 >= 2LL * ctx->num_cu));
     if (mb5) launch_t<__half, 1, 5, 4, 0, EK_PLAIN>(ctx, a, groups, st);
     else if (dtype == SS4K_F16) { if (nb == 1) { SS4K_LAUNCH_EK(__half, 1) } else { SS4K_LAUNCH_EK(__half, 2) } }
     else { if (nb == 1) { SS4K_LAUNCH_EK(float, 1) } else { SS4K_LAUNCH_EK(float, 2) } }

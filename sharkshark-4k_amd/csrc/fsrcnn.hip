@@ -9,7 +9,6 @@
 //   tail  = conv1x1(12->56)+PReLU -> ConvTranspose 9x9 stride s   (fused, exact-fp32 MFMA: k_fs_tail)
 #include "common.h"
 #include "glue.h"
-#include <cstdlib>
 
 namespace ss4k {
 
@@ -636,12 +635,11 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
 }
 
 void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const float* in, float* out, int planes, int h,
-                    int w, float* ws12a, float* ws12b, hipStream_t st) {
+                    int w, float* ws12a, float* ws12b, bool exact, hipStream_t st) {
   const size_t total = (size_t)planes * h * w;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
-  // SS4K_FS_EXACT=1: the exact-fp32 MFMA tail with the LDS ring (A/B switch and the reference of the split-precision test)
-  const char* exact_env = std::getenv("SS4K_FS_EXACT");   // read per call: the tests flip it
-  const bool exact = exact_env && exact_env[0] == '1';
+  // exact (SS4K_FS_EXACT=1 when the model was built): the exact-fp32 kernels - vector-ALU mapping layers, fp32-MFMA tail with
+  // the LDS ring - A/B switch and the reference of the split-precision test
   // (an fp16-split MFMA head - 16x16x32, the first product's accumulators feeding the 1x1 shrink - was built and measured:
   // 0.56 ms against this kernel's 0.62 per 12 planes of 720p; PReLU + re-splitting the 56-channel map costs ~7 vector
   // instructions per value, as many as the whole exact vector-ALU chain: not kept)

@@ -55,6 +55,6 @@ struct FsrcnnWeights {
   float b_deconv;
 };
 void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const float* in, float* out, int planes, int h,
-                    int w, float* ws12a, float* ws12b, hipStream_t st);
+                    int w, float* ws12a, float* ws12b, bool exact, hipStream_t st);
 
 }  // namespace ss4k

@@ -177,6 +177,8 @@ void Model::build(const float* w, size_t n) {
   if (const char* e = std::getenv("SS4K_RS_W8")) rs_wide = e[0] == '1';          // A/B switch: eight-wave variants of the 32-cout shapes
   // frame lanes (models.h): 0 / unset = choose per shape from two timed calls of each mode, 1 = off, 2 = always on
   if (const char* e = std::getenv("SS4K_LANES")) lanes_mode = std::max(0, std::min(2, std::atoi(e)));
+  if (const char* e = std::getenv("SS4K_MB")) mb_override = std::atoi(e);
+  if (const char* e = std::getenv("SS4K_FS_EXACT")) fs_exact = e[0] == '1';
   if (const char* e = std::getenv("SS4K_LANE_GRID")) lane_grid_share = (float)std::atof(e);   // A/B switch: grid of a lane's launch as a share of the chip's slots
   SS4K_REQUIRE(n == model_param_count(desc), "weight blob size does not match the model description");
   ParamCursor pc{w, n};
@@ -264,7 +266,7 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
   a.bsvd_resid = o.bsvd_resid;
   a.epi = o.epi; a.out = o.out.p; a.out_plane_bytes = o.out.plane_bytes; a.out_plane0 = o.out.plane0;
   a.cout_real = L.cout_real; a.cout_pad = L.cout_pad;
-  a.dbg = dbg; a.dbg_buf = dbg_buf;
+  a.dbg = dbg; a.dbg_buf = dbg_buf; a.mb_override = mb_override;
   a.reverse = (flip_walk && (launch_parity ^= 1)) ? 1 : 0;
   const double flops = 2.0 * 9.0 * L.cin_real * L.cout_real * (double)H * W * (o.epi == EPI_NHWC_SUB2 ? 0.25 : 1.0);
   if (ctx->prof && !section_open) {   // conv section of this forward: first conv launch ... end of the last one, on the caller's stream
@@ -417,7 +419,7 @@ void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_
     if (acts.size() < 2) acts.resize(2);
     if (plan_only) { plan_bytes.assign(2, px * 12 * 4); return; }
     acts[0].ensure(px * 12 * 4); acts[1].ensure(px * 12 * 4);
-    fsrcnn_forward(ctx, fsw, desc.scale, in, out, n, h, w, acts[0].as<float>(), acts[1].as<float>(), st);
+    fsrcnn_forward(ctx, fsw, desc.scale, in, out, n, h, w, acts[0].as<float>(), acts[1].as<float>(), fs_exact, st);
     return;
   }
   lanes_begin(n, h, w, st);

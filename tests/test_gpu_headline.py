@@ -242,14 +242,15 @@ def test_tile_height_builds_bit_identical(ctx, monkeypatch):
     waste, SS4K_MB=4/5 forces one): tiles only partition the pixels, so the network output must not change by a bit -
     including ragged heights where the last tile row of either shape is partly outside the image."""
     t = W.rrdbnet_table(8, scale=2, num_block=2)
-    m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=2), W.flatten(t, W.rrdbnet_keys(2)))
+    def build(mb):   # SS4K_MB is read when the model is built
+        if mb is None:
+            monkeypatch.delenv("SS4K_MB", raising=False)
+        else:
+            monkeypatch.setenv("SS4K_MB", mb)
+        return _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=2), W.flatten(t, W.rrdbnet_keys(2)))
+    m4, m5, ma = build("4"), build("5"), build(None)
     for shape in ((2, 3, 120, 136), (1, 3, 92, 200), (3, 3, 80, 72)):   # body grids 60x68, 46x100, 40x36
         x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[2])).cuda()
-        monkeypatch.setenv("SS4K_MB", "4")
-        a = m(x).clone()
-        monkeypatch.setenv("SS4K_MB", "5")
-        b = m(x).clone()
-        monkeypatch.delenv("SS4K_MB")
-        c = m(x).clone()
+        a, b, c = m4(x).clone(), m5(x).clone(), ma(x).clone()
         assert torch.isfinite(a).all()
         assert torch.equal(a, b) and torch.equal(a, c), f"{shape}: tile height changed the result"

@@ -72,12 +72,11 @@ def test_fsrcnn_split_tail_vs_exact(ctx, monkeypatch, factor):
     LDS ring.  On the real T91 checkpoint values the two agree to a few 1e-6 of the output peak - two orders inside the
     path's tolerance (rtol 1e-3 / atol 1e-4), which both also meet against the oracle."""
     table = _t91(factor)
-    m = factory.build_model_fsrcnn(ctx, factor=factor, weights=table)
     x = torch.rand(3, 1, 150, 333, generator=torch.Generator().manual_seed(4))   # ragged: several wave strips, partial last one
-    monkeypatch.setenv("SS4K_FS_EXACT", "1")
-    exact = m(x.cuda()).cpu()
+    monkeypatch.setenv("SS4K_FS_EXACT", "1")   # read when the model is built
+    exact = factory.build_model_fsrcnn(ctx, factor=factor, weights=table)(x.cuda()).cpu()
     monkeypatch.delenv("SS4K_FS_EXACT")
-    split = m(x.cuda()).cpu()
+    split = factory.build_model_fsrcnn(ctx, factor=factor, weights=table)(x.cuda()).cpu()
     peak = float(exact.abs().max())
     err = float((split - exact).abs().max())
     print(f"fsrcnn x{factor} T91: split-fp16 tail vs exact-fp32 tail max |diff| {err:.3g} = {err / peak:.2e} of the output peak {peak:.3g}")

@@ -1,4 +1,4 @@
-"""Dev tool: A/B of environment switches that the library reads per launch or per model build, on the headline job.
+"""Dev tool: A/B of environment switches that the library reads when a model is built, on the headline job.
 usage: python tools/env_ab.py "SS4K_MB5=0;SS4K_MB5=1" [batch] [rounds]   (variants separated by ';', several VAR=VAL per variant by ',')
 Interleaved rounds in one process; the first variant is the reference of the bit-identity check."""
 import os, sys, time

@@ -1,5 +1,5 @@
 """Dev tool: FSRCNN x2 / x4 on 12 planes of 720p: ms per call with the split-precision fp16 MFMA tail and with the
-exact-fp32 MFMA tail (SS4K_FS_EXACT=1 is read at the first launch of a process: run both ways), and the difference
+exact-fp32 kernels (SS4K_FS_EXACT=1 is read when a model is built: run the tool both ways), and the difference
 between the two on the real T91 checkpoint values."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
