@@ -40,7 +40,7 @@ CONV_KERNEL_NAME = ("3x3 implicit-GEMM conv, all launches of a step: ss4k::conv3
 
 WORKLOADS = {
     "rrdbnet": "RealESRGAN RRDBNet x2 (23 blocks) 720p->1440p fp16 [BASELINE configs[2]]",
-    "fsrcnn": "FSRCNN x2 720p->1440p fp32 [BASELINE configs[1]]",
+    "fsrcnn": "FSRCNN x2 720p->1440p, fp32 tensors; head exact fp32 (vector ALUs), mapping + transposed conv on fp16 MFMA with hi/lo-split operands and fp32 accumulation (fp32-grade: ~1e-6 of the exact kernels) [BASELINE configs[1]]",
     "pipeline": "BSVD denoise + RealESRGAN RRDBNet x2 720p->1440p fp16, per-frame path [BASELINE configs[3]]",
     "srvgg": "SRVGGNetCompact realesr-general-x4v3 x4 + bicubic to 1440p fp16 (the reference's shipped default)",
     "rrdbnet_x4": "RealESRGAN RRDBNet x4 (23 blocks) 1080p->4320x7680->bicubic 2160x3840 fp16 [BASELINE configs[4], per GPU]",
@@ -324,7 +324,7 @@ def main():
             ach = flops_per_frame * fps / world / 1e12
             result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": F32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": ach / F32_VECTOR_PEAK_TFLOPS, "traffic": None,
-                                  "kernel": "fsrcnn kernels, whole-step average (exact-fp32 MFMA and fp32 vector ALUs: both peak at 157.3)"}
+                                  "kernel": "fsrcnn kernels, whole-step average of the algorithmic fp32 FLOPs against the fp32 peak (157.3) that bounds an exact-fp32 implementation; the mapping and tail stages run on fp16 MFMA with hi/lo-split operands (3 MFMAs per product, fp32 accumulate)"}
     if rank == 0 and world == 1 and not args.no_also and args.workload == "rrdbnet":
         # the other single-GPU BASELINE configs and the 1-frame (image-server / latency) job, measured the
         # same way (short, outside the headline timing); conv-based ones carry their own roofline fraction
@@ -353,6 +353,8 @@ def main():
                     also[name]["conv_tflops"] = rl["achieved"]; also[name]["conv_frac_of_peak"] = rl["frac"]
                     also[name]["conv_launches_per_step"] = rl["launches_per_step"]
             else:
+                # algorithmic fp32 FLOPs against the fp32 vector / matrix peak that bounds an exact-fp32 implementation (the
+                # fp16-split stages are not bound by it: context, not a roofline fraction)
                 also[name]["frac_of_fp32_peak"] = also[name]["net_tflops"] / F32_VECTOR_PEAK_TFLOPS
             del out2, fr2
             if name != "rrdbnet_n1":
