@@ -321,9 +321,11 @@ void Model::lanes_begin(int n, int h, int w, hipStream_t st) {
   cur_lanes = 2;
   if (hipEventQuery(t->ev[0][1]) == hipSuccess && hipEventQuery(t->ev[1][1]) == hipSuccess) {
     float ms2 = 0, ms1 = 0;
-    SS4K_HIP(hipEventElapsedTime(&ms2, t->ev[0][0], t->ev[0][1]));
-    SS4K_HIP(hipEventElapsedTime(&ms1, t->ev[1][0], t->ev[1][1]));
-    t->decided = ms2 < 0.99f * ms1 ? 2 : 1;
+    // (a timed forward that threw left its end event unrecorded: no measurement, stay with one chain)
+    const bool ok = hipEventElapsedTime(&ms2, t->ev[0][0], t->ev[0][1]) == hipSuccess &&
+                    hipEventElapsedTime(&ms1, t->ev[1][0], t->ev[1][1]) == hipSuccess && ms1 > 0.f && ms2 > 0.f;
+    if (!ok) (void)hipGetLastError();
+    t->decided = ok && ms2 < 0.99f * ms1 ? 2 : 1;
     t->ms[0] = ms2; t->ms[1] = ms1;
     for (auto& pr : t->ev) for (auto& e : pr) { (void)hipEventDestroy(e); e = nullptr; }
     cur_lanes = t->decided;
