@@ -360,6 +360,28 @@ def main():
             if name != "rrdbnet_n1":
                 del up2, keep2
             torch.cuda.empty_cache()
+        # 1-frame jobs from TWO callers (two upscalers, two streams, jobs alternating): what an image server with two requests
+        # queued gets from this GPU - the overlap the frame lanes give a multi-frame job, done by the caller
+        try:
+            up_b, keep_b, _ = build_upscaler(_capi.Context(local), "rrdbnet", device, lr_shape=in_shape)
+            fr1 = frames[:1]
+            o2h, o2w = up.out_shape(1, *in_shape)
+            outs2 = [torch.empty((1, o2h, o2w, 3), dtype=torch.uint8, device=device) for _ in range(2)]
+            sts = [torch.cuda.Stream(device), torch.cuda.Stream(device)]
+            pair = [up, up_b]
+            def two(reps):
+                for i in range(reps):
+                    with torch.cuda.stream(sts[i % 2]):
+                        pair[i % 2](fr1, outs2[i % 2])
+            torch.cuda.synchronize(); two(6); torch.cuda.synchronize()
+            t1 = time.perf_counter(); two(40); torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            also["rrdbnet_n1_two_callers"] = {"workload": WORKLOADS["rrdbnet"] + ", 1-frame jobs alternating over two upscalers on two streams",
+                                              "frames_per_step": 1, "fps": 40 / dt, "net_tflops": flops_per_frame * 40 / dt / 1e12}
+            del up_b, keep_b, outs2
+            torch.cuda.empty_cache()
+        except Exception as e:  # never lose the headline line to a secondary measurement
+            also["rrdbnet_n1_two_callers"] = {"error": str(e)}
         result["also"] = also
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, psnr = cpu_baseline(args.workload, ctx)
