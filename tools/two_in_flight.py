@@ -12,11 +12,12 @@ def make():
     ctx = _capi.Context(0)
     sr = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2), flat)
     return ctx, sr, _capi.Upscaler(ctx, sr, (720, 1280), None, True, False, None, 1.0)
-frames = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (1, 720, 1280, 3), dtype=np.uint8)).cuda()
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+frames = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (batch, 720, 1280, 3), dtype=np.uint8)).cuda()
 a, b = make(), make()
-outs = [torch.empty((1, 1440, 2560, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+outs = [torch.empty((batch, 1440, 2560, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-for _ in range(3):
+for _ in range(6):
     a[2](frames, outs[0]); b[2](frames, outs[1])
 torch.cuda.synchronize()
 reps = 40
@@ -24,11 +25,11 @@ t0 = time.perf_counter()
 for _ in range(reps):
     a[2](frames, outs[0])
 torch.cuda.synchronize()
-one = reps / (time.perf_counter() - t0)
+one = reps * batch / (time.perf_counter() - t0)
 t0 = time.perf_counter()
 for i in range(reps):
     with torch.cuda.stream(s1 if i % 2 == 0 else s2):
         (a if i % 2 == 0 else b)[2](frames, outs[i % 2])
 torch.cuda.synchronize()
-two = reps / (time.perf_counter() - t0)
-print(f"1-frame jobs, one caller stream: {one:.1f} frames/s; two caller streams (two upscalers): {two:.1f} frames/s ({two / one:.3f}x)")
+two = reps * batch / (time.perf_counter() - t0)
+print(f"{batch}-frame jobs, one caller stream: {one:.1f} frames/s; two caller streams (two upscalers): {two:.1f} frames/s ({two / one:.3f}x)")
