@@ -33,7 +33,8 @@ from sharkshark4k_amd.upscale import model as factory  # noqa: E402
 
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16
 F32_VECTOR_PEAK_TFLOPS = 157.3
-PMC_TRAFFIC_FILE = "r02b_conv3x3_pmc_traffic.json"  # refreshed whenever the conv kernel changes (tools/pmc_traffic.py)
+PMC_TRAFFIC_FILE = "conv3x3_pmc_traffic_current.json"  # written by tools/collect_profiles.sh next to its per-round copy (tools/pmc_traffic.py)
+HBM_SPEC_GBS, HBM_ACHIEVABLE_GBS = 8000.0, 6290.0  # MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured (float4 copy)
 CONV_KERNEL_NAME = ("3x3 implicit-GEMM conv, all launches of a step: ss4k::conv3x3_kernel<__half,NB> (LDS weights, "
                     "v_mfma_f32_32x32x16_f16) + ss4k::rs::conv3x3_rs_kernel<6,16,1,4> (register-stationary weights, "
                     "v_mfma_f32_16x16x32_f16; conv5 of every RDB)")
@@ -100,8 +101,10 @@ def cpu_baseline(workload, gpu_ctx, seconds_budget=14.0):
     from oracle import nets as onets
     from oracle import service as osvc
     from tests.helpers import smooth_u8
-    # many-core hosts oversubscribe small convs badly (256 threads: 285 s for a 96x160 crop); 16 is the sweet spot
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    # many-core hosts oversubscribe small convs badly (256 threads: 285 s for a 96x160 crop): the thread count is the best of
+    # a short sweep on a 180x320 crop (below)
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(min(16, ncores))
     if workload == "fsrcnn":
         table = W.fsrcnn_table(0)
         def make(crop):
@@ -115,11 +118,21 @@ def cpu_baseline(workload, gpu_ctx, seconds_budget=14.0):
             osv = osvc.OracleUpscaler(lambda x: onets.rrdbnet(x, table, 2, 23), upscaler_model="realesrgan", lr_shape=crop)
             sr = _capi.Model(gpu_ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2), flat)
             return osv, _capi.Upscaler(gpu_ctx, sr, crop, None, True, False, None, 1.0), sr
-    probe = (90, 160)
+    probe = (180, 320)
     osv, _, _ = make(probe)
     pf = torch.from_numpy(smooth_u8(7, (1, probe[0], probe[1], 3)))
     osv.upscale(pf)
-    t0 = time.perf_counter(); osv.upscale(pf); t_probe = time.perf_counter() - t0
+    sweep = {}
+    for nt in (16, 32, 64, 128):
+        if nt > ncores and sweep:
+            break
+        torch.set_num_threads(min(nt, ncores))
+        t0 = time.perf_counter(); osv.upscale(pf); sweep[torch.get_num_threads()] = time.perf_counter() - t0
+        if sweep[torch.get_num_threads()] > 4.0 * min(sweep.values()):   # oversubscribed: more threads only get worse
+            break
+    best_nt = min(sweep, key=sweep.get)
+    torch.set_num_threads(best_nt)
+    t_probe = sweep[best_nt]
     crop = probe
     for cand in ((720, 1280), (360, 640), (180, 320)):
         if t_probe * (cand[0] * cand[1]) / (probe[0] * probe[1]) <= seconds_budget:
@@ -135,7 +148,8 @@ def cpu_baseline(workload, gpu_ctx, seconds_budget=14.0):
     ncpu, cpu_model = host_cpu()
     return {"value": frac / sec, "unit": "frames/s (720p-frame equivalents)", "cores": torch.get_num_threads(),
             "host_cpu_count": ncpu, "host_cpu_model": cpu_model, "kind": "port",
-            "sample": f"oracle (PyTorch CPU fp32, {torch.get_num_threads()} threads) on one {crop[0]}x{crop[1]} frame crop "
+            "thread_sweep_s_on_180x320_crop": {str(k): round(v, 3) for k, v in sweep.items()},
+            "sample": f"oracle (PyTorch CPU fp32, {torch.get_num_threads()} threads = the fastest of a {sorted(sweep)} sweep) on one {crop[0]}x{crop[1]} frame crop "
                       f"= {frac:.4f} of a 720p frame: {sec:.2f} s"}, psnr
 
 
@@ -233,6 +247,27 @@ def conv_roofline(ctx, up, frames, out, psteps=3):
             "concurrent_launches": ms / sec_ms, "conv_ms_per_step": sec_ms / psteps}
 
 
+def fsrcnn_stage_rooflines(ctx, up, frames, out, psteps=3):
+    """FSRCNN's three stages timed live (events around each stage on the launch stream), each against the unit that bounds it:
+    the head runs exact fp32 on the vector ALUs (157.3 TFLOP/s); mapping and tail run on the fp16 matrix cores with hi/lo-split
+    operands - three MFMAs per product, so their algorithmic bound is the dense fp16 peak / 3."""
+    ctx.prof_reset(); ctx.prof_enable(True)
+    for _ in range(psteps):
+        up(frames, out)
+    torch.cuda.synchronize()
+    stages = {}
+    for kind, name, peak, unit in ((1, "head (5x5 conv 1->56 + 1x1 56->12, exact fp32, vector ALUs)", F32_VECTOR_PEAK_TFLOPS, "fp32 vector peak"),
+                                   (2, "mapping (4 x conv3x3 12->12, fp16 MFMA, hi/lo split)", MFMA_F16_DENSE_PEAK_TFLOPS / 3, "dense fp16 MFMA peak / 3"),
+                                   (3, "tail (1x1 12->56 + 9x9 transposed conv, fp16 MFMA, hi/lo split)", MFMA_F16_DENSE_PEAK_TFLOPS / 3, "dense fp16 MFMA peak / 3")):
+        n, ms, fl = ctx.prof_read_kind(kind)
+        if n > 0 and ms > 0:
+            ach = fl / (ms * 1e-3) / 1e12
+            stages[name] = {"ms_per_step": ms / psteps, "algorithmic_gflop_per_step": fl / psteps / 1e9, "achieved_tflops": ach,
+                            "peak_tflops": peak, "peak_is": unit, "frac": ach / peak}
+    ctx.prof_enable(False)
+    return stages
+
+
 def host_cpu():
     model = "unknown"
     try:
@@ -310,8 +345,24 @@ def main():
                 fpl = args.batch * 351.0 / rl["launches_per_step"]
                 traffic = pj["traffic_bytes_per_launch"] * fpl / pj["frames_per_launch"]
                 traffic_src = f"profiles/{PMC_TRAFFIC_FILE} (" + pj["correction"] + f"; {pj['frames_per_launch']} frames per launch in the counter passes)"
-            result["roofline"] = {"bound": "mfma", "achieved": rl["achieved"], "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": rl["frac"], "traffic": traffic,
+            mfma = {"achieved": rl["achieved"], "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rl["frac"]}
+            hbm = None
+            if traffic is not None:
+                # the fabric-side bound at the MEASURED bytes (L2 <-> Infinity Cache / HBM; the counters include Infinity-Cache
+                # hits, MI355X_MICROARCH.md HBM section): bytes per step / conv time of a step
+                bytes_step = traffic * rl["launches_per_step"]
+                gbs = bytes_step / (rl["conv_ms_per_step"] * 1e-3) / 1e9
+                hbm = {"achieved": gbs, "peak": HBM_SPEC_GBS, "unit": "GB/s", "frac": gbs / HBM_SPEC_GBS,
+                       "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": gbs / HBM_ACHIEVABLE_GBS,
+                       "bytes_per_step": bytes_step,
+                       "flop_per_byte": rl["algorithmic_gflop_per_launch"] * 1e9 / traffic,
+                       "ridge_flop_per_byte": MFMA_F16_DENSE_PEAK_TFLOPS * 1e12 / (HBM_ACHIEVABLE_GBS * 1e9),
+                       "note": "measured fabric bytes (layer-by-layer dense blocks re-read x 5x, x1 4x, ... per RDB), not SURVEY 8(d)'s "
+                               "algorithmic bytes; FETCH_SIZE counts Infinity-Cache hits, so the HBM share of these bytes is unknown"}
+            binding = "hbm" if hbm is not None and hbm["frac"] > mfma["frac"] else "mfma"
+            top = hbm if binding == "hbm" else mfma
+            result["roofline"] = {"bound": binding, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
+                                  "frac": top["frac"], "mfma": mfma, "hbm": hbm, "traffic": traffic,
                                   "traffic_unit": "bytes per launch (L2<->fabric, PMC)", "traffic_source": traffic_src,
                                   "kernel": CONV_KERNEL_NAME,
                                   "launches_per_step": rl["launches_per_step"],
@@ -356,6 +407,7 @@ def main():
                 # algorithmic fp32 FLOPs against the fp32 vector / matrix peak that bounds an exact-fp32 implementation (the
                 # fp16-split stages are not bound by it: context, not a roofline fraction)
                 also[name]["frac_of_fp32_peak"] = also[name]["net_tflops"] / F32_VECTOR_PEAK_TFLOPS
+                also[name]["stages"] = fsrcnn_stage_rooflines(ctx, up2, fr2, out2)
             del out2, fr2
             if name != "rrdbnet_n1":
                 del up2, keep2

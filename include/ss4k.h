@@ -65,8 +65,29 @@ typedef struct ss4k_model_desc {
   int32_t bsvd_stream; /* 0: every frame of a forward call is independent - how the service drives BSVD
                           (F = 1, fsrcnn_upscaler.py:277); 1: the n frames of one ss4k_model_forward call are ONE
                           stream run through the bidirectional buffers (BSVD.forward, bsvd/model.py:515-580) */
-  int32_t reserved[4];
+  int32_t flags;       /* SS4K_MODEL_* bits below; 0 = defaults.  None of them changes what is computed beyond what its
+                          comment says: they choose between kernels / schedules that the tests hold bit-identical (or, for
+                          FS_EXACT, inside the path's tolerance), and exist so that a caller - and the parity tests - can
+                          pin a route without environment variables */
+  int32_t reserved[3];
 } ss4k_model_desc;
+
+enum {
+  SS4K_MODEL_FS_EXACT = 1,      /* FSRCNN: exact-fp32 kernels for every stage instead of the fp16 hi/lo-split matrix-core
+                                   stages (fp32-grade, ~1e-6 of the exact ones); also chosen automatically when the
+                                   checkpoint's range does not fit the split (see csrc/models.cpp fsrcnn_split_is_safe) */
+  SS4K_MODEL_ONE_CHAIN = 2,     /* an even job never runs as two concurrent launch chains (frame lanes) */
+  SS4K_MODEL_TWO_CHAINS = 4,    /* ... always does (default: measured per shape over the first calls) */
+  SS4K_MODEL_NO_RS = 8,         /* every conv layer on the LDS-weights kernel (conv_mfma.hip); default: conv5 of an RDB on the
+                                   register-stationary kernel (conv_rs.hip).  Changes the order of fp32 additions inside a
+                                   layer (one fp16 rounding per layer either way) */
+  SS4K_MODEL_TILE_ROWS_16 = 16, /* 32-cout body layers on 16-row tiles ... */
+  SS4K_MODEL_TILE_ROWS_20 = 32, /* ... or on 20-row tiles (default: by image height); bit-identical results */
+  SS4K_MODEL_NO_CHAIN = 64,     /* RRDBNet body of 1- and 2-frame jobs as one launch per layer instead of the cross-layer
+                                   chain kernel (csrc/conv_chain.hip); bit-identical results */
+  SS4K_MODEL_CHAIN = 128,       /* ... chain kernel for every fp16 job size that fits it */
+  SS4K_MODEL_FLAGS_ALL = 255
+};
 
 int ss4k_abi_version(void);
 const char* ss4k_last_error(void);
@@ -174,6 +195,9 @@ int ss4k_op_f32nchw_to_u8nhwc(ss4k_ctx* ctx, const float* in_dev, uint8_t* out_d
 int ss4k_prof_enable(ss4k_ctx* ctx, int enable);
 int ss4k_prof_reset(ss4k_ctx* ctx);
 int ss4k_prof_read(ss4k_ctx* ctx, int64_t* launches, double* total_ms, double* flops);
+/* The same per kernel family: kind 0 = the 3x3 conv kernels (what ss4k_prof_read returns), 1 / 2 / 3 = FSRCNN's head (5x5 conv +
+ * shrink), mapping (4 x conv3x3 12->12) and tail (expand + 9x9 transposed conv) stages, each bracketed as one unit. */
+int ss4k_prof_read_kind(ss4k_ctx* ctx, int kind, int64_t* launches, double* total_ms, double* flops);
 /* Conv sections: wall time, on the caller's stream, from the first conv launch of every network forward to the end
  * of its last one (launch boundaries included).  A job's frames may go through the conv layers as two CONCURRENT launch
  * chains (frame lanes): the per-launch times of ss4k_prof_read then overlap, and sum(FLOPs) / section time is the rate

@@ -27,7 +27,7 @@ SYMBOLS = [
     "ss4k_upscaler_reset", "ss4k_upscaler_out_shape", "ss4k_upscaler_last_enqueue_ms", "ss4k_model_workspace_bytes", "ss4k_upscale_frames", "ss4k_upscaler_enable_taps",
     "ss4k_upscaler_read_tap", "ss4k_op_u8nhwc_to_f32nchw", "ss4k_op_area_resize", "ss4k_op_bicubic_resize",
     "ss4k_op_bilinear_resize", "ss4k_op_depthwise_reflect", "ss4k_op_plane_stats", "ss4k_op_f32nchw_to_u8nhwc",
-    "ss4k_prof_enable", "ss4k_prof_reset", "ss4k_prof_read", "ss4k_prof_read_section_ms",
+    "ss4k_prof_enable", "ss4k_prof_reset", "ss4k_prof_read", "ss4k_prof_read_kind", "ss4k_prof_read_section_ms",
 ]
 DEV_SYMBOLS = ["ss4k_bench_conv"]  # include/ss4k_dev.h: libss4k_hip_dev.so only (SS4K_LIB=.../libss4k_hip_dev.so)
 
@@ -36,7 +36,12 @@ class ModelDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("dtype", C.c_int32), ("scale", C.c_int32), ("num_feat", C.c_int32),
                 ("num_block", C.c_int32), ("num_grow_ch", C.c_int32), ("bsvd_chns", C.c_int32 * 3),
                 ("bsvd_mid_ch", C.c_int32), ("bsvd_interm_ch", C.c_int32), ("bsvd_stream", C.c_int32),
-                ("reserved", C.c_int32 * 4)]
+                ("flags", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+# ss4k_model_desc.flags (include/ss4k.h)
+MODEL_FS_EXACT, MODEL_ONE_CHAIN, MODEL_TWO_CHAINS, MODEL_NO_RS, MODEL_TILE_ROWS_16, MODEL_TILE_ROWS_20 = 1, 2, 4, 8, 16, 32
+MODEL_NO_CHAIN, MODEL_CHAIN = 64, 128
 
 
 class UpscaleCfg(C.Structure):
@@ -56,11 +61,16 @@ _lib = None
 def lib() -> C.CDLL:
     """Load the HIP library; fail loudly if it has not been built (no fallback path exists)."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise Ss4kError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
-    L = C.CDLL(LIB_PATH)
+    if _lib is None:
+        _lib = load(LIB_PATH)
+    return _lib
+
+
+def load(path: str) -> C.CDLL:
+    """Bind one build of the library (the product library, or libss4k_hip_dev.so for a test that needs its hooks)."""
+    if not os.path.exists(path):
+        raise Ss4kError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(path)
     vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
     L.ss4k_last_error.restype = C.c_char_p
     L.ss4k_ctx_create.argtypes = [i, C.POINTER(vp)]
@@ -92,8 +102,8 @@ def lib() -> C.CDLL:
     L.ss4k_prof_enable.argtypes = [vp, i]
     L.ss4k_prof_reset.argtypes = [vp]
     L.ss4k_prof_read.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ss4k_prof_read_kind.argtypes = [vp, i, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ss4k_prof_read_section_ms.argtypes = [vp, C.POINTER(C.c_double)]
-    _lib = L
     return L
 
 
@@ -142,6 +152,12 @@ class Context:
     def prof_read(self) -> Tuple[int, float, float]:
         n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
         _check(lib().ss4k_prof_read(self._h, C.byref(n), C.byref(ms), C.byref(fl)))
+        return n.value, ms.value, fl.value
+
+    def prof_read_kind(self, kind: int) -> Tuple[int, float, float]:
+        """(launches, total ms, algorithmic FLOPs) of one kernel family: 0 conv, 1 / 2 / 3 FSRCNN head / mapping / tail."""
+        n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+        _check(lib().ss4k_prof_read_kind(self._h, kind, C.byref(n), C.byref(ms), C.byref(fl)))
         return n.value, ms.value, fl.value
 
     def prof_read_section_ms(self) -> float:
@@ -212,12 +228,13 @@ class Context:
 
 def make_desc(kind: int, dtype: int = F32, scale: int = 2, num_feat: int = 64, num_block: int = 23,
               num_grow_ch: int = 32, bsvd_chns: Sequence[int] = (32, 64, 128), bsvd_mid_ch: int = 32,
-              bsvd_interm_ch: int = 30, bsvd_stream: bool = False) -> ModelDesc:
+              bsvd_interm_ch: int = 30, bsvd_stream: bool = False, flags: int = 0) -> ModelDesc:
     d = ModelDesc()
     d.kind, d.dtype, d.scale, d.num_feat, d.num_block, d.num_grow_ch = kind, dtype, scale, num_feat, num_block, num_grow_ch
     d.bsvd_chns = (C.c_int32 * 3)(*bsvd_chns)
     d.bsvd_mid_ch, d.bsvd_interm_ch = bsvd_mid_ch, bsvd_interm_ch
     d.bsvd_stream = 1 if bsvd_stream else 0
+    d.flags = int(flags)
     return d
 
 

@@ -426,7 +426,9 @@ static void prof_collect(ss4k_ctx* c) {
   for (auto& e : c->prof_events) {
     SS4K_HIP(hipEventSynchronize(e.b));
     float ms = 0; SS4K_HIP(hipEventElapsedTime(&ms, e.a, e.b));
-    c->prof_ms += ms; c->prof_flops += e.flops; c->prof_launches += 1;
+    const int k = e.kind >= 0 && e.kind < PROF_KINDS ? e.kind : 0;
+    c->kind_ms[k] += ms; c->kind_flops[k] += e.flops; c->kind_launches[k] += 1;
+    if (k == PROF_CONV) { c->prof_ms += ms; c->prof_flops += e.flops; c->prof_launches += 1; }
     c->prof_pool.push_back(e);
   }
   c->prof_events.clear();
@@ -440,7 +442,8 @@ static void prof_collect(ss4k_ctx* c) {
 }
 int ss4k_prof_enable(ss4k_ctx* c, int en) { if (!c) return SS4K_EINVAL; c->prof = en != 0; return SS4K_OK; }
 int ss4k_prof_reset(ss4k_ctx* c) {
-  return guard([&] { SS4K_REQUIRE(c, "NULL ctx"); prof_collect(c); c->prof_ms = 0; c->prof_section_ms = 0; c->prof_flops = 0; c->prof_launches = 0; });
+  return guard([&] { SS4K_REQUIRE(c, "NULL ctx"); prof_collect(c); c->prof_ms = 0; c->prof_section_ms = 0; c->prof_flops = 0; c->prof_launches = 0;
+    for (int k = 0; k < PROF_KINDS; ++k) { c->kind_ms[k] = 0; c->kind_flops[k] = 0; c->kind_launches[k] = 0; } });
 }
 int ss4k_prof_read(ss4k_ctx* c, int64_t* launches, double* ms, double* flops) {
   return guard([&] {
@@ -449,6 +452,15 @@ int ss4k_prof_read(ss4k_ctx* c, int64_t* launches, double* ms, double* flops) {
     if (launches) *launches = c->prof_launches;
     if (ms) *ms = c->prof_ms;
     if (flops) *flops = c->prof_flops;
+  });
+}
+int ss4k_prof_read_kind(ss4k_ctx* c, int kind, int64_t* launches, double* ms, double* flops) {
+  return guard([&] {
+    SS4K_REQUIRE(c && kind >= 0 && kind < PROF_KINDS, "ss4k_prof_read_kind: bad argument");
+    prof_collect(c);
+    if (launches) *launches = c->kind_launches[kind];
+    if (ms) *ms = c->kind_ms[kind];
+    if (flops) *flops = c->kind_flops[kind];
   });
 }
 int ss4k_prof_read_section_ms(ss4k_ctx* c, double* section_ms) {

@@ -49,7 +49,8 @@ struct DevBuf {
   template <typename T> T* as() const { return reinterpret_cast<T*>(ptr); }
 };
 
-struct ProfEvent { hipEvent_t a, b; double flops; };
+struct ProfEvent { hipEvent_t a, b; double flops; int kind; };   // kind: PROF_* below
+enum { PROF_CONV = 0, PROF_FS_HEAD = 1, PROF_FS_MAP = 2, PROF_FS_TAIL = 3, PROF_KINDS = 4 };
 
 }  // namespace ss4k
 
@@ -65,6 +66,7 @@ struct ss4k_ctx {
   int64_t prof_launches = 0;
   std::set<const void*> lds_attr_set;  // kernels whose dynamic-LDS limit was raised on this device
   double prof_ms = 0, prof_flops = 0;
+  double kind_ms[ss4k::PROF_KINDS] = {}, kind_flops[ss4k::PROF_KINDS] = {}; int64_t kind_launches[ss4k::PROF_KINDS] = {};
   // frame lanes (models.h): the second launch chain's stream and the fork / join events, shared by every model of the
   // context (models run one after the other on the caller's stream); created on first use
   hipStream_t lane_stream_ = nullptr;
@@ -85,9 +87,22 @@ struct ss4k_ctx {
   double prof_section_ms = 0;
   ss4k::ProfEvent prof_get_events() {
     ss4k::ProfEvent pe{};
-    if (!prof_pool.empty()) { pe = prof_pool.back(); prof_pool.pop_back(); pe.flops = 0; return pe; }
+    if (!prof_pool.empty()) { pe = prof_pool.back(); prof_pool.pop_back(); pe.flops = 0; pe.kind = 0; return pe; }
     if (hipEventCreate(&pe.a) != hipSuccess || hipEventCreate(&pe.b) != hipSuccess) throw ss4k::Error(SS4K_EHIP, "hipEventCreate failed");
     return pe;
+  }
+  // bracket one launch (or one stage) with events on its stream; no-ops unless profiling is enabled
+  ss4k::ProfEvent prof_begin(hipStream_t st, int kind) {
+    ss4k::ProfEvent pe{};
+    if (!prof) return pe;
+    pe = prof_get_events(); pe.kind = kind;
+    if (hipEventRecord(pe.a, st) != hipSuccess) throw ss4k::Error(SS4K_EHIP, "hipEventRecord failed");
+    return pe;
+  }
+  void prof_end(ss4k::ProfEvent pe, hipStream_t st, double flops) {
+    if (!pe.a) return;
+    if (hipEventRecord(pe.b, st) != hipSuccess) throw ss4k::Error(SS4K_EHIP, "hipEventRecord failed");
+    pe.flops = flops; prof_events.push_back(pe);
   }
   const char* zero_page() {
     auto& b = scratch["zero_page"];

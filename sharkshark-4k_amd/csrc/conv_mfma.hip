@@ -849,12 +849,7 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
   SS4K_REQUIRE(a.act != ACT_LRELU || (a.slope >= 0.f && a.slope <= 1.f), "conv3x3: LeakyReLU slope must be in [0,1]");
   SS4K_REQUIRE(!a.ups2 || ((a.H % 2 == 0) && (a.W % 2 == 0)), "conv3x3: ups2 needs even grid");
   SS4K_REQUIRE((double)a.N * a.H * a.W < 2147483648.0, "conv3x3: a plane holds at most 2^31 pixels");
-  ProfEvent pe{};
-  if (ctx->prof) {
-    if (!ctx->prof_pool.empty()) { pe = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); }
-    else { SS4K_HIP(hipEventCreate(&pe.a)); SS4K_HIP(hipEventCreate(&pe.b)); }
-    SS4K_HIP(hipEventRecord(pe.a, st));
-  }
+  const ProfEvent pe = ctx->prof_begin(st, PROF_CONV);
   // fp16 tile shapes <couts/32, rows per wave, waves>; see DESIGN.md 4.1 for how they were chosen
   // fp16 layers of a supported shape with a plain epilogue: register-stationary weights on the 16x16x32 MFMA
   if (a.wrs && dtype == SS4K_F16 && !a.dbg && a.epi == EPI_NHWC && !a.bsvd_resid && a.act != ACT_RELU6) {
@@ -912,11 +907,7 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
     else { if (nb == 1) { SS4K_LAUNCH_EK(float, 1) } else { SS4K_LAUNCH_EK(float, 2) } }
 #undef SS4K_LAUNCH_EK
   }
-  if (ctx->prof) {
-    SS4K_HIP(hipEventRecord(pe.b, st));
-    pe.flops = a0.flops;
-    ctx->prof_events.push_back(pe);
-  }
+  ctx->prof_end(pe, st, a0.flops);
 }
 
 }  // namespace ss4k

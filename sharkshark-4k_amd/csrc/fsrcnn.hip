@@ -289,8 +289,11 @@ typedef __fp16 fp16x2v __attribute__((ext_vector_type(2)));
 struct HiLo { f16x8v hi, lo; };
 // two fp32 values -> packed fp16 hi pair and packed fp16 lo pair
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
-  const float h0 = __uint_as_float(__float_as_uint(x0) & 0xFFFFE000u), h1 = __uint_as_float(__float_as_uint(x1) & 0xFFFFE000u);
-  const fp16x2v ph = __builtin_amdgcn_cvt_pkrtz(h0, h1);                              // exact: 11 significand bits
+  // hi = x rounded toward zero to fp16 (in the normal range: x with 13 mantissa bits cleared, exact); lo is computed from the
+  // value that LANDED in fp16, so an fp16-subnormal hi (|x| < 2^-14) loses nothing either.  |x| >= 65504 does not fit the
+  // split (hi saturates): see Model::build / SS4K_MODEL_FS_EXACT.
+  const fp16x2v ph = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+  const float h0 = (float)ph[0], h1 = (float)ph[1];
   const fp16x2v pl = __builtin_amdgcn_cvt_pkrtz((x0 - h0) * 2048.f, (x1 - h1) * 2048.f);
   hi = __builtin_bit_cast(uint32_t, ph); lo = __builtin_bit_cast(uint32_t, pl);
 }
@@ -643,8 +646,13 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
   // (an fp16-split MFMA head - 16x16x32, the first product's accumulators feeding the 1x1 shrink - was built and measured:
   // 0.56 ms against this kernel's 0.62 per 12 planes of 720p; PReLU + re-splitting the 56-channel map costs ~7 vector
   // instructions per value, as many as the whole exact vector-ALU chain: not kept)
+  // per-stage timing for bench.py's stage rooflines (ss4k_prof_read_kind); algorithmic FLOPs per LR pixel and plane:
+  // head 2 * (25 * 56 + 56 * 12), mapping 2 * 4 * 9 * 12 * 12, tail 2 * (12 * 56 + 81 * 56)  (12 464 MAC in all)
+  ProfEvent pe = ctx->prof_begin(st, PROF_FS_HEAD);
   hipLaunchKernelGGL(k_fs_head, grid, block, 0, st, in, ws12a, W.w_feat, W.b_feat, W.a_feat, W.w_shrink, W.b_shrink,
                      W.a_shrink, planes, h, w);
+  ctx->prof_end(pe, st, 4144.0 * (double)total);
+  pe = ctx->prof_begin(st, PROF_FS_MAP);
   constexpr int FS_MAP_R = 4;
   const dim3 mgrid((unsigned)(((size_t)planes * ((h + FS_MAP_R - 1) / FS_MAP_R) * w + 255) / 256));
   float* cur = ws12a; float* nxt = ws12b;
@@ -665,7 +673,9 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
     hipLaunchKernelGGL(k_fs_maps4, dim3((unsigned)(planes * mbands * mstrips)), block, FM_LDS, st, cur, nxt, mw, planes, h, w, mbands);
     std::swap(cur, nxt);
   }
+  ctx->prof_end(pe, st, 10368.0 * (double)total);
   SS4K_REQUIRE(factor == 2 || factor == 4, "FSRCNN: scale must be 2 or 4");
+  pe = ctx->prof_begin(st, PROF_FS_TAIL);
   const int ci = exact ? FS_CI : 4 * (factor == 2 ? FsTailGeo<2>::CI : FsTailGeo<4>::CI);   // interior LR columns per workgroup
   const int strips = (w + ci - 1) / ci;
   // one round of workgroups at three per CU; every band re-does 4 halo rows
@@ -678,6 +688,7 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
   };
   if (factor == 2) { if (exact) launch_tail(k_fs_tail<2>, 2); else launch_tail(k_fs_tail_r<2>, 2); }
   else { if (exact) launch_tail(k_fs_tail<4>, 4); else launch_tail(k_fs_tail_r<4>, 4); }
+  ctx->prof_end(pe, st, 10416.0 * (double)total);
   SS4K_HIP(hipGetLastError());
 }
 

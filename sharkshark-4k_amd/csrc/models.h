@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include "glue.h"
+#include <tuple>
 
 namespace ss4k {
 
@@ -59,17 +60,26 @@ struct Model {
   float lane_grid_share = 1.f; // grid of a lane's launch as a share of the chip's workgroup slots (measured: 1.0 is best)
   int cur_lanes = 1, cur_n = 0;
   bool forked = false;
-  struct LaneTune { int n, h, w, calls = 0, decided = 0; hipEvent_t ev[2][2] = {}; float ms[2] = {}; };
-  std::vector<LaneTune> lane_tune;
+  struct LaneTune { int calls = 0, decided = 0; hipEvent_t ev[2][2] = {}; float ms[2] = {}; };
+  // per (n, h, w); an image server fed arbitrary sizes must not grow this without bound: past LANE_TUNE_MAX shapes a new
+  // shape runs one chain and is not measured
+  static constexpr size_t LANE_TUNE_MAX = 64;
+  std::map<std::tuple<int, int, int>, LaneTune> lane_tune;
   hipEvent_t tune_timed = nullptr;
   ProfEvent section{}; bool section_open = false;   // bench: wall time of a forward's conv launches
   void lanes_begin(int n, int h, int w, hipStream_t st);
   void lanes_join(hipStream_t st, bool end_of_forward);
+  int fail_at_conv = 0, conv_calls = 0, forward_calls = 0;   // dev library only: fault injection (SS4K_FAIL_AT_CONV)
   int dbg = 0;  // ablation build selector forwarded to the conv kernel (bench only)
   unsigned long long* dbg_buf = nullptr;
 
   void build(const float* w, size_t n);
+  // forward() = forward_impl() inside a guard: if anything throws after the second launch chain was forked, the caller's
+  // stream is made to wait for the lane stream (the next call must not race lane-1 kernels still reading the activation
+  // buffers), and the one-shot requests (out_stats_acc, the open profiling section, the timed tuning call) are dropped
   void forward(const float* in, float* out, int n, int h, int w, hipStream_t st);
+  void forward_impl(const float* in, float* out, int n, int h, int w, hipStream_t st);
+  void abort_forward(hipStream_t st) noexcept;
   void out_shape(int n, int h, int w, int* oc, int* oh, int* ow) const;
   int in_channels() const;
   int rs_mask = 32;        // layer shapes routed to conv_rs.hip (bit per shape, models.cpp rs_shape_bit); default: RDB conv5
@@ -79,7 +89,7 @@ struct Model {
     for (auto& l : layers) { l.w.release(); l.bias.release(); l.prelu.release(); l.wrs.release(); }
     for (auto& a : acts) a.release();
     fs_blob.release();
-    for (auto& t : lane_tune) for (auto& pr : t.ev) for (auto e : pr) if (e) (void)hipEventDestroy(e);
+    for (auto& t : lane_tune) for (auto& pr : t.second.ev) for (auto e : pr) if (e) (void)hipEventDestroy(e);
   }
 
   int add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec spec, bool has_prelu_after, bool allow_rs = false);

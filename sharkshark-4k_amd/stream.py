@@ -44,6 +44,7 @@ class StreamDispatcher:
         self._dropped = set()        # steps skipped at submit time and not yet passed by next_emit
         self.dropped_total = 0
         self.lost_total = 0          # steps that were queued but whose result never came back
+        self.late_total = 0          # results that arrived after their step had been declared lost (discarded)
         self._pending: Dict[int, UpscalerQueueEntry] = {}
         self.max_reorder = max_reorder
         self.lost_after_s = lost_after_s
@@ -98,11 +99,11 @@ class StreamDispatcher:
                 self.next_emit += 1
             elif self._pending:
                 # results are waiting behind a step that has not come back
-                now = time.time()
+                now = time.monotonic()
                 if self._stalled_since is None:
                     self._stalled_since = now
                 if force or now - self._stalled_since > self.lost_after_s:
-                    nxt = min(self._pending)  # lost downstream: do not stall the stream
+                    nxt = min(self._pending)  # lost downstream: do not stall the stream (poll() keeps every pending step >= next_emit)
                     gone = [s for s in range(self.next_emit, nxt) if s not in self._dropped]
                     self.lost_total += len(gone)
                     self._dropped.difference_update(range(self.next_emit, nxt))
@@ -124,32 +125,38 @@ class StreamDispatcher:
 
     def poll(self, timeout: float = 0.0) -> List[UpscalerQueueEntry]:
         """Collect finished jobs from every service and return those that can be emitted in order."""
-        deadline = time.time() + timeout
+        deadline = time.monotonic() + timeout
         while True:
             got_any = False
             for svc in self.services:
                 try:
                     e = svc.result_queue.get_nowait()
-                    self._pending[e.step] = e
                     got_any = True
+                    if e.step < self.next_emit:
+                        # its step was already passed (declared lost after lost_after_s, or skipped): emitting it now would
+                        # put a stale frame behind newer ones and rewind next_emit, so it is counted and dropped
+                        self.late_total += 1
+                        print(f"StreamDispatcher: result of step {e.step} arrived late (stream is at {self.next_emit}), discarded")
+                        continue
+                    self._pending[e.step] = e
                 except queue.Empty:
                     pass
             ready = self._emit_ready(force=len(self._pending) > self.max_reorder)
-            if ready or time.time() >= deadline:
+            if ready or time.monotonic() >= deadline:
                 return ready
             if not got_any:
                 time.sleep(0.001)
 
     def drain(self, expected_steps: Sequence[int], timeout: float = 60.0) -> List[UpscalerQueueEntry]:
         out, want = [], set(expected_steps)
-        deadline = time.time() + timeout
-        while want and time.time() < deadline:
+        deadline = time.monotonic() + timeout
+        while want and time.monotonic() < deadline:
             for e in self.poll(timeout=0.05):
                 out.append(e)
                 want.discard(e.step)
         return out
 
     def report(self) -> dict:
-        return {"frame_step": self.frame_step, "dropped": self.dropped_total, "lost": self.lost_total,
+        return {"frame_step": self.frame_step, "dropped": self.dropped_total, "lost": self.lost_total, "late": self.late_total,
                 "pending": len(self._pending),
                 "upscaler.inputq": [s.job_queue.qsize() for s in self.services]}

@@ -63,7 +63,11 @@ def _load_checkpoint(spec, what: str, default_name: str, checkpoint_dir: Optiona
         spec = path
     if isinstance(spec, (str, os.PathLike)):
         import torch
-        return "ckpt", torch.load(os.fspath(spec), map_location="cpu", weights_only=False)
+        # tensors-only unpickling: the reference's checkpoints (FSRCNN T91, RealESRGAN, BSVD) are plain tensor dicts, and a
+        # .pth found in a directory is not trusted code.  SS4K_UNSAFE_TORCH_LOAD=1 is the explicit opt-in for a legacy file
+        # that pickles other objects (the reference itself loads with torch's old default, fsrcnn/factory.py:12).
+        unsafe = os.environ.get("SS4K_UNSAFE_TORCH_LOAD") == "1"
+        return "ckpt", torch.load(os.fspath(spec), map_location="cpu", weights_only=not unsafe)
     if isinstance(spec, Mapping):
         if any(k in spec for k in ("state_dict", "params_ema", "params")) or any("nets_list." in str(k) for k in spec):
             return "ckpt", spec

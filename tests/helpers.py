@@ -51,3 +51,23 @@ def smooth_u8(seed, shape):
     box = (cs[:, k:, k:] - cs[:, :-k, k:] - cs[:, k:, :-k] + cs[:, :-k, :-k]) / (k * k)
     box = (box - box.min()) / (box.max() - box.min())
     return (box[:, :h, :w] * 255).astype(np.uint8)
+
+
+def record_measured(name, **values):
+    """Parity figures a test measured (PSNR, max LSB, ...) are appended to gpurun_out/parity_measured.json, so that the
+    asserted thresholds can be read next to what was measured (tools/parity_measured.sh copies the file to profiles/)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "gpurun_out", "parity_measured.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                data = json.load(f)
+        data[name] = {k: (float(v) if isinstance(v, (int, float, np.floating, np.integer)) else v) for k, v in values.items()}
+        with open(path, "w") as f:
+            json.dump(data, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

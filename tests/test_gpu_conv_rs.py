@@ -2,7 +2,7 @@
 LDS-weights kernel (csrc/conv_mfma.hip) and the CPU oracle, layer shape by layer shape.
 
 Both kernels read and write the same fp16 "planes" tensors and accumulate in fp32, so their results differ only by
-the order of the fp32 additions (then one fp16 rounding per layer).  ``SS4K_NO_RS=1`` at model build routes every
+the order of the fp32 additions (then one fp16 rounding per layer).  ``SS4K_MODEL_NO_RS`` in the model description routes every
 layer to the LDS-weights kernel (A/B switch of Model::build).
 """
 import os
@@ -21,15 +21,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _build(ctx, desc, flat, no_rs):
-    old = os.environ.get("SS4K_NO_RS")
-    os.environ["SS4K_NO_RS"] = "1" if no_rs else "0"
-    try:
-        return _capi.Model(ctx, desc, flat)
-    finally:
-        if old is None:
-            del os.environ["SS4K_NO_RS"]
-        else:
-            os.environ["SS4K_NO_RS"] = old
+    # SS4K_MODEL_NO_RS (include/ss4k.h): every layer on the LDS-weights kernel
+    desc.flags = (desc.flags | _capi.MODEL_NO_RS) if no_rs else (desc.flags & ~_capi.MODEL_NO_RS)
+    return _capi.Model(ctx, desc, flat)
 
 
 @pytest.mark.parametrize("scale,shape", [(2, (1, 3, 64, 96)), (2, (3, 3, 86, 150)), (4, (2, 3, 37, 70)), (1, (1, 3, 128, 256))])

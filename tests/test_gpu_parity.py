@@ -65,6 +65,25 @@ def test_fsrcnn_golden(ctx, factor, tag):
     assert_close(m(dev(g["x"])), g["y"], what=f"fsrcnn x{factor} {tag}")
 
 
+def test_config0_fsrcnn_x2_t91_256x256_service_vs_oracle(ctx):
+    """BASELINE configs[0]'s workload at its stated size on the HIP path: FSRCNN x2, real T91 weights, ONE 256x256 random
+    frame through ss4k_upscale_frames (per-frame path: the network runs on the three colour planes,
+    fsrcnn_upscaler.py:292-299, model/fsrcnn/model.py:55-62) against the oracle service."""
+    table = _t91(2)
+    sr = factory.build_model_fsrcnn(ctx, factor=2, weights=table)
+    up = _capi.Upscaler(ctx, sr, (256, 256), None, True, True, None, 1.0)
+    frames = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (1, 256, 256, 3), dtype=np.uint8))
+    up.enable_taps(True)
+    got = up(frames.cuda())
+    osv = osvc.OracleUpscaler(lambda x: onets.fsrcnn(x, table, 2), upscaler_model="fsrcnn", lr_shape=(256, 256))
+    taps = {}
+    want = osv.upscale_single(frames[0], taps)[None]
+    assert got.shape == (1, 512, 512, 3)
+    assert_u8_close(got, want, what="configs[0] FSRCNN x2 T91 256x256")
+    assert_close(up.read_tap(1)[0], taps["model"][:, 0], what="configs[0] model tap")     # network output, fp32 tolerance
+    assert_close(up.read_tap(4)[0], taps["final"][:, 0], what="configs[0] final float")
+
+
 @pytest.mark.parametrize("factor", [2, 4])
 def test_fsrcnn_split_tail_vs_exact(ctx, monkeypatch, factor):
     """The production tail computes its two products on the fp16 matrix rate from hi/lo-split operands (three MFMAs per

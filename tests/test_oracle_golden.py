@@ -167,3 +167,31 @@ def test_rrdbnet_functional_oracle_matches_module_form(scale):
     assert a.shape == b.shape == (1, 3, 16 * scale, 24 * scale)
     assert torch.allclose(a, b, rtol=0, atol=1e-6)
 
+
+
+@pytest.mark.parametrize("factor", [2, 4])
+def test_fsrcnn_t91_activation_range(factor):
+    """The HIP path's fp16 hi/lo-split stages need every operand inside the fp16 range (csrc/models.cpp, FSRCNN build).
+    On the real T91 checkpoints every tensor those stages split - the shrink output, the four mapping outputs and the
+    expand output - stays below 10^3 for image-range inputs (measured: 116) (flat black / white, noise, a checkerboard at the pixel
+    pitch), two orders of magnitude inside 65504; the weights are below 11."""
+    import torch.nn.functional as F
+    w = _t91(factor)
+    assert max(float(np.abs(v).max()) for v in w.values()) < 16.0
+    g = torch.Generator().manual_seed(0)
+    yy, xx = torch.meshgrid(torch.arange(64), torch.arange(64), indexing="ij")
+    inputs = [torch.zeros(1, 1, 64, 64), torch.ones(1, 1, 64, 64), torch.rand(1, 1, 64, 64, generator=g),
+              ((yy + xx) % 2).float()[None, None], (torch.rand(1, 1, 64, 64, generator=g) > 0.5).float()]
+    t = lambda k: torch.from_numpy(np.asarray(w[k]))
+    worst = 0.0
+    with torch.no_grad():
+        for x in inputs:
+            y = F.prelu(F.conv2d(x, t("feature_extraction.0.weight"), t("feature_extraction.0.bias"), padding=2), t("feature_extraction.1.weight"))
+            y = F.prelu(F.conv2d(y, t("shrink.0.weight"), t("shrink.0.bias")), t("shrink.1.weight"))
+            worst = max(worst, float(y.abs().max()))
+            for i in range(4):
+                y = F.prelu(F.conv2d(y, t(f"map.{2*i}.weight"), t(f"map.{2*i}.bias"), padding=1), t(f"map.{2*i+1}.weight"))
+                worst = max(worst, float(y.abs().max()))
+            y = F.prelu(F.conv2d(y, t("expand.0.weight"), t("expand.0.bias")), t("expand.1.weight"))
+            worst = max(worst, float(y.abs().max()))
+    assert worst < 1000.0, worst

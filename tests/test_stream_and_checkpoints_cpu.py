@@ -85,6 +85,29 @@ def test_lost_result_does_not_stall_the_stream():
     assert rep["lost"] == 1 and rep["dropped"] == 0 and rep["pending"] == 0 and d.dropped == []
 
 
+def test_late_result_is_discarded_and_order_never_rewinds():
+    """A result that arrives AFTER its step was declared lost (a slow first job while the other service keeps
+    returning) must not be emitted behind newer frames, must not move next_emit backwards, and must not make the
+    following batch stall or be counted as lost again."""
+    svcs = [FakeService(maxsize=8), FakeService(maxsize=8)]
+    emitted = []
+    d = StreamDispatcher(svcs, fps=24, lost_after_s=0.2, on_result=lambda e: emitted.append(e.step))
+    assert d.submit_batch(torch.zeros(16, 2, 2, 3, dtype=torch.uint8)) == [0, 1, 2, 3]
+    slow = svcs[0].job_queue.get()               # step 0 is still being worked on ...
+    svcs[0].work(); svcs[1].work()
+    assert [e.step for e in d.drain([1, 2, 3], timeout=5)] == [1, 2, 3]
+    assert d.next_emit == 4
+    slow.profiler.set("upscaler.upscale", 0.004)
+    svcs[0].result_queue.put(slow)               # ... and comes back after the stream has moved on
+    assert d.poll() == [] and d.next_emit == 4   # discarded, nothing rewinds
+    steps = d.submit_batch(torch.zeros(8, 2, 2, 3, dtype=torch.uint8))
+    svcs[0].work(); svcs[1].work()
+    assert [e.step for e in d.drain(steps, timeout=1)] == [4, 5]   # no second stall
+    assert emitted == [1, 2, 3, 4, 5]
+    rep = d.report()
+    assert rep["lost"] == 1 and rep["late"] == 1 and rep["pending"] == 0
+
+
 def test_dispatcher_with_real_worker_processes():
     svcs = [NearestDouble(), NearestDouble()]
     for s in svcs:

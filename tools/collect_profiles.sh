@@ -21,6 +21,8 @@ export SS4K_LANES=2
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B --steps 2 --warmup 1 --no-roofline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B --steps 2 --warmup 1 --no-roofline > /dev/null 2>&1
 python3 tools/pmc_traffic.py $O/fetch $O/write $O/${TAG}_conv3x3_pmc_traffic.json 2 > /dev/null
+# the name bench.py reads (bench.py PMC_TRAFFIC_FILE): both files are copied into profiles/
+cp $O/${TAG}_conv3x3_pmc_traffic.json $O/conv3x3_pmc_traffic_current.json
 rm -rf $O/fetch $O/write
 # 3. headline: SQ counters (matrix-pipe share, LDS conflicts, wait shares) and L2 hit rate, per kernel
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS \
