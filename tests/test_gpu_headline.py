@@ -51,12 +51,12 @@ def test_rrdbnet_23_blocks_fp32_vs_oracle(ctx, scale, shape):
     assert err / peak < 1e-4
 
 
-def _image_range(table):
+def _image_range(table, gain=0.01):
     """A trained network's output is image-range; the 0.1-scaled Kaiming tables peak near 10.  Same body, conv_last scaled
     and biased so that the output sits in [0,1] - the range north_star's atol = 1e-4 is quoted for."""
     t = dict(table)
-    t["conv_last.weight"] = t["conv_last.weight"] * np.float32(0.01)
-    t["conv_last.bias"] = np.full_like(t["conv_last.bias"], 0.5)
+    t["conv_last.weight"] = table["conv_last.weight"] * np.float32(gain)
+    t["conv_last.bias"] = np.full_like(table["conv_last.bias"], 0.5)
     return t
 
 
@@ -64,11 +64,14 @@ def _image_range(table):
 def test_rrdbnet_23_blocks_fp32_image_range_literal_tolerance(ctx, scale, shape):
     """All 23 blocks, fp32, output in image range: north_star's tolerance taken literally (rtol 1e-3, atol 1e-4)."""
     _cpu_threads()
-    table = _image_range(W.rrdbnet_table(31 + scale, scale=scale))
-    m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F32, scale=scale), W.flatten(table, W.rrdbnet_keys(23)))
+    raw = W.rrdbnet_table(31 + scale, scale=scale)
     x = torch.from_numpy(smooth_u8(3 + scale, (shape[0], shape[2], shape[3], 3))).permute(0, 3, 1, 2).float().div(255.0)
     with torch.no_grad():
+        # conv_last is linear: one oracle pass finds the gain that puts this table's output at 0.5 +- 0.45
+        dev0 = float((onets.rrdbnet(x, _image_range(raw), scale, 23) - 0.5).abs().max())
+        table = _image_range(raw, gain=0.01 * 0.45 / dev0)
         want = onets.rrdbnet(x, table, scale, 23)
+    m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F32, scale=scale), W.flatten(table, W.rrdbnet_keys(23)))
     assert 0.0 < float(want.min()) and float(want.max()) < 1.0, (float(want.min()), float(want.max()))
     got = m(x.cuda())
     assert_close(got, want, rtol=1e-3, atol=1e-4, what=f"rrdbnet x{scale} 23 blocks, image-range output")
@@ -154,7 +157,7 @@ def test_config3_bsvd_rrdbnet_fp32_vs_oracle_small(ctx, rate, out_shape, in_hw):
 
 
 # measured (profiles/r03_parity_measured.json) + 1 LSB / - 2 dB
-C3_PSNR_DB, C3_MAX_LSB = 45.0, 16
+C3_PSNR_DB, C3_MAX_LSB = 55.9, 2   # measured 57.93 dB, 1 LSB (both jobs)
 
 
 def test_config3_bsvd_rrdbnet_720p_fp16_vs_oracle(ctx):
@@ -236,7 +239,7 @@ def test_config4_rrdbnet_x4_23_blocks_fp16_vs_oracle_crop(ctx):
     assert pn >= 50.0, f"network output PSNR {pn:.2f} dB"
 
 
-C4_PSNR_DB, C4_MAX_LSB = 45.0, 8
+C4_PSNR_DB, C4_MAX_LSB = 55.5, 2   # measured 57.55 dB, 1 LSB (profiles/r03_parity_measured.json)
 
 
 # ------------------------------------------------------------------------------ (f) fp16 storage at realistic activation ranges
