@@ -158,6 +158,35 @@ struct ConvArgs {
 };
 enum { DBG_NO_STORE = 1, DBG_NO_MMA = 2, DBG_NO_TILE_DMA = 4, DBG_NO_W_DMA = 8, DBG_NO_EPILOGUE = 16, DBG_STAMP = 32 };  // | tile-shape id << 8 (ss4k_bench_conv)
 
+// ---- cross-layer execution of a chain of plain 32-cout-wide convs as ONE persistent launch (conv_chain.hip) -------------
+// A chain is a list of ITEMS; an item is one conv layer restricted to one 32-cout group (a 64-cout layer = two items), over all
+// tiles.  Work units (item, tile) are handed out in order from a queue; a unit may read what earlier layers wrote on its 3 x 3
+// tile neighbourhood as soon as those units have finished - per-tile counters replace the kernel boundary.
+struct ChainItem {
+  const char* in0; size_t in0_plane_bytes; int in0_plane0, nchunks0;
+  const char* in1; size_t in1_plane_bytes; int in1_plane0, nchunks1;
+  const char* wpk;                      // this group's packed weights (ConvArgs.wpk + group offset)
+  const float* bias;                    // this group's 32 bias values (virtual cout order)
+  int act; float slope, alpha, gamma;   // ACT_NONE / ACT_LRELU only
+  const char* res1; size_t r1_plane_bytes; int r1_plane0;
+  const char* res2; size_t r2_plane_bytes; int r2_plane0;
+  char* out; size_t out_plane_bytes; int out_plane0;   // out_plane0: first plane of this GROUP
+  int newest;                           // first K-chunk whose plane the previous layer wrote (0: all of them)
+  unsigned need_old, need_new;          // units that must have finished on every tile of the 3 x 3 neighbourhood before chunk 0 /
+                                        // before chunk `newest` is read (and before anything is written)
+  int pad_[3];
+};
+struct ChainArgs {
+  const ChainItem* items; int nitems;
+  unsigned* ctl;                        // [0] queue head, [1] error word, [4 ...] per-tile counters of finished units; zeroed per launch
+  const char* zero_page;
+  int N, n0, H, W, tiles_x, tiles_y;
+};
+// every unit of the chain: fp16, plain epilogue, cout group of 32.  rows_per_wave 4 or 5 (16- / 20-row tiles).
+void launch_conv_chain(ss4k_ctx* ctx, const ChainArgs& a, int rows_per_wave, hipStream_t st);
+size_t conv_chain_ctl_bytes(int ntiles);
+int conv_chain_tiles(int N, int H, int W, int rows_per_wave, int* tiles_x, int* tiles_y);
+
 // launchers (conv_mfma.hip)
 void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a, int dtype, hipStream_t st);
 int conv_cw(int dtype);  // channels per plane / K-chunk: 16
@@ -173,6 +202,7 @@ struct PackSpec {
   std::vector<int> cin_map;        // [nchunks * CW] logical cin of every channel slot the conv reads, -1 = none
   int nchunks0, nchunks1;          // how the chunks split over the two input segments
   int ps2;                         // virtual cout order [sub][c'] for PixelShuffle(2)
+  int force_nb1 = 0;               // pack a 64-cout layer as two 32-cout groups (conv_chain.hip runs every layer on the 32-cout tile body)
 };
 struct PackedConv {
   std::vector<uint8_t> w;          // device-order bytes

@@ -103,7 +103,7 @@ static void upload(DevBuf& b, const void* src, size_t bytes) {
 // bit of a layer shape in Model::rs_mask: 0-2 = 32 couts with 2/3/4 K-chunks (RDB conv1-3), 3 = conv4, 4 = 64->64, 5 = conv5
 static int rs_shape_bit(int nch, int cout_pad) { return cout_pad == 32 ? nch - 2 : (nch == 2 ? 4 : 5); }
 
-int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool has_prelu_after, bool allow_rs) {
+int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool has_prelu_after, bool allow_rs, bool chainable) {
   s.dtype = desc.dtype; s.cout_real = cout; s.cin_total = cin_total;
   const float* w = pc.take((size_t)cout * cin_total * 9);
   const float* b = pc.take(cout);
@@ -120,6 +120,12 @@ int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool h
     upload(L.wrs, wr.data(), wr.size());
     weight_bytes += wr.size();
     L.rs_wide = rs_wide;
+  }
+  if (chainable && chain_mode != 1 && desc.dtype == SS4K_F16 && p.nb == 2) {
+    PackSpec s1 = s; s1.force_nb1 = 1;
+    const PackedConv p1 = pack_conv3x3(s1, w, b, a);
+    upload(L.wch, p1.w.data(), p1.w.size());
+    weight_bytes += p1.w.size();
   }
   L.has_prelu = a != nullptr;
   L.cout_real = cout; L.cout_pad = p.cout_pad; L.nchunks0 = s.nchunks0; L.nchunks1 = s.nchunks1;
@@ -183,6 +189,9 @@ void Model::build(const float* w, size_t n) {
   if (fl & SS4K_MODEL_NO_RS) use_rs = false;
   if (fl & SS4K_MODEL_TILE_ROWS_16) mb_override = 4;
   if (fl & SS4K_MODEL_TILE_ROWS_20) mb_override = 5;
+  SS4K_REQUIRE(!((fl & SS4K_MODEL_NO_CHAIN) && (fl & SS4K_MODEL_CHAIN)), "desc.flags: NO_CHAIN and CHAIN exclude each other");
+  if (fl & SS4K_MODEL_NO_CHAIN) chain_mode = 1;
+  if (fl & SS4K_MODEL_CHAIN) chain_mode = 2;
   if (!(fl & (SS4K_MODEL_ONE_CHAIN | SS4K_MODEL_TWO_CHAINS)))
     if (const char* e = std::getenv("SS4K_LANES")) lanes_mode = std::max(0, std::min(2, std::atoi(e)));
   if (const char* e = std::getenv("SS4K_FS_EXACT")) fs_exact = fs_exact || e[0] == '1';
@@ -251,7 +260,7 @@ void Model::build(const float* w, size_t n) {
       for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 5; ++c) {
           const int co = c < 4 ? g : nf;
-          add_conv(pc, co, nf + c * g, c == 0 ? spec_plain(nf) : spec_concat(nf, c * g), false, /*allow_rs=*/true);
+          add_conv(pc, co, nf + c * g, c == 0 ? spec_plain(nf) : spec_concat(nf, c * g), false, /*allow_rs=*/true, /*chainable=*/true);
         }
     for (int i = 0; i < 4; ++i) add_conv(pc, nf, nf, spec_plain(nf), false, /*allow_rs=*/true);
     add_conv(pc, 3, nf, spec_plain(nf), false);
@@ -302,6 +311,11 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
     SS4K_HIP(hipEventRecord(section.a, st));
     section_open = true;
   }
+  if (chain_rec) {
+    a.flops = flops * N;
+    chain_record(a, L);
+    return;
+  }
   if (cur_lanes <= 1 || N != cur_n) {
     a.flops = flops * N;
     launch_conv3x3(ctx, a, desc.dtype, st);
@@ -319,6 +333,85 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
     a.flops = flops * a.N;
     launch_conv3x3(ctx, a, desc.dtype, l == 0 ? st : ctx->lane_stream());
   }
+}
+
+// ---- cross-layer chain (conv_chain.hip) ---------------------------------------------------------------------------------
+void Model::chain_record(const ConvArgs& a, const ConvLayer& L) {
+  SS4K_REQUIRE(desc.dtype == SS4K_F16 && a.epi == EPI_NHWC && !a.bsvd_resid && !a.ups2 && !a.prelu &&
+               (a.act == ACT_NONE || a.act == ACT_LRELU) && (a.cout_pad == 32 || a.cout_pad == 64),
+               "internal: layer cannot run in a conv chain");
+  SS4K_REQUIRE(a.cout_pad == 32 || L.wch.ptr, "internal: 64-cout chain layer without its two-group weights");
+  const int nch = a.nchunks0 + a.nchunks1, groups = a.cout_pad / 32;
+  SS4K_REQUIRE(nch >= 2, "internal: chain layer with fewer than two K-chunks");
+  const char* wbase = a.cout_pad == 32 ? reinterpret_cast<const char*>(a.wpk) : L.wch.as<char>();
+  ChainLayerRec rec{(int)chain_items.size(), groups, a.out + (size_t)a.out_plane0 * a.out_plane_bytes,
+                    a.out + (size_t)(a.out_plane0 + a.cout_pad / 16) * a.out_plane_bytes, a.flops};
+  // K-chunks whose planes the PREVIOUS chain layer wrote: they must form the tail of the K loop (the dense block's newest
+  // growth planes do); anything else is polled for in front of the first chunk
+  int newest = 0;
+  if (!chain_layers.empty()) {
+    const ChainLayerRec& pv = chain_layers.back();
+    auto is_new = [&](int c) {
+      const char* pl = c < a.nchunks0 ? a.in0 + (size_t)(a.in0_plane0 + c) * a.in0_plane_bytes
+                                      : a.in1 + (size_t)(a.in1_plane0 + c - a.nchunks0) * a.in1_plane_bytes;
+      return pl >= pv.out_lo && pl < pv.out_hi;
+    };
+    int first = nch;
+    for (int c = nch - 1; c >= 0 && is_new(c); --c) first = c;
+    bool suffix_only = true;
+    for (int c = 0; c < first; ++c) suffix_only = suffix_only && !is_new(c);
+    newest = (suffix_only && first >= 2 && first < nch) ? first : 0;
+  }
+  const int kl = (int)chain_layers.size();
+  const unsigned cum_k = (unsigned)chain_items.size();                                  // units per tile of layers < k
+  const unsigned cum_km1 = kl >= 1 ? (unsigned)chain_layers[kl - 1].first_item : 0u;    // ... of layers < k - 1
+  for (int g = 0; g < groups; ++g) {
+    ChainItem it{};
+    it.in0 = a.in0; it.in0_plane_bytes = a.in0_plane_bytes; it.in0_plane0 = a.in0_plane0; it.nchunks0 = a.nchunks0;
+    it.in1 = a.in1; it.in1_plane_bytes = a.in1_plane_bytes; it.in1_plane0 = a.in1_plane0; it.nchunks1 = a.nchunks1;
+    it.wpk = wbase + (size_t)g * nch * 9 * 64 * 16;
+    it.bias = a.bias + 32 * g;
+    it.act = a.act; it.slope = a.slope; it.alpha = a.alpha; it.gamma = a.gamma;
+    it.res1 = a.res1; it.r1_plane_bytes = a.r1_plane_bytes; it.r1_plane0 = a.r1_plane0 + 2 * g;
+    it.res2 = a.res2; it.r2_plane_bytes = a.r2_plane_bytes; it.r2_plane0 = a.r2_plane0 + 2 * g;
+    it.out = a.out; it.out_plane_bytes = a.out_plane_bytes; it.out_plane0 = a.out_plane0 + 2 * g;
+    it.newest = newest; it.need_old = cum_km1; it.need_new = cum_k;
+    chain_items.push_back(it);
+  }
+  chain_layers.push_back(rec);
+}
+
+void Model::chain_run(int N, int H, int W, hipStream_t st) {
+  chain_rec = false;
+  if (chain_items.empty()) return;
+  if (!chain_err_host) {
+    SS4K_HIP(hipHostMalloc(reinterpret_cast<void**>(&chain_err_host), 64, hipHostMallocDefault));
+    *chain_err_host = 0;
+  }
+  // a unit of an earlier chain launch gave up waiting (a co-running kernel starved it for seconds, or a defect): its results
+  // were void.  The copy of the error word is asynchronous, so this reports the failure on the next call.
+  if (*chain_err_host) { *chain_err_host = 0; throw Error(SS4K_EHIP, "conv chain: a work unit timed out waiting for its neighbours (previous forward's output is invalid)"); }
+  const size_t bytes = chain_items.size() * sizeof(ChainItem);
+  if (chain_uploaded.size() != chain_items.size() || std::memcmp(chain_uploaded.data(), chain_items.data(), bytes) != 0) {
+    chain_tab.ensure(bytes);
+    chain_uploaded = chain_items;   // the source of the asynchronous copy stays alive in the model
+    SS4K_HIP(hipMemcpyAsync(chain_tab.ptr, chain_uploaded.data(), bytes, hipMemcpyHostToDevice, st));
+  }
+  const auto waste = [&](int th) { return (double)((H + th - 1) / th * th) / H; };
+  const int mb = mb_override ? mb_override : (waste(20) < waste(16) - 1e-9 ? 5 : 4);
+  ChainArgs ca{};
+  ca.items = chain_tab.as<ChainItem>(); ca.nitems = (int)chain_items.size();
+  ca.N = N; ca.n0 = 0; ca.H = H; ca.W = W;
+  const int ntiles = conv_chain_tiles(N, H, W, mb, &ca.tiles_x, &ca.tiles_y);
+  chain_ctl.ensure(conv_chain_ctl_bytes(ntiles));
+  ca.ctl = chain_ctl.as<unsigned>();
+  ca.zero_page = ctx->zero_page();
+  double flops = 0;
+  for (const auto& l : chain_layers) flops += l.flops;
+  const ProfEvent pe = ctx->prof_begin(st, PROF_CONV);
+  launch_conv_chain(ctx, ca, mb, st);
+  ctx->prof_end(pe, st, flops);
+  SS4K_HIP(hipMemcpyAsync(chain_err_host, ca.ctl + 1, 4, hipMemcpyDeviceToHost, st));
 }
 
 // Called at the top of a conv network's forward: one launch chain or two?  Both give bit-identical tensors.
@@ -437,6 +530,7 @@ void Model::abort_forward(hipStream_t st) noexcept {
   }
   if (section_open) { ctx->prof_pool.push_back(section); section_open = false; }
   tune_timed = nullptr; cur_lanes = 1;
+  chain_rec = false;
   out_stats_acc = nullptr; out_stats_done = false;
 }
 
@@ -496,6 +590,15 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
     int li = 0;
     { ConvOpts o; o.out = F; conv(li++, P, nullptr, n, H, W, o, st); }
     Tens cur = F;
+    // the body of small fp16 jobs as ONE persistent launch with per-tile hand-offs between the layers (conv_chain.hip):
+    // 1-frame jobs by default (nothing else can overlap their 345 launch boundaries); SS4K_MODEL_CHAIN / _NO_CHAIN force it
+    // (default: jobs of at most 1.5 tiles per workgroup slot and layer - one 720p frame is 460 / 512; bigger jobs keep their slots
+    // busy across a boundary, and an even job has its frame lanes)
+    const long long tiles16 = (long long)n * ((H + 15) / 16) * ((W + 31) / 32);
+    const bool use_chain = !plan_only && f16 && !dbg && chain_mode != 1 && (chain_mode == 2 || 2 * tiles16 <= 3LL * 2 * ctx->num_cu) && nf == 64 && g == 32;
+    if (use_chain) {
+      chain_rec = true; chain_items.clear(); chain_layers.clear();
+    }
     for (int b = 0; b < desc.num_block; ++b) {
       const Tens a = cur;
       const Tens t1 = X[0], t2 = X[1];
@@ -512,6 +615,11 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
         conv(li++, rin[rr], &G, n, H, W, o, st);
       }
       cur = dst;
+    }
+    if (use_chain) {
+      lanes_join(st, false);   // (a forced chain on an even batch: conv_first may have run as two launch chains)
+      cur_lanes = 1;
+      chain_run(n, H, W, st);
     }
     { ConvOpts o; o.res1 = &F; o.out = X[0]; conv(li++, cur, nullptr, n, H, W, o, st); }  // feat + conv_body(body)
     Tens U1 = act(6, px * 4, nf), U2 = act(7, px * 16, nf), U3 = act(8, px * 16, nf);

@@ -11,6 +11,7 @@ struct Tens { char* p; size_t plane_bytes; int plane0; };
 
 struct ConvLayer {
   DevBuf w, bias, prelu;
+  DevBuf wch;              // 64-cout fp16 body layers: the weights once more as two 32-cout groups (conv_chain.hip)
   DevBuf wrs;              // conv_rs.hip weight order (fp16 layers of a supported shape, else empty)
   bool rs_wide = false;    // ... packed for the eight-wave variant
   bool has_prelu = false;
@@ -69,6 +70,18 @@ struct Model {
   ProfEvent section{}; bool section_open = false;   // bench: wall time of a forward's conv launches
   void lanes_begin(int n, int h, int w, hipStream_t st);
   void lanes_join(hipStream_t st, bool end_of_forward);
+  // cross-layer chain (conv_chain.hip): the RRDB body of small fp16 jobs as ONE persistent launch.  While chain_rec is set,
+  // conv() records work items instead of launching; chain_run() resolves the dependencies and launches the chain.
+  int chain_mode = 0;          // 0: 1-frame jobs, 1: never (SS4K_MODEL_NO_CHAIN), 2: every fp16 job (SS4K_MODEL_CHAIN)
+  bool chain_rec = false;
+  struct ChainLayerRec { int first_item, nitems; const char* out_lo; const char* out_hi; double flops; };
+  std::vector<ChainItem> chain_items;
+  std::vector<ChainLayerRec> chain_layers;
+  std::vector<ChainItem> chain_uploaded;
+  DevBuf chain_tab, chain_ctl;
+  unsigned* chain_err_host = nullptr;   // pinned copy of the chain's error word, refreshed after every chain launch
+  void chain_record(const ConvArgs& a, const ConvLayer& L);
+  void chain_run(int N, int H, int W, hipStream_t st);
   int fail_at_conv = 0, conv_calls = 0, forward_calls = 0;   // dev library only: fault injection (SS4K_FAIL_AT_CONV)
   int dbg = 0;  // ablation build selector forwarded to the conv kernel (bench only)
   unsigned long long* dbg_buf = nullptr;
@@ -86,13 +99,15 @@ struct Model {
   bool rs_wide = false;    // eight-wave variants of the 32-cout RS shapes (SS4K_RS_W8=1: A/B switch)
   bool use_rs = true;      // route eligible fp16 layers to the register-stationary kernel (SS4K_NO_RS=1: A/B switch)
   ~Model() {
-    for (auto& l : layers) { l.w.release(); l.bias.release(); l.prelu.release(); l.wrs.release(); }
+    for (auto& l : layers) { l.w.release(); l.bias.release(); l.prelu.release(); l.wrs.release(); l.wch.release(); }
+    chain_tab.release(); chain_ctl.release();
+    if (chain_err_host) (void)hipHostFree(chain_err_host);
     for (auto& a : acts) a.release();
     fs_blob.release();
     for (auto& t : lane_tune) for (auto& pr : t.second.ev) for (auto e : pr) if (e) (void)hipEventDestroy(e);
   }
 
-  int add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec spec, bool has_prelu_after, bool allow_rs = false);
+  int add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec spec, bool has_prelu_after, bool allow_rs = false, bool chainable = false);
   PackSpec spec_plain(int cin_real, int ps2 = 0) const;
   PackSpec spec_concat(int c0, int c1) const;
   PackSpec spec_masked(int c) const;

@@ -53,9 +53,10 @@ PackedConv pack_conv3x3(const PackSpec& s, const float* w, const float* bias, co
   const int nchunks = s.nchunks0 + s.nchunks1;
   SS4K_REQUIRE((int)s.cin_map.size() == nchunks * CW, "pack_conv3x3: cin_map size");
   PackedConv p;
-  p.nb = s.cout_real <= 32 ? 1 : 2;
+  p.nb = (s.cout_real <= 32 || s.force_nb1) ? 1 : 2;
   const int gw = p.nb * 32;
-  p.cout_pad = (s.cout_real + gw - 1) / gw * gw;
+  const int padw = s.cout_real <= 32 ? 32 : 64;   // the tensor's planes come in 32- / 64-cout blocks whatever the group width
+  p.cout_pad = (s.cout_real + padw - 1) / padw * padw;
   p.groups = p.cout_pad / gw;
   const size_t esz = s.dtype == SS4K_F16 ? 2 : 4;
   const size_t nelem = (size_t)p.groups * nchunks * 9 * KS * p.nb * 64 * E;

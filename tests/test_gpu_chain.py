@@ -1,0 +1,95 @@
+"""GPU: the cross-layer chain kernel (csrc/conv_chain.hip) - the RRDB body of a small job as ONE persistent launch with
+per-tile hand-offs between the layers - against the one-launch-per-layer path.
+
+The chain runs every layer on the LDS-weights kernel's 32-cout tile body, so its results must be BIT-IDENTICAL to the
+per-launch path with SS4K_MODEL_NO_RS (same MFMA order per output, same epilogue arithmetic); against the default
+per-launch route (conv5 on the register-stationary kernel) only the order of fp32 additions inside a layer differs.
+Every hand-off is exercised on reused buffers (the growth planes are rewritten every RDB, the trunk buffers rotate), so a
+stale read or a too-early write anywhere in the 345-layer chain changes the output."""
+import numpy as np
+import pytest
+import torch
+
+import sharkshark4k_amd  # noqa: F401
+from sharkshark4k_amd import _capi
+from sharkshark4k_amd import weights as W
+from oracle import nets as onets
+from tests.helpers import psnr, smooth_u8
+
+pytestmark = pytest.mark.gpu
+
+NO_CHAIN, CHAIN, NO_RS = _capi.MODEL_NO_CHAIN, _capi.MODEL_CHAIN, _capi.MODEL_NO_RS
+
+
+def _model(ctx, flat, scale, nb, flags):
+    return _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=nb, flags=flags), flat)
+
+
+@pytest.mark.parametrize("scale,shape,rows", [(2, (1, 3, 144, 208), 0), (2, (2, 3, 92, 200), 16), (2, (3, 3, 80, 72), 20),
+                                              (4, (1, 3, 37, 70), 0), (1, (1, 3, 128, 256), 0), (2, (1, 3, 360, 500), 0)])
+def test_chain_bit_identical_to_launches(ctx, scale, shape, rows):
+    """Forced chain (any batch) vs one launch per layer on the same tile body; ragged sizes put partly filled tiles on every
+    edge, several frames put several frames' tiles into one queue, both tile heights are covered."""
+    tab = W.rrdbnet_table(71 + scale, scale=scale, num_block=3)
+    flat = W.flatten(tab, W.rrdbnet_keys(3))
+    tr = {0: 0, 16: _capi.MODEL_TILE_ROWS_16, 20: _capi.MODEL_TILE_ROWS_20}[rows]
+    ref = _model(ctx, flat, scale, 3, NO_CHAIN | NO_RS | tr)
+    ch = _model(ctx, flat, scale, 3, CHAIN | tr)
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[2])).cuda()
+    want = ref(x).clone()
+    assert torch.isfinite(want).all()
+    for _ in range(3):
+        got = ch(x)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), f"{shape}: chain differs from the per-launch path, max |d| {float((got - want).abs().max()):.3g}"
+
+
+def test_chain_is_the_default_for_one_small_frame_and_matches_oracle(ctx):
+    """A 1-frame job takes the chain without being asked to; its output equals the forced chain's and the NO_RS launch path's,
+    and stays as close to the oracle as the default multi-frame route."""
+    tab = W.rrdbnet_table(9, scale=2, num_block=4)
+    flat = W.flatten(tab, W.rrdbnet_keys(4))
+    x = torch.from_numpy(smooth_u8(2, (2, 96, 160, 3))).permute(0, 3, 1, 2).float().div(255.0).cuda()
+    dflt, forced, ref = _model(ctx, flat, 2, 4, 0), _model(ctx, flat, 2, 4, CHAIN), _model(ctx, flat, 2, 4, NO_CHAIN | NO_RS)
+    a, b, c = dflt(x[:1]).clone(), forced(x[:1]).clone(), ref(x[:1]).clone()
+    assert torch.equal(a, b) and torch.equal(a, c)
+    with torch.no_grad():
+        want = onets.rrdbnet(x.cpu(), tab, 2, 4)
+    two = dflt(x)   # 2-frame job: default route (frame lanes, conv5 on the register-stationary kernel)
+    peak = float(want.abs().max())
+    p1, p2 = psnr(a.cpu(), want[:1], peak=peak), psnr(two.cpu(), want, peak=peak)
+    assert p1 > 55.0 and p2 > 55.0 and abs(p1 - p2) < 1.5, (p1, p2)
+
+
+def test_chain_720p_23_blocks_repeatable(ctx):
+    """The headline network on one 720p frame: 12 runs of the chain give 12 identical tensors, equal to the per-launch path."""
+    flat = W.flatten(W.rrdbnet_table(0, scale=2), W.rrdbnet_keys(23))
+    ch, ref = _model(ctx, flat, 2, 23, 0), _model(ctx, flat, 2, 23, NO_CHAIN | NO_RS)
+    x = torch.from_numpy(smooth_u8(123, (1, 720, 1280, 3))).permute(0, 3, 1, 2).float().div(255.0).cuda()
+    want = ref(x).clone()
+    for i in range(12):
+        got = ch(x)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), f"run {i}: chain output changed"
+
+
+def test_chain_two_contexts_on_two_streams_do_not_deadlock(ctx):
+    """Two chains in flight at once (two contexts, two streams - the two-callers case): units come from a queue, so neither
+    launch needs all of its workgroups resident; both finish and both are right."""
+    flat = W.flatten(W.rrdbnet_table(3, scale=2, num_block=6), W.rrdbnet_keys(6))
+    ctx2 = _capi.Context(0)
+    m1, m2 = _model(ctx, flat, 2, 6, CHAIN), _model(ctx2, flat, 2, 6, CHAIN)
+    ref = _model(ctx, flat, 2, 6, NO_CHAIN | NO_RS)
+    x = torch.rand(1, 3, 720, 1280, generator=torch.Generator().manual_seed(8)).cuda()
+    want = ref(x).clone()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for i in range(6):
+        with torch.cuda.stream(s1 if i % 2 == 0 else s2):
+            outs.append((m1 if i % 2 == 0 else m2)(x))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, want)
+    del m2
+    ctx2.close()
