@@ -174,13 +174,18 @@ struct ChainItem {
   int newest;                           // first K-chunk whose plane the previous layer wrote (0: all of them)
   unsigned need_old, need_new;          // units that must have finished on every tile of the 3 x 3 neighbourhood before chunk 0 /
                                         // before chunk `newest` is read (and before anything is written)
-  int pad_[3];
+  unsigned pub_need;                    // > 0: this unit's counter add waits until its OWN tile's counter has reached pub_need (the
+                                        // second cout group of a layer publishes after the first, so that "layer's first unit
+                                        // done" can be read off the counter)
+  int pad_[2];
 };
 struct ChainArgs {
   const ChainItem* items; int nitems;
   unsigned* ctl;                        // [0] queue head, [1] error word, [4 ...] per-tile counters of finished units; zeroed per launch
   const char* zero_page;
   int N, n0, H, W, tiles_x, tiles_y;
+  int grid;                             // > 0: workgroups to launch (default: one per workgroup slot)
+  int abl;                              // dev library: timing-only ablation build (conv_chain.hip)
 };
 // every unit of the chain: fp16, plain epilogue, cout group of 32.  rows_per_wave 4 or 5 (16- / 20-row tiles).
 void launch_conv_chain(ss4k_ctx* ctx, const ChainArgs& a, int rows_per_wave, hipStream_t st);

@@ -36,7 +36,7 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int NW = 4;
-constexpr unsigned SPIN_LIMIT = 1u << 22;   // polls (x ~0.1 us) before a unit gives up: the kernel always drains
+constexpr unsigned SPIN_LIMIT = 1u << 21;   // polls (~1 us each) before a unit gives up: the kernel always drains
 
 template <int MB> constexpr size_t lds_bytes_chain() {
   return (size_t)(2 * Geo<__half, MB, NW>::TILE_SLOTS + 2 * 9 * 64) * 16 + 2 * 64 * 4 + 16;
@@ -58,16 +58,51 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const char* p) {
 }
 constexpr int AUX_SC1 = 16;
 
-__device__ __forceinline__ void store8_sc1(__amdgpu_buffer_rsrc_t r, uint32_t voff, const float* v) {
+// A unit's parameters, copied ONCE per unit from the item table into registers (scalar loads from the constant address space:
+// the table is not written during the launch).  Reading an item field where it is used would put a load and its wait - which
+// also drains the LDS-DMA prefetch and the previous unit's stores - into the chunk loop (measured: -10 % on the whole chain).
+typedef const __attribute__((address_space(4))) ChainItem* CItem;
+struct UnitP {
+  const char* in0; size_t in0_pb; int nch0;     // first plane of segment 0, bytes per plane, chunks in segment 0
+  const char* in1; size_t in1_pb; int nch;      // first plane of segment 1; total chunks
+  const char* wpk; const float* bias;
+  float slope, alpha, gamma;                    // slope 1 = no activation
+  const char* res1; size_t r1_pb; const char* res2; size_t r2_pb;   // first plane of this group's residual planes or null
+  char* out; size_t out_pb;
+  int newest; unsigned need0, need_new;         // need0: what the first chunk waits for
+  unsigned pub_need;
+};
+__device__ __forceinline__ UnitP load_unit(const ChainItem* items, int item) {
+  CItem it = (CItem)(items + item);
+  UnitP u;
+  u.in0_pb = it->in0_plane_bytes; u.in0 = it->in0 + (size_t)it->in0_plane0 * u.in0_pb; u.nch0 = it->nchunks0;
+  u.in1_pb = it->in1_plane_bytes; u.in1 = it->in1 ? it->in1 + (size_t)it->in1_plane0 * u.in1_pb : nullptr; u.nch = it->nchunks0 + it->nchunks1;
+  u.wpk = it->wpk; u.bias = it->bias;
+  u.slope = it->act == ACT_LRELU ? it->slope : 1.f; u.alpha = it->alpha; u.gamma = it->gamma;
+  u.r1_pb = it->r1_plane_bytes; u.res1 = it->res1 ? it->res1 + (size_t)it->r1_plane0 * u.r1_pb : nullptr;
+  u.r2_pb = it->r2_plane_bytes; u.res2 = it->res2 ? it->res2 + (size_t)it->r2_plane0 * u.r2_pb : nullptr;
+  u.out_pb = it->out_plane_bytes; u.out = it->out + (size_t)it->out_plane0 * u.out_pb;
+  u.newest = it->newest; u.need_new = it->need_new; u.need0 = it->newest == 0 ? it->need_new : it->need_old;
+  u.pub_need = it->pub_need;
+  return u;
+}
+
+template <int AUX>
+__device__ __forceinline__ void store8_aux(__amdgpu_buffer_rsrc_t r, uint32_t voff, const float* v) {
   uint4 a;
   __half* ha = reinterpret_cast<__half*>(&a);
 #pragma unroll
   for (int i = 0; i < 8; ++i) ha[i] = __float2half(v[i]);
-  __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<u32x4v*>(&a), r, voff, 0, AUX_SC1);
+  __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<u32x4v*>(&a), r, voff, 0, AUX);
 }
 
-template <int MB>
-__global__ __launch_bounds__(64 * NW, 2) void conv3x3_chain_kernel(const ChainArgs ca) {
+// ABL: timing-only ablations of the dev library (results are void): 1 = plain LDS-DMA for the activations, 2 = non-temporal
+// instead of write-through stores, 4 = no dependency polls at all
+template <int MB> constexpr int chain_wgs_per_cu() { return lds_bytes_chain<MB>() * 3 <= 160 * 1024 ? 3 : 2; }
+
+template <int MB, int ABL>
+__global__ __launch_bounds__(64 * NW, chain_wgs_per_cu<MB>()) void conv3x3_chain_kernel(const ChainArgs ca) {
+  auto store8_sc1 = [](__amdgpu_buffer_rsrc_t r, uint32_t voff, const float* v) { if (ABL & 2) store8_aux<2>(r, voff, v); else store8_aux<AUX_SC1>(r, voff, v); };
   using T = __half;
   using G = Geo<T, MB, NW>;
   constexpr int SPR = G::SPR, REC = G::REC, NG = 3;
@@ -126,18 +161,27 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_chain_kernel(const ChainAr
     return (ty >= 0 && ty < ca.tiles_y && tx >= 0 && tx < ca.tiles_x) ? f * tiles_per_frame + ty * ca.tiles_x + tx : -1;
   };
   auto satisfied = [&](unsigned v, int nbi, unsigned need) -> bool { return __all(nbi < 0 || (int)(v - need) >= 0) != 0; };
+  unsigned st_block = 0, st_spin0 = 0, st_spin1 = 0;   // ABL & 8 (dev): blocking starts, polls spent waiting at a unit's start / inside
+  bool st_mid = false;
   auto poll_block = [&](int nbi, unsigned need) {   // one wave; returns when the neighbourhood has reached `need`
+    if (ABL & 4) return;
     unsigned spins = 0;
+    const unsigned long long t0 = (ABL & 8) ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz
     while (true) {
       unsigned v = need;
       if (nbi >= 0) v = __hip_atomic_load(flags + nbi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (satisfied(v, nbi, need)) break;
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > SPIN_LIMIT) {   // give up: results of this forward are void, the host sees the error word
+      ++spins;
+      // give up after SPIN_LIMIT polls - or as soon as any unit has (the error word is sticky: once a unit timed out the results
+      // of this forward are void and every wait ends, so the launch drains in milliseconds); the host sees the error word
+      const bool dead = (spins & 1023u) == 0 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      if (spins > SPIN_LIMIT || dead) {
         if (lane == 0) __hip_atomic_fetch_or(errw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
     }
+    if (ABL & 8) { const unsigned dt = (unsigned)(__builtin_amdgcn_s_memrealtime() - t0); if (st_mid) st_spin1 += dt; else st_spin0 += dt; }
   };
 
   constexpr int NDMA_T = DMA_PER_WAVE, NDMA_W = (9 + NW - 1) / NW, NDMA = NDMA_T + NDMA_W;
@@ -145,11 +189,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_chain_kernel(const ChainAr
   static_assert((3 * MB) % SE == 0 && NDMA <= NG * 3 * MB / SE, "not enough DMA slots in the MFMA stream");
   const char* pf_plane = nullptr; const char* pf_wsrc = nullptr;
   uint32_t pf_tdst = 0, pf_wdst = 0; bool pf_on = false;
-  auto prefetch_begin = [&](const ChainItem* it, int c, int buf) {
-    pf_plane = (c < it->nchunks0) ? it->in0 + (size_t)(it->in0_plane0 + c) * it->in0_plane_bytes
-                                  : it->in1 + (size_t)(it->in1_plane0 + c - it->nchunks0) * it->in1_plane_bytes;
+  auto prefetch_begin = [&](const UnitP& u, int c, int buf) {
+    pf_plane = (c < u.nch0) ? u.in0 + (size_t)c * u.in0_pb : u.in1 + (size_t)(c - u.nch0) * u.in1_pb;
     pf_tdst = lds0 + buf * TILE_BYTES;
-    pf_wsrc = it->wpk + (size_t)c * W_BYTES + lane * 16;
+    pf_wsrc = u.wpk + (size_t)c * W_BYTES + lane * 16;
     pf_wdst = lds0 + 2 * TILE_BYTES + buf * W_BYTES;
     pf_on = true;
   };
@@ -161,21 +204,33 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_chain_kernel(const ChainAr
         const size_t boff = (size_t)src_off[idx] * REC + (size_t)((plan[idx] >> 16) & 0xff);
         const char* src = src_off[idx] != OOB ? pf_plane + boff : ca.zero_page + (lane & 3) * 16;
         const uint32_t dst = __builtin_amdgcn_readfirstlane(pf_tdst + k * 1024);
-        if (plan[idx] >= 0) dma16_sc1(src, dst);   // activations: written by other workgroups of this launch
+        if (plan[idx] >= 0) { if (ABL & 1) dma16(src, dst); else dma16_sc1(src, dst); }   // activations: written by other workgroups of this launch
       }
     } else if (idx < NDMA) {
       const int k = wave + NW * (idx - NDMA_T);
       if (k < 9) dma16(pf_wsrc + k * 1024, __builtin_amdgcn_readfirstlane(pf_wdst + k * 1024));   // weights: never written here
     }
   };
-  auto write_epi = [&](int par, const ChainItem* it) {
+  auto write_epi = [&](int par, const UnitP& u) {
     if (tid < 32) {
-      epi_lds[par * 64 + tid] = it->bias[tid];
-      epi_lds[par * 64 + 32 + tid] = it->act == ACT_LRELU ? it->slope : 1.f;
+      epi_lds[par * 64 + tid] = u.bias[tid];
+      epi_lds[par * 64 + 32 + tid] = u.slope;
     }
   };
-  auto publish = [&](int tile) {   // after every wave's vmcnt(0) and a workgroup barrier
-    if (tid == 0) __hip_atomic_fetch_add(flags + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // The counter add of a finished unit: after every wave's vmcnt(0) (its write-through stores have left) and a workgroup
+  // barrier.  (Measured and dropped: every wave publishing for itself right after its epilogue - the explicit store drain cost
+  // 4 % and the neighbours did not wait any less.)
+  auto publish = [&](int tile, unsigned pub_need) {
+    if (tid == 0) {
+      if (pub_need && !(ABL & 4)) {   // (an earlier unit of the same layer on this tile: it never waits for this one)
+        unsigned spins = 0;
+        while ((int)(__hip_atomic_load(flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - pub_need) < 0) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > SPIN_LIMIT) { __hip_atomic_fetch_or(errw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+      }
+      __hip_atomic_fetch_add(flags + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   };
 
   // ---- first ticket
@@ -184,40 +239,45 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_chain_kernel(const ChainAr
   unsigned q = __builtin_amdgcn_readfirstlane(ctl[0]);
   if (q >= nwork) return;
   int item = (int)(q / (unsigned)ntiles), tile = (int)(q - (unsigned)item * (unsigned)ntiles);
-  const ChainItem* it = ca.items + item;
+  UnitP up = load_unit(ca.items, item);
   int n, y0, x0;
   setup_tile(tile, n, y0, x0);
   int par = 0;
-  write_epi(par, it);
+  write_epi(par, up);
   bool have0 = false;   // this unit's first chunk is already in LDS (prefetched during the previous unit's last chunk)
   int pend = -1;        // tile whose counter add is pending (its stores may still be in flight)
+  unsigned pend_need = 0;
   int buf = 0;
 
   struct Frags { uint4 wf[3]; uint4 af[MB + 2]; };
 
   while (true) {
-    const int nchunks = it->nchunks0 + it->nchunks1;
+    const UnitP cur = up;
+    const int nchunks = cur.nch;
     if (!have0) {
       // blocking start of a unit: publish what is pending (never block while holding back a finished tile), wait for the
       // unit's first dependency, bring the first chunk in
       if (pend >= 0) {
         dma_wait();
         __syncthreads();
-        publish(pend);
+        publish(pend, pend_need);
         pend = -1;
       }
-      if (wave == 0) poll_block(nb_index(tile), it->newest == 0 ? it->need_new : it->need_old);
+      if (ABL & 8) ++st_block;
+      st_mid = false;
+      if (wave == 0) poll_block(nb_index(tile), cur.need0);
       __syncthreads();
       buf = 0;
-      prefetch_begin(it, 0, 0);
+      prefetch_begin(cur, 0, 0);
 #pragma unroll
       for (int i = 0; i < NDMA; ++i) dma_op(i);
       dma_wait();
       __syncthreads();
     }
-    // the workgroup's next ticket: fetched now, needed two chunks before the end of this unit
+    // the workgroup's next ticket is taken as LATE as possible - three chunks before the end of this unit, one chunk before it
+    // is needed: a ticket held while this unit computes (or waits) is a unit nobody else may start, and units that run out of
+    // order eat the margin between a unit and the ones it waits for
     unsigned tk = 0;
-    if (tid == 0) tk = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     f32x16 acc[MB];
     {
@@ -233,10 +293,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_chain_kernel(const ChainAr
         for (int i = 0; i < 16; ++i) acc[mb][i] = bias_v[i];
     }
     const int cur_n = n, cur_y0 = y0, cur_x0 = x0, cur_tile = tile;
-    const ChainItem* const cur = it;
     const int xo = cur_x0 + lr;
     unsigned q_next = nwork; bool next_ready = false;
-    const ChainItem* it_next = it; int item_next = 0, tile_next = 0;
+    int tile_next = 0;
 
     for (int c = 0; c < nchunks; ++c) {
       pf_on = false;
@@ -244,23 +303,24 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_chain_kernel(const ChainAr
         prefetch_begin(cur, c + 1, buf ^ 1);
       } else if (next_ready) {
         setup_tile(tile_next, n, y0, x0);
-        prefetch_begin(it_next, 0, buf ^ 1);
+        prefetch_begin(up, 0, buf ^ 1);   // `up` already holds the next unit's parameters
       }
       // polls that must be resolved by the barrier at the end of this chunk (wave 0): the flag loads are issued here, two
       // chunks ahead of the DMA they guard, and evaluated after this chunk's MFMAs
-      const bool due_new = c + 2 == cur->newest, due_next = c + 2 == nchunks;
+      if (c + 3 == nchunks && tid == 0) tk = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool due_new = c + 2 == cur.newest, due_next = c + 2 == nchunks;
       unsigned fv = 0, need = 0; int nbi = -1; unsigned qn = nwork;
       if (wave == 0 && (due_new || due_next)) {
         if (due_next) {
           qn = __builtin_amdgcn_readfirstlane(tk);
           if (qn < nwork) {
             const int itn = (int)(qn / (unsigned)ntiles), tn = (int)(qn - (unsigned)itn * (unsigned)ntiles);
-            const ChainItem* nx = ca.items + itn;
+            CItem nx = (CItem)(ca.items + itn);
             need = nx->newest == 0 ? nx->need_new : nx->need_old;
             nbi = nb_index(tn);
           }
         } else {
-          need = cur->need_new; nbi = nb_index(cur_tile);
+          need = cur.need_new; nbi = nb_index(cur_tile);
         }
         if (nbi >= 0) fv = __hip_atomic_load(flags + nbi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -307,24 +367,34 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_chain_kernel(const ChainAr
       }
       if (c + 1 < nchunks) {
         dma_wait();       // next chunk has landed; this wave's stores of the previous unit have drained
+        if (c == 0 && pend >= 0) {
+          // the previous unit's counter add, as early as its stores allow - and BEFORE this unit may block below (a blocked
+          // workgroup never holds back a finished tile: its neighbours may be waiting for exactly that tile)
+          __syncthreads();
+          publish(pend, pend_need);
+          pend = -1;
+        }
         if (wave == 0 && (due_new || due_next)) {
-          const bool ok = satisfied(fv, nbi, need);
+          const bool ok = (ABL & 4) ? true : satisfied(fv, nbi, need);
           if (due_new) {
+            st_mid = true;
             if (!ok) poll_block(nbi, need);   // the previous layer is not through on the neighbourhood yet: wait here
           } else if (lane == 0) {
             ctl[0] = qn; ctl[1] = (qn < nwork && ok) ? 1u : 0u;
           }
         }
         __syncthreads();  // every wave is done reading this buffer (and has passed its vmcnt(0))
-        if (c == 0 && pend >= 0) { publish(pend); pend = -1; }
         buf ^= 1;
         if (due_next) {
           q_next = __builtin_amdgcn_readfirstlane(ctl[0]);
           next_ready = __builtin_amdgcn_readfirstlane(ctl[1]) != 0;
           if (q_next < nwork) {
-            item_next = (int)(q_next / (unsigned)ntiles); tile_next = (int)(q_next - (unsigned)item_next * (unsigned)ntiles);
-            it_next = ca.items + item_next;
-            write_epi(par ^ 1, it_next);
+            // the next unit's parameters come into registers here: nothing is in flight behind this barrier, so the waits
+            // of these loads cost nothing (and `cur` keeps this unit's copy)
+            const int item_next = (int)(q_next / (unsigned)ntiles);
+            tile_next = (int)(q_next - (unsigned)item_next * (unsigned)ntiles);
+            up = load_unit(ca.items, item_next);
+            write_epi(par ^ 1, up);
           }
         }
       }
@@ -341,7 +411,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_chain_kernel(const ChainAr
       constexpr int HB = 16;
       int lhe = lh;
       asm volatile("" : "+v"(lhe));
-      const float alpha = cur->alpha, gamma = cur->gamma;
+      const float alpha = cur.alpha, gamma = cur.gamma;
       float slope_v[16];
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
@@ -352,9 +422,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_chain_kernel(const ChainAr
       const size_t wrec0 = (((size_t)cur_n * ca.H + cur_y0 + wave * MB) * ca.W + cur_x0) * REC;
       const uint32_t voff0 = (uint32_t)lr * REC + (uint32_t)lhe * HB;
       const uint32_t row_b = (uint32_t)ca.W * REC;
-      char* outb = cur->out + (size_t)cur->out_plane0 * cur->out_plane_bytes + wrec0;
-      const __amdgpu_buffer_rsrc_t ro0 = rsrc_of(outb), ro1 = rsrc_of(outb + cur->out_plane_bytes);
-      const bool has1 = cur->res1 != nullptr, has2 = cur->res2 != nullptr;
+      char* outb = cur.out + wrec0;
+      const __amdgpu_buffer_rsrc_t ro0 = rsrc_of(outb), ro1 = rsrc_of(outb + cur.out_pb);
+      const bool has1 = cur.res1 != nullptr, has2 = cur.res2 != nullptr;
       if (!has1 && !has2) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
@@ -371,10 +441,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_chain_kernel(const ChainAr
           }
         }
       } else {
-        const char* r1b = has1 ? cur->res1 + (size_t)cur->r1_plane0 * cur->r1_plane_bytes + wrec0 : outb;
-        const char* r2b = has2 ? cur->res2 + (size_t)cur->r2_plane0 * cur->r2_plane_bytes + wrec0 : outb;
-        const __amdgpu_buffer_rsrc_t r10 = rsrc_of(r1b), r11 = rsrc_of(r1b + (has1 ? cur->r1_plane_bytes : 0));
-        const __amdgpu_buffer_rsrc_t r20 = rsrc_of(r2b), r21 = rsrc_of(r2b + (has2 ? cur->r2_plane_bytes : 0));
+        const char* r1b = has1 ? cur.res1 + wrec0 : outb;
+        const char* r2b = has2 ? cur.res2 + wrec0 : outb;
+        const __amdgpu_buffer_rsrc_t r10 = rsrc_of(r1b), r11 = rsrc_of(r1b + (has1 ? cur.r1_pb : 0));
+        const __amdgpu_buffer_rsrc_t r20 = rsrc_of(r2b), r21 = rsrc_of(r2b + (has2 ? cur.r2_pb : 0));
         constexpr int RB = 2;
 #pragma unroll
         for (int mb0 = 0; mb0 < MB; mb0 += RB) {
@@ -422,37 +492,47 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_chain_kernel(const ChainAr
         }
       }
     }
-    pend = cur_tile;
+    pend = cur_tile; pend_need = cur.pub_need;
 
     if (q_next >= nwork) break;
-    q = q_next; item = item_next; tile = tile_next; it = it_next; par ^= 1;
+    q = q_next; tile = tile_next; par ^= 1;
     have0 = next_ready;
     if (!have0) setup_tile(tile, n, y0, x0);
   }
   // the last unit of this workgroup
   dma_wait();
   __syncthreads();
-  publish(pend);
+  publish(pend, pend_need);
+  if ((ABL & 8) && tid == 0) {
+    __hip_atomic_fetch_add(head + 2, st_block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(head + 3, st_spin0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(flags + ntiles, st_spin1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
-template <int MB>
+template <int MB, int ABL = 0>
 static void launch_t(ss4k_ctx* ctx, const ChainArgs& a, hipStream_t st) {
   constexpr size_t lds = lds_bytes_chain<MB>();
-  static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-  const void* fn = reinterpret_cast<const void*>(&conv3x3_chain_kernel<MB>);
+  constexpr int per_cu = chain_wgs_per_cu<MB>();
+  static_assert(per_cu * lds <= 160 * 1024, "workgroups per CU");
+  const void* fn = reinterpret_cast<const void*>(&conv3x3_chain_kernel<MB, ABL>);
   if (ctx->lds_attr_set.insert(fn).second)
     SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
-  // units are queued, so any grid works; one workgroup per slot (two per CU), never more workgroups than a layer has tiles x 2
-  const int gx = std::max(1, std::min(2 * ctx->num_cu, 2 * ntiles));
+  // Units are queued, so any grid is CORRECT.  The fastest grid keeps fewer units in flight than lie between a unit and the
+  // nearest unit it waits for, (L, t) -> (L - 1, t + tiles_x + 1), i.e. ntiles - tiles_x - 1 tickets: with more workgroups every
+  // unit starts before its predecessor layer has reached it and the chain of waits becomes the critical path (measured on one
+  // 720p frame, 460 tiles, 512 slots: 438-460 workgroups 94-97 fps, 480: 88-91, 512: 80-90)
+  int gx = std::max(1, std::min(per_cu * ctx->num_cu, ntiles - a.tiles_x - 1));
+  if (a.grid > 0) gx = a.grid;
   SS4K_HIP(hipMemsetAsync(a.ctl, 0, conv_chain_ctl_bytes(ntiles), st));
-  hipLaunchKernelGGL((conv3x3_chain_kernel<MB>), dim3(gx), dim3(64 * NW), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_chain_kernel<MB, ABL>), dim3(gx), dim3(64 * NW), lds, st, a);
   SS4K_HIP(hipGetLastError());
 }
 
 }  // namespace chain
 
-size_t conv_chain_ctl_bytes(int ntiles) { return ((size_t)(4 + ntiles) * 4 + 15) & ~size_t(15); }
+size_t conv_chain_ctl_bytes(int ntiles) { return ((size_t)(4 + ntiles + 1) * 4 + 15) & ~size_t(15); }   // + one statistics word (dev)
 
 int conv_chain_tiles(int N, int H, int W, int rows_per_wave, int* tiles_x, int* tiles_y) {
   const int th = 4 * rows_per_wave;
@@ -464,7 +544,32 @@ void launch_conv_chain(ss4k_ctx* ctx, const ChainArgs& a, int rows_per_wave, hip
   SS4K_REQUIRE(a.items && a.nitems > 0 && a.ctl && a.N > 0 && a.H > 0 && a.W > 0, "conv chain: empty");
   SS4K_REQUIRE((double)a.N * a.H * a.W < 2147483648.0 && (double)a.W * 32.0 * 24.0 < 2147483648.0, "conv chain: a plane holds at most 2^31 pixels");
   SS4K_REQUIRE((double)a.nitems * a.N * a.tiles_x * a.tiles_y < 4.0e9, "conv chain: too many work units");
+#ifdef SS4K_DEV
+  if (a.abl && rows_per_wave == 3) {
+    switch (a.abl) {
+      case 4: chain::launch_t<3, 4>(ctx, a, st); break;
+      case 8: chain::launch_t<3, 8>(ctx, a, st); break;
+      default: throw Error(SS4K_EINVAL, "chain ablation on 12-row tiles: 4 or 8");
+    }
+    return;
+  }
+  if (a.abl) {
+    SS4K_REQUIRE(rows_per_wave == 4, "chain ablations are built for 16- and 12-row tiles");
+    switch (a.abl) {
+      case 1: chain::launch_t<4, 1>(ctx, a, st); break;
+      case 2: chain::launch_t<4, 2>(ctx, a, st); break;
+      case 3: chain::launch_t<4, 3>(ctx, a, st); break;
+      case 4: chain::launch_t<4, 4>(ctx, a, st); break;
+      case 7: chain::launch_t<4, 7>(ctx, a, st); break;
+      case 8: chain::launch_t<4, 8>(ctx, a, st); break;
+      default: throw Error(SS4K_EINVAL, "chain ablation: 1, 2, 3, 4, 7 or 8 (statistics)");
+    }
+    return;
+  }
+#endif
+  SS4K_REQUIRE(a.abl == 0, "chain ablations live in libss4k_hip_dev.so only");
   if (rows_per_wave == 5) chain::launch_t<5>(ctx, a, st);
+  else if (rows_per_wave == 3) chain::launch_t<3>(ctx, a, st);
   else chain::launch_t<4>(ctx, a, st);
 }
 

@@ -316,6 +316,11 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
     chain_record(a, L);
     return;
   }
+#ifdef SS4K_DEV
+  // experiment: a 64-cout body layer as two 32-cout groups on the per-launch path (what the chain does to conv5)
+  static const bool split64 = std::getenv("SS4K_SPLIT64") && std::getenv("SS4K_SPLIT64")[0] == '1';
+  if (split64 && L.wch.ptr && a.cout_pad == 64 && a.epi == EPI_NHWC) { a.wpk = L.wch.ptr; a.wrs = nullptr; a.cout_pad = -64; }
+#endif
   if (cur_lanes <= 1 || N != cur_n) {
     a.flops = flops * N;
     launch_conv3x3(ctx, a, desc.dtype, st);
@@ -342,29 +347,37 @@ void Model::chain_record(const ConvArgs& a, const ConvLayer& L) {
                "internal: layer cannot run in a conv chain");
   SS4K_REQUIRE(a.cout_pad == 32 || L.wch.ptr, "internal: 64-cout chain layer without its two-group weights");
   const int nch = a.nchunks0 + a.nchunks1, groups = a.cout_pad / 32;
-  SS4K_REQUIRE(nch >= 2, "internal: chain layer with fewer than two K-chunks");
+  SS4K_REQUIRE(nch >= 3, "internal: chain layer with fewer than three K-chunks");
   const char* wbase = a.cout_pad == 32 ? reinterpret_cast<const char*>(a.wpk) : L.wch.as<char>();
   ChainLayerRec rec{(int)chain_items.size(), groups, a.out + (size_t)a.out_plane0 * a.out_plane_bytes,
                     a.out + (size_t)(a.out_plane0 + a.cout_pad / 16) * a.out_plane_bytes, a.flops};
   // K-chunks whose planes the PREVIOUS chain layer wrote: they must form the tail of the K loop (the dense block's newest
   // growth planes do); anything else is polled for in front of the first chunk
-  int newest = 0;
-  if (!chain_layers.empty()) {
+  const int kl = (int)chain_layers.size();
+  const unsigned cum_k = (unsigned)chain_items.size();                                  // units per tile of layers < k
+  const unsigned cum_km1 = kl >= 1 ? (unsigned)chain_layers[kl - 1].first_item : 0u;    // ... of layers < k - 1
+  int newest = 0; unsigned need_old = cum_km1, need_new = cum_k;
+  if (kl >= 1) {
     const ChainLayerRec& pv = chain_layers.back();
-    auto is_new = [&](int c) {
-      const char* pl = c < a.nchunks0 ? a.in0 + (size_t)(a.in0_plane0 + c) * a.in0_plane_bytes
-                                      : a.in1 + (size_t)(a.in1_plane0 + c - a.nchunks0) * a.in1_plane_bytes;
-      return pl >= pv.out_lo && pl < pv.out_hi;
+    auto plane_of = [&](int c) {
+      return c < a.nchunks0 ? a.in0 + (size_t)(a.in0_plane0 + c) * a.in0_plane_bytes
+                            : a.in1 + (size_t)(a.in1_plane0 + c - a.nchunks0) * a.in1_plane_bytes;
     };
+    auto is_new = [&](int c) { const char* pl = plane_of(c); return pl >= pv.out_lo && pl < pv.out_hi; };
     int first = nch;
     for (int c = nch - 1; c >= 0 && is_new(c); --c) first = c;
     bool suffix_only = true;
     for (int c = 0; c < first; ++c) suffix_only = suffix_only && !is_new(c);
     newest = (suffix_only && first >= 2 && first < nch) ? first : 0;
+    // conv1 of an RDB: EVERY chunk is the previous layer's (conv5's) output, which came from two units per tile - planes 0-1
+    // from the first cout group, planes 2-3 from the second, published in that order (pub_need).  Chunks 0-1 then only wait
+    // for the first group's units (one unit short of the whole previous layer), chunks 2-3 for the second's: the unit starts
+    // without blocking and the wait for the second group hides under the first two chunks
+    if (pv.nitems == 2 && nch == 4 && a.nchunks1 == 0 && is_new(0) && plane_of(0) == pv.out_lo &&
+        plane_of(2) == pv.out_lo + 2 * a.in0_plane_bytes) {
+      newest = 2; need_old = cum_k - 1; need_new = cum_k;
+    }
   }
-  const int kl = (int)chain_layers.size();
-  const unsigned cum_k = (unsigned)chain_items.size();                                  // units per tile of layers < k
-  const unsigned cum_km1 = kl >= 1 ? (unsigned)chain_layers[kl - 1].first_item : 0u;    // ... of layers < k - 1
   for (int g = 0; g < groups; ++g) {
     ChainItem it{};
     it.in0 = a.in0; it.in0_plane_bytes = a.in0_plane_bytes; it.in0_plane0 = a.in0_plane0; it.nchunks0 = a.nchunks0;
@@ -375,7 +388,8 @@ void Model::chain_record(const ConvArgs& a, const ConvLayer& L) {
     it.res1 = a.res1; it.r1_plane_bytes = a.r1_plane_bytes; it.r1_plane0 = a.r1_plane0 + 2 * g;
     it.res2 = a.res2; it.r2_plane_bytes = a.r2_plane_bytes; it.r2_plane0 = a.r2_plane0 + 2 * g;
     it.out = a.out; it.out_plane_bytes = a.out_plane_bytes; it.out_plane0 = a.out_plane0 + 2 * g;
-    it.newest = newest; it.need_old = cum_km1; it.need_new = cum_k;
+    it.newest = newest; it.need_old = need_old; it.need_new = need_new;
+    it.pub_need = g > 0 ? cum_k + (unsigned)g : 0u;   // group g publishes after groups < g of this layer on the same tile
     chain_items.push_back(it);
   }
   chain_layers.push_back(rec);
@@ -398,7 +412,10 @@ void Model::chain_run(int N, int H, int W, hipStream_t st) {
     SS4K_HIP(hipMemcpyAsync(chain_tab.ptr, chain_uploaded.data(), bytes, hipMemcpyHostToDevice, st));
   }
   const auto waste = [&](int th) { return (double)((H + th - 1) / th * th) / H; };
-  const int mb = mb_override ? mb_override : (waste(20) < waste(16) - 1e-9 ? 5 : 4);
+  int mb = mb_override ? mb_override : (waste(20) < waste(16) - 1e-9 ? 5 : 4);
+#ifdef SS4K_DEV
+  if (const char* e = std::getenv("SS4K_CHAIN_MB")) mb = std::atoi(e);
+#endif
   ChainArgs ca{};
   ca.items = chain_tab.as<ChainItem>(); ca.nitems = (int)chain_items.size();
   ca.N = N; ca.n0 = 0; ca.H = H; ca.W = W;
@@ -406,12 +423,25 @@ void Model::chain_run(int N, int H, int W, hipStream_t st) {
   chain_ctl.ensure(conv_chain_ctl_bytes(ntiles));
   ca.ctl = chain_ctl.as<unsigned>();
   ca.zero_page = ctx->zero_page();
+#ifdef SS4K_DEV
+  if (const char* e = std::getenv("SS4K_CHAIN_GRID")) ca.grid = std::atoi(e);
+  if (const char* e = std::getenv("SS4K_CHAIN_ABL")) ca.abl = std::atoi(e);
+#endif
   double flops = 0;
   for (const auto& l : chain_layers) flops += l.flops;
   const ProfEvent pe = ctx->prof_begin(st, PROF_CONV);
   launch_conv_chain(ctx, ca, mb, st);
   ctx->prof_end(pe, st, flops);
   SS4K_HIP(hipMemcpyAsync(chain_err_host, ca.ctl + 1, 4, hipMemcpyDeviceToHost, st));
+#ifdef SS4K_DEV
+  if (ca.abl == 8) {   // statistics build: how often units started blocked, how long they polled
+    SS4K_HIP(hipStreamSynchronize(st));
+    std::vector<unsigned> h(4 + ntiles + 1);
+    SS4K_HIP(hipMemcpy(h.data(), ca.ctl, h.size() * 4, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[chain] grid %d: %d items x %d tiles = %u units: %u blocking starts; workgroup-time spent polling: %.1f us at unit starts, %.1f us inside units (all workgroups together)\n",
+            ca.grid, ca.nitems, ntiles, (unsigned)ca.nitems * ntiles, h[2], h[3] / 100.0, h[4 + ntiles] / 100.0);
+  }
+#endif
 }
 
 // Called at the top of a conv network's forward: one launch chain or two?  Both give bit-identical tensors.
@@ -617,7 +647,11 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
       cur = dst;
     }
     if (use_chain) {
-      lanes_join(st, false);   // (a forced chain on an even batch: conv_first may have run as two launch chains)
+      if (forked) {   // (a forced chain on an even batch: conv_first ran as two launch chains; the conv section stays open)
+        SS4K_HIP(hipEventRecord(ctx->lane_done(), ctx->lane_stream()));
+        SS4K_HIP(hipStreamWaitEvent(st, ctx->lane_done(), 0));
+        forked = false;
+      }
       cur_lanes = 1;
       chain_run(n, H, W, st);
     }
