@@ -48,7 +48,7 @@ WORKLOADS = {
 }
 
 
-def build_upscaler(ctx, workload, device, lr_shape=(720, 1280)):
+def build_upscaler(ctx, workload, device, lr_shape=(720, 1280), flags=0):
     """Returns (upscaler, keepalive, algorithmic FLOPs per frame of the networks)."""
     px = lr_shape[0] * lr_shape[1]
     def bcast(table, keys):
@@ -65,7 +65,7 @@ def build_upscaler(ctx, workload, device, lr_shape=(720, 1280)):
     if workload in ("rrdbnet", "pipeline"):
         n = 16_703_171
         flat = sharding.broadcast_weights(W.flatten(W.rrdbnet_table(0, scale=2), W.rrdbnet_keys(23)) if rank == 0 else None, n, device)
-        sr = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2), flat)
+        sr = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, flags=flags), flat)
         flops = 8.263e12 * px / (720 * 1280)
         if workload == "rrdbnet":
             up = _capi.Upscaler(ctx, sr, lr_shape, None, True, False, None, 1.0)
@@ -384,8 +384,11 @@ def main():
                                           ("pipeline", "pipeline", args.batch, (720, 1280), 10),
                                           ("srvgg", "srvgg", args.batch, (720, 1280), 10),
                                           ("rrdbnet_n1", "rrdbnet", 1, (720, 1280), 20),
+                                          ("rrdbnet_n1_chain", "rrdbnet", 1, (720, 1280), 20),
                                           ("rrdbnet_x4", "rrdbnet_x4", 1, (1080, 1920), 5)):
-            up2, keep2, fpf = (up, keep, flops_per_frame) if name == "rrdbnet_n1" else build_upscaler(ctx, wl, device, lr_shape=shape)
+            # rrdbnet_n1_chain: the RRDB body as one persistent launch with per-tile hand-offs (SS4K_MODEL_CHAIN, csrc/conv_chain.hip)
+            up2, keep2, fpf = (up, keep, flops_per_frame) if name == "rrdbnet_n1" else build_upscaler(
+                ctx, wl, device, lr_shape=shape, flags=_capi.MODEL_CHAIN if name == "rrdbnet_n1_chain" else 0)
             fr2 = frames[:nb] if shape == in_shape else synthetic_frames(nb, shape, seed=77).to(device)
             o2h, o2w = up2.out_shape(nb, *shape)
             out2 = torch.empty((nb, o2h, o2w, 3), dtype=torch.uint8, device=device)
@@ -396,7 +399,8 @@ def main():
                 up2(fr2, out2)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
-            also[name] = {"workload": WORKLOADS[wl], "frames_per_step": nb, "fps": reps * nb / dt,
+            also[name] = {"workload": WORKLOADS[wl] + (", body as one chained launch (SS4K_MODEL_CHAIN)" if name.endswith("_chain") else ""),
+                          "frames_per_step": nb, "fps": reps * nb / dt,
                           "net_tflops": fpf * reps * nb / dt / 1e12}
             if wl != "fsrcnn":
                 rl = conv_roofline(ctx, up2, fr2, out2, psteps=2)

@@ -121,7 +121,7 @@ int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool h
     weight_bytes += wr.size();
     L.rs_wide = rs_wide;
   }
-  if (chainable && chain_mode != 1 && desc.dtype == SS4K_F16 && p.nb == 2) {
+  if (chainable && chain_mode == 2 && desc.dtype == SS4K_F16 && p.nb == 2) {
     PackSpec s1 = s; s1.force_nb1 = 1;
     const PackedConv p1 = pack_conv3x3(s1, w, b, a);
     upload(L.wch, p1.w.data(), p1.w.size());
@@ -450,41 +450,47 @@ void Model::chain_run(int N, int H, int W, hipStream_t st) {
 // streams being served concurrently by the hardware queues.  So, unless forced by SS4K_LANES, the choice is MEASURED per
 // (n, h, w): calls 0-1 run two chains, calls 2-3 one, the second call of each pair is timed with events on the
 // caller's stream (no host synchronisation: the events are polled on later calls), and the faster mode is kept.
-void Model::lanes_begin(int n, int h, int w, hipStream_t st) {
-  cur_lanes = 1; cur_n = n; forked = false; tune_timed = nullptr;
-  if (plan_only || lanes_mode == 1 || n % 2 != 0 || desc.dtype != SS4K_F16 || dbg) return;
-  if (lanes_mode == 2) { cur_lanes = 2; return; }
+// One step of a two-way measured choice for a job shape: returns the mode this call runs in - 2 ("the new way": two launch
+// chains / the chain kernel) on calls 0-1, 1 ("the plain way") on calls 2-3, the second call of each pair timed with events on
+// the caller's stream (no host synchronisation: the events are polled on later calls), then the faster one for good.
+int Model::tune_step(std::map<std::tuple<int, int, int>, LaneTune>& tab, int n, int h, int w, hipStream_t st) {
   const auto key = std::make_tuple(n, h, w);
-  auto it = lane_tune.find(key);
-  if (it == lane_tune.end()) {
-    if (lane_tune.size() >= LANE_TUNE_MAX) return;   // unmeasured shape past the cap: one chain
-    it = lane_tune.emplace(key, LaneTune{}).first;
+  auto it = tab.find(key);
+  if (it == tab.end()) {
+    if (tab.size() >= LANE_TUNE_MAX) return 1;   // unmeasured shape past the cap: the plain way
+    it = tab.emplace(key, LaneTune{}).first;
   }
   LaneTune* t = &it->second;
-  if (t->decided) { cur_lanes = t->decided; return; }
+  if (t->decided) return t->decided;
   const int k = t->calls++;
   if (k < 4) {
-    cur_lanes = k < 2 ? 2 : 1;
     if (k & 1) {   // second call of the pair: timed
       auto& ev = t->ev[k >> 1];
       SS4K_HIP(hipEventCreate(&ev[0])); SS4K_HIP(hipEventCreate(&ev[1]));
       SS4K_HIP(hipEventRecord(ev[0], st));
       tune_timed = ev[1];
     }
-    return;
+    return k < 2 ? 2 : 1;
   }
-  cur_lanes = 2;
   if (hipEventQuery(t->ev[0][1]) == hipSuccess && hipEventQuery(t->ev[1][1]) == hipSuccess) {
     float ms2 = 0, ms1 = 0;
-    // (a timed forward that threw left its end event unrecorded: no measurement, stay with one chain)
+    // (a timed forward that threw left its end event unrecorded: no measurement, stay with the plain way)
     const bool ok = hipEventElapsedTime(&ms2, t->ev[0][0], t->ev[0][1]) == hipSuccess &&
                     hipEventElapsedTime(&ms1, t->ev[1][0], t->ev[1][1]) == hipSuccess && ms1 > 0.f && ms2 > 0.f;
     if (!ok) (void)hipGetLastError();
     t->decided = ok && ms2 < 0.99f * ms1 ? 2 : 1;
     t->ms[0] = ms2; t->ms[1] = ms1;
     for (auto& pr : t->ev) for (auto& e : pr) { (void)hipEventDestroy(e); e = nullptr; }
-    cur_lanes = t->decided;
+    return t->decided;
   }
+  return 2;
+}
+
+void Model::lanes_begin(int n, int h, int w, hipStream_t st) {
+  cur_lanes = 1; cur_n = n; forked = false; tune_timed = nullptr;
+  if (plan_only || lanes_mode == 1 || n % 2 != 0 || desc.dtype != SS4K_F16 || dbg) return;
+  if (lanes_mode == 2) { cur_lanes = 2; return; }
+  cur_lanes = tune_step(lane_tune, n, h, w, st);
 }
 
 // the caller's stream continues only after both chains: called before any non-conv work on the tensors and at the end
@@ -622,10 +628,11 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
     Tens cur = F;
     // the body of small fp16 jobs as ONE persistent launch with per-tile hand-offs between the layers (conv_chain.hip):
     // 1-frame jobs by default (nothing else can overlap their 345 launch boundaries); SS4K_MODEL_CHAIN / _NO_CHAIN force it
-    // (default: jobs of at most 1.5 tiles per workgroup slot and layer - one 720p frame is 460 / 512; bigger jobs keep their slots
-    // busy across a boundary, and an even job has its frame lanes)
-    const long long tiles16 = (long long)n * ((H + 15) / 16) * ((W + 31) / 32);
-    const bool use_chain = !plan_only && f16 && !dbg && chain_mode != 1 && (chain_mode == 2 || 2 * tiles16 <= 3LL * 2 * ctx->num_cu) && nf == 64 && g == 32;
+    // Opt-in (SS4K_MODEL_CHAIN).  Measured on one 720p frame (460 tiles per layer, 512 workgroup slots): the chain runs a single
+    // caller's 1-frame jobs 1-6 % faster than 345 launches (box by box), but two callers alternating on two streams are better
+    // off with launches (105-112 against 98 frames/s: their chains of launches fill each other's gaps, two chain kernels only
+    // compete for the slots) - and a model cannot know how many callers the GPU has.  DESIGN.md 4.1d.
+    const bool use_chain = !plan_only && f16 && !dbg && nf == 64 && g == 32 && chain_mode == 2;
     if (use_chain) {
       chain_rec = true; chain_items.clear(); chain_layers.clear();
     }

@@ -66,13 +66,15 @@ struct Model {
   // shape runs one chain and is not measured
   static constexpr size_t LANE_TUNE_MAX = 64;
   std::map<std::tuple<int, int, int>, LaneTune> lane_tune;
+  int tune_step(std::map<std::tuple<int, int, int>, LaneTune>& tab, int n, int h, int w, hipStream_t st);
+
   hipEvent_t tune_timed = nullptr;
   ProfEvent section{}; bool section_open = false;   // bench: wall time of a forward's conv launches
   void lanes_begin(int n, int h, int w, hipStream_t st);
   void lanes_join(hipStream_t st, bool end_of_forward);
   // cross-layer chain (conv_chain.hip): the RRDB body of small fp16 jobs as ONE persistent launch.  While chain_rec is set,
   // conv() records work items instead of launching; chain_run() resolves the dependencies and launches the chain.
-  int chain_mode = 0;          // 0: 1-frame jobs, 1: never (SS4K_MODEL_NO_CHAIN), 2: every fp16 job (SS4K_MODEL_CHAIN)
+  int chain_mode = 1;          // 1: never (default, SS4K_MODEL_NO_CHAIN); 2: the RRDB body of every fp16 job (SS4K_MODEL_CHAIN)
   bool chain_rec = false;
   struct ChainLayerRec { int first_item, nitems; const char* out_lo; const char* out_hi; double flops; };
   std::vector<ChainItem> chain_items;
@@ -104,7 +106,7 @@ struct Model {
     if (chain_err_host) (void)hipHostFree(chain_err_host);
     for (auto& a : acts) a.release();
     fs_blob.release();
-    for (auto& t : lane_tune) for (auto& pr : t.second.ev) for (auto e : pr) if (e) (void)hipEventDestroy(e);
+    for (auto* tab : {&lane_tune}) for (auto& t : *tab) for (auto& pr : t.second.ev) for (auto e : pr) if (e) (void)hipEventDestroy(e);
   }
 
   int add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec spec, bool has_prelu_after, bool allow_rs = false, bool chainable = false);

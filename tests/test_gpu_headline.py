@@ -117,13 +117,9 @@ def test_config2_rrdbnet_x2_720p_fp16_service_vs_oracle(ctx):
                     asserted="PSNR >= 50 dB, max <= 4 LSB")
     assert p >= 50.0, f"PSNR {p:.2f} dB"
     assert int(d.max()) <= 4, f"max |delta| {int(d.max())} LSB"
-    # frames are independent: a frame's result does not depend on what else is in the job (4- and 2-frame jobs take the same
-    # kernels: bit-identical); a 1-frame job takes the cross-layer chain, whose conv5 adds in the LDS-weights kernel's order
-    # rather than the register-stationary kernel's: the same frame to the LSB
+    # a 4-frame job gives every frame the same result as a 1-frame job (frames are independent)
     four = torch.cat([frames, torch.from_numpy(smooth_u8(124, (3, 720, 1280, 3)))]).cuda()
-    f4 = up(four)[0].cpu()
-    assert torch.equal(up(four[:2])[0].cpu(), f4)
-    assert int((f4.int() - got[0].int()).abs().max()) <= 1
+    assert torch.equal(up(four)[0].cpu(), got[0])
 
 
 # ------------------------------------------------------------------------------ (c) configs[3]: BSVD + RRDBNet, per-frame path
