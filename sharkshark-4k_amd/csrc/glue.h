@@ -24,6 +24,8 @@ void op_bicubic_u8(const float* in, uint8_t* out, int n, int c, int h, int w, in
 void op_normalize(float* x, const float* st_hr, const float* st_lr, int planes, int hw, hipStream_t st);
 void op_depthwise_reflect(const float* in, float* out, const float* taps_dev, int planes, int h, int w, int k,
                           int clamp01, const float* blend_src, float blend_a, float blend_b, hipStream_t st);
+// separable form of the service's 17x17 sigma-8 reflect-padded Gaussian: in -> (horizontal) tmp -> (vertical) out
+void op_gauss17_reflect(const float* in, float* tmp, float* out, const float* g17_dev, int planes, int h, int w, hipStream_t st);
 void op_bilinear(const float* in, float* out, int planes, int h, int w, int oh, int ow, int subtract_from_out,
                  int clamp01, hipStream_t st);
 void op_bicubic(const float* in, float* out, int planes, int h, int w, int oh, int ow, int clamp01, hipStream_t st);

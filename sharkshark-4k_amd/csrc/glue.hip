@@ -232,6 +232,34 @@ void op_depthwise_reflect(const float* in, float* out, const float* taps_dev, in
   SS4K_LAUNCH_OK();
 }
 
+// 17-tap Gaussian of the local colour match (fsrcnn_upscaler.py:20-52, :211-213) as two 1-D passes: the reference's normalised
+// 17x17 kernel is the outer product of g = e / sum(e), e_i = exp(-(i - 8)^2 / (2 sigma^2)), and reflect padding commutes with
+// the split.  289 taps -> 34 (the 2-D form stays as the granular op ss4k_op_depthwise_reflect, which takes any taps).
+template <bool VERT>
+__global__ void k_gauss17(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ g, int planes,
+                          int h, int w) {
+  const int y = blockIdx.y, pl = blockIdx.z;
+  const float* src = in + (size_t)pl * h * w;
+  float* dst = out + ((size_t)pl * h + y) * w;
+  float gt[17];
+#pragma unroll
+  for (int k = 0; k < 17; ++k) gt[k] = g[k];
+  for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 17; ++k)
+      acc += gt[k] * (VERT ? src[(size_t)reflect(y + k - 8, h) * w + x] : src[(size_t)y * w + reflect(x + k - 8, w)]);
+    dst[x] = acc;
+  }
+}
+void op_gauss17_reflect(const float* in, float* tmp, float* out, const float* g17_dev, int planes, int h, int w, hipStream_t st) {
+  SS4K_REQUIRE(h <= 65535 && planes <= 65535, "gauss17: grid limits");
+  SS4K_REQUIRE(h > 8 && w > 8, "gauss17 reflect: padding (8) must be smaller than the plane, as torch requires");
+  hipLaunchKernelGGL(k_gauss17<false>, grid_rows(w, h, planes), dim3(256), 0, st, in, tmp, g17_dev, planes, h, w);
+  hipLaunchKernelGGL(k_gauss17<true>, grid_rows(w, h, planes), dim3(256), 0, st, tmp, out, g17_dev, planes, h, w);
+  SS4K_LAUNCH_OK();
+}
+
 // ------------------------------------------------------------------ bilinear / bicubic (align_corners=False)
 // V consecutive outputs per thread (V = 4: 16-byte read-modify-write of the output row when ow % 4 == 0)
 template <int V>

@@ -32,7 +32,18 @@ rm -rf $O/sq
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/tcc -- $B --steps 1 --warmup 1 --no-roofline > /dev/null 2>&1
 python3 tools/pmc_summary.py $O/tcc $O/${TAG}_rrdbnet_tcc_counters.json > /dev/null
 rm -rf $O/tcc
+# 3b. where the fabric requests go: rocprofv3 on gfx950 lists no Infinity-Cache (MALL) hit / miss counter (rocprofv3 -L: nothing
+#     named mall / l3); the nearest split the TCC exposes is "requests destined for DRAM (MC)" against all EA requests
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum --kernel-trace --output-format csv -d $O/ea -- $B --steps 1 --warmup 1 --no-roofline > /dev/null 2>&1
+python3 tools/pmc_summary.py $O/ea $O/${TAG}_rrdbnet_ea_dram_counters.json > /dev/null
+rm -rf $O/ea
 unset SS4K_LANES
+# 3c. working set against the Infinity Cache, WITH frame lanes: 4 frames at once (default) against two passes of 2 frames
+#     (dev library switch SS4K_SUBBATCH=2; each pass still runs as two launch chains of one frame)
+SS4K_LIB=$PWD/sharkshark-4k_amd/libss4k_hip_dev.so python3 tools/env_ab.py "SS4K_LANES=2,SS4K_SUBBATCH=0;SS4K_LANES=2,SS4K_SUBBATCH=2" 4 3 > $O/${TAG}_subbatch_ab_with_lanes.txt 2>&1
+# 3d. 1-frame jobs: one launch per layer against the chain kernel (SS4K_MODEL_CHAIN = 128), and the chain's stall statistics
+python3 tools/n1_ab.py 1 3 0,128 2>&1 | grep "^round" > $O/${TAG}_n1_chain_ab.txt
+SS4K_LIB=$PWD/sharkshark-4k_amd/libss4k_hip_dev.so python3 tools/n1_ab.py 1 1 144:SS4K_CHAIN_ABL=8 2>&1 | grep "chain\]" | tail -1 >> $O/${TAG}_n1_chain_ab.txt
 # 4. the other workloads: per-kernel stats
 for wl in fsrcnn pipeline srvgg rrdbnet_x4; do
   extra=""; [ $wl = rrdbnet_x4 ] && extra="--batch 1"
