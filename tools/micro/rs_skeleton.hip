@@ -109,6 +109,108 @@ __global__ __launch_bounds__(256, 1) void k(const uint4* __restrict__ wsrc, cons
   out[blockIdx.x * 256 + threadIdx.x] = s;
   if (threadIdx.x == 0 && blockIdx.x == 17) { res->cyc = t1 - t0; res->rt = r1 - r0; }
 }
+// Round 3 (VERDICT r2 "next" 3): the variant that was costed and skipped - the 16x16x32 shape with the WHOLE layer's weights
+// resident in LDS (conv1-3 of an RDB: 36 / 54 / 72 KB) next to a ring of 32-channel halo stages, EIGHT waves (two per SIMD, 256
+// registers each) so that one wave's LDS-DMA issue hides under its SIMD partner's MFMAs.  Wave = (row group of 4 rows, cout half):
+// per (chunk, tap column) it reads its 3 weight fragments from LDS once and keeps them for the 6 input rows of that column
+// (0.5 weight reads per B read).  Stages = what fits beside the weights (conv1: 3, conv2 / conv3: 2).
+template <int NCH, int NSTAGE>
+__global__ __launch_bounds__(512, 2) void k_wl8(const uint4* __restrict__ wsrc, const char* __restrict__ buf, size_t span,
+                                                float* out, int ntiles, Res* res) {
+  constexpr int ROWS = 4, NW = 8, WBYTES = NCH * 9 * 2 * 1024;   // 32 couts: two 16-cout blocks of 1 KB fragments per (chunk, tap)
+  constexpr int NDMA8 = (STAGE / 1024 + NW) / NW;                 // 5
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rg = wave & 3, cg = wave >> 2;
+  for (int i = threadIdx.x; i < (WBYTES + NSTAGE * STAGE) / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = wsrc[i & 4095];
+  __syncthreads();
+  const char* wl = smem + cg * 1024 + lane * 16;                   // this wave's cout block of every (chunk, tap) pair
+  const char* rd = smem + WBYTES + lane * 16 + rg * ROWS * 2176;
+  size_t pos = ((size_t)blockIdx.x * NW + wave) * 1024;
+  const size_t stride = (size_t)gridDim.x * NW * 1024;
+  int g = 0;
+  unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    f32x4 acc[ROWS][2];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c, ++g) {
+      const int slot = g % NSTAGE, fill = (g + NSTAGE - 1) % NSTAGE;
+      const char* st = rd + slot * STAGE;
+      const unsigned dst = lds0 + WBYTES + fill * STAGE;
+      int dma_i = 0;
+      constexpr int NM = 3 * (ROWS + 2);
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        uint4 wf[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) wf[dy] = *reinterpret_cast<const uint4*>(wl + ((c * 9 + dy * 3 + dx) * 2) * 1024);
+#pragma unroll
+        for (int ir = 0; ir < ROWS + 2; ++ir) {
+          uint4 b[2];
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) b[pb] = *reinterpret_cast<const uint4*>(st + ir * 2176 + pb * 1024 + dx * 64);
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const int mb = ir - dy;
+            if (mb >= 0 && mb < ROWS) {
+#pragma unroll
+              for (int pb = 0; pb < 2; ++pb)
+                acc[mb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&wf[dy]),
+                                                                     *reinterpret_cast<const f16x8*>(&b[pb]), acc[mb][pb], 0, 0, 0);
+            }
+          }
+          const int step = dx * (ROWS + 2) + ir;
+          if (dma_i < NDMA8 && step * NDMA8 >= dma_i * NM) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int kk = wave + NW * dma_i;
+            if (kk * 1024 < STAGE) dma16(buf + (pos & (span - 1)) + lane * 16, dst + kk * 1024);
+            pos += stride;
+            ++dma_i;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      if (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NDMA8) : "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 4; ++e) s += acc[i][j][e];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 17) { res->cyc = t1 - t0; res->rt = r1 - r0; }
+}
+template <int NCH, int NSTAGE>
+void run_wl8(const uint4* w, const char* buf, size_t span, float* out, Res* res, const char* what) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int ntiles = 6000 / NCH, grid = 256;
+  constexpr int LDSB = NCH * 9 * 2 * 1024 + NSTAGE * STAGE;
+  static_assert(LDSB <= 160 * 1024, "LDS");
+  const void* fn = reinterpret_cast<const void*>(&k_wl8<NCH, NSTAGE>);
+  hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+  const double mfma_per_wave = (double)ntiles * NCH * 9 * 4 * 2;
+  float ms = 0;
+  hipEventRecord(e0);
+  do {
+    hipLaunchKernelGGL((k_wl8<NCH, NSTAGE>), dim3(grid), dim3(512), LDSB, 0, w, buf, span, out, ntiles, res);
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+  } while (ms < 1500.0);
+  hipEventRecord(e0);
+  const int reps = 4;
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_wl8<NCH, NSTAGE>), dim3(grid), dim3(512), LDSB, 0, w, buf, span, out, ntiles, res);
+  hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+  Res r; hipMemcpy(&r, res, sizeof(Res), hipMemcpyDeviceToHost);
+  const double tf = grid * 8 * mfma_per_wave * 16384.0 * reps / ms / 1e9;
+  printf("%-34s <NCH %d, 8 waves, LDS weights %d KB, stages %d> %6.0f TFLOP/s  clock %4.0f MHz  MFMA-pipe %4.1f %% of cycles (x2 waves per SIMD)  DMA %4.1f B per 32K-FLOP\n", what, NCH,
+         NCH * 18, NSTAGE, tf, (double)r.cyc / r.rt * 100.0, 100.0 * mfma_per_wave * 16.0 / (double)r.cyc, (double)STAGE / (8.0 * 9 * 4 * 2 / 2));
+  fflush(stdout);
+}
 template <int NCH, int ROWS, int CB, int NSTAGE>
 void run(const uint4* w, const char* buf, size_t span, float* out, Res* res, const char* what) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -149,6 +251,12 @@ int main() {
     run<6, 16, 1, 3>(w, big, 2u << 20, out, res, "conv5 shape, DMA from L2 window");
     run<6, 16, 1, 3>(w, big, BIG, out, res, "conv5 shape, DMA from 2 GB stream");
     run<2, 8, 2, 3>(w, big, BIG, out, res, "64->64 shape, DMA from 2 GB stream");
+    run<3, 4, 2, 3>(w, big, BIG, out, res, "conv2 shape, DMA from 2 GB stream");
+    run_wl8<2, 3>(w, big, BIG, out, res, "conv1 shape, 8 waves + LDS weights");
+    run_wl8<3, 2>(w, big, BIG, out, res, "conv2 shape, 8 waves + LDS weights");
+    run_wl8<4, 2>(w, big, BIG, out, res, "conv3 shape, 8 waves + LDS weights");
+    run_wl8<2, 3>(w, big, 2u << 20, out, res, "conv1 shape, 8 waves + LDS w, L2 win");
+    run_wl8<4, 2>(w, big, 2u << 20, out, res, "conv3 shape, 8 waves + LDS w, L2 win");
   }
   return 0;
 }
