@@ -293,8 +293,11 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_
   // value that LANDED in fp16, so an fp16-subnormal hi (|x| < 2^-14) loses nothing either.  |x| >= 65504 does not fit the
   // split (hi saturates): see Model::build / SS4K_MODEL_FS_EXACT.
   const fp16x2v ph = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+  // (x - hi) * 2048 as fma(hi, -2048, x * 2048): both products are exact (a power of two), the difference is exact, and the fp16 hi
+  // enters the fma directly (v_fma_mix_f32) - one multiply (packed over the pair) + one mixed fma per value instead of convert,
+  // subtract, multiply
   const float h0 = (float)ph[0], h1 = (float)ph[1];
-  const fp16x2v pl = __builtin_amdgcn_cvt_pkrtz((x0 - h0) * 2048.f, (x1 - h1) * 2048.f);
+  const fp16x2v pl = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf(h0, -2048.f, x0 * 2048.f), __builtin_fmaf(h1, -2048.f, x1 * 2048.f));
   hi = __builtin_bit_cast(uint32_t, ph); lo = __builtin_bit_cast(uint32_t, pl);
 }
 __device__ __forceinline__ float dpp_shl1(float v) {   // lane i <- lane i + 1 (0 past the wave)
