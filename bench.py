@@ -372,10 +372,14 @@ def main():
                                   "frames_per_launch": args.batch * 351.0 / rl["launches_per_step"],
                                   "kernel_time_share_of_step": rl["conv_ms_per_step"] / (1000.0 * elapsed / args.steps)}
         elif args.workload == "fsrcnn":
-            ach = flops_per_frame * fps / world / 1e12
-            result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": F32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": ach / F32_VECTOR_PEAK_TFLOPS, "traffic": None,
-                                  "kernel": "fsrcnn kernels, whole-step average of the algorithmic fp32 FLOPs against the fp32 peak (157.3) that bounds an exact-fp32 implementation; the mapping and tail stages run on fp16 MFMA with hi/lo-split operands (3 MFMAs per product, fp32 accumulate)"}
+            # FSRCNN: three stages, each against the unit that bounds it (fsrcnn_stage_rooflines); the line's roofline is the
+            # stage that takes the longest
+            stages = fsrcnn_stage_rooflines(ctx, up, frames, out)
+            if stages:
+                name, dom = max(stages.items(), key=lambda kv: kv[1]["ms_per_step"])
+                result["roofline"] = {"bound": "mfma", "achieved": dom["achieved_tflops"], "peak": dom["peak_tflops"], "unit": "TFLOP/s",
+                                      "frac": dom["frac"], "traffic": None, "kernel": "fsrcnn stage: " + name, "peak_is": dom["peak_is"],
+                                      "stages": stages}
     if rank == 0 and world == 1 and not args.no_also and args.workload == "rrdbnet":
         # the other single-GPU BASELINE configs and the 1-frame (image-server / latency) job, measured the
         # same way (short, outside the headline timing); conv-based ones carry their own roofline fraction
