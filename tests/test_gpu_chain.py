@@ -26,10 +26,12 @@ def _model(ctx, flat, scale, nb, flags):
 
 
 @pytest.mark.parametrize("scale,shape,rows", [(2, (1, 3, 144, 208), 0), (2, (2, 3, 92, 200), 16), (2, (3, 3, 80, 72), 20),
-                                              (4, (1, 3, 37, 70), 0), (1, (1, 3, 128, 256), 0), (2, (1, 3, 360, 500), 0)])
+                                              (4, (1, 3, 37, 70), 0), (1, (1, 3, 128, 256), 0), (2, (1, 3, 360, 500), 0),
+                                              (2, (1, 3, 16, 20), 0), (2, (3, 3, 24, 60), 16), (4, (2, 3, 9, 33), 0)])
 def test_chain_bit_identical_to_launches(ctx, scale, shape, rows):
     """Forced chain (any batch) vs one launch per layer on the same tile body; ragged sizes put partly filled tiles on every
-    edge, several frames put several frames' tiles into one queue, both tile heights are covered."""
+    edge, several frames put several frames' tiles into one queue, both tile heights are covered; the last three shapes are
+    one, two and three tiles per frame (fewer tiles than the distance rule for the grid assumes: one workgroup does it all)."""
     tab = W.rrdbnet_table(71 + scale, scale=scale, num_block=3)
     flat = W.flatten(tab, W.rrdbnet_keys(3))
     tr = {0: 0, 16: _capi.MODEL_TILE_ROWS_16, 20: _capi.MODEL_TILE_ROWS_20}[rows]
