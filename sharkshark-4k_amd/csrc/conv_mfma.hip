@@ -779,6 +779,11 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
     const long long tiles20 = (long long)a.N * ((a.H + 19) / 20) * a.tiles_x * (a.grid_share > 0.f ? 2 : 1);
     const bool mb5 = dtype == SS4K_F16 && nb == 1 && ek == EK_PLAIN &&
                      (a.mb_override ? a.mb_override == 5 : (waste(20) < waste(16) - 1e-9 && tiles20 >= 2LL * ctx->num_cu));
+#ifdef SS4K_DEV
+    // experiment (SS4K_MB=3, dev library): 12-row tiles at THREE workgroups per CU for the 32-cout layers
+    if (a.mb_override == 3 && dtype == SS4K_F16 && nb == 1 && ek == EK_PLAIN) launch_t<__half, 1, 3, 4, 0, EK_PLAIN>(ctx, a, groups, st);
+    else
+#endif
     if (mb5) launch_t<__half, 1, 5, 4, 0, EK_PLAIN>(ctx, a, groups, st);
     else if (dtype == SS4K_F16) { if (nb == 1) { SS4K_LAUNCH_EK(__half, 1) } else { SS4K_LAUNCH_EK(__half, 2) } }
     else { if (nb == 1) { SS4K_LAUNCH_EK(float, 1) } else { SS4K_LAUNCH_EK(float, 2) } }
