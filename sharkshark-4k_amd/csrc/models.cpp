@@ -407,9 +407,12 @@ void Model::chain_run(int N, int H, int W, hipStream_t st) {
   if (*chain_err_host) { *chain_err_host = 0; throw Error(SS4K_EHIP, "conv chain: a work unit timed out waiting for its neighbours (previous forward's output is invalid)"); }
   const size_t bytes = chain_items.size() * sizeof(ChainItem);
   if (chain_uploaded.size() != chain_items.size() || std::memcmp(chain_uploaded.data(), chain_items.data(), bytes) != 0) {
+    // a new job shape (or re-allocated activations): rare, so the upload is allowed to wait - for the previous chain launch, which
+    // may still be reading the old table, and for the copy itself (the host vector is reused by the next shape change)
+    SS4K_HIP(hipStreamSynchronize(st));
     chain_tab.ensure(bytes);
-    chain_uploaded = chain_items;   // the source of the asynchronous copy stays alive in the model
-    SS4K_HIP(hipMemcpyAsync(chain_tab.ptr, chain_uploaded.data(), bytes, hipMemcpyHostToDevice, st));
+    chain_uploaded = chain_items;
+    SS4K_HIP(hipMemcpy(chain_tab.ptr, chain_uploaded.data(), bytes, hipMemcpyHostToDevice));
   }
   const auto waste = [&](int th) { return (double)((H + th - 1) / th * th) / H; };
   int mb = mb_override ? mb_override : (waste(20) < waste(16) - 1e-9 ? 5 : 4);
