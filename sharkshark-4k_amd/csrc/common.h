@@ -140,7 +140,6 @@ struct ConvArgs {
   const void* wpk;                      // packed weights [group][chunk][dx,ks][dy][nb][lane][E]
   const void* wrs;                      // conv_rs.hip layout [group][cout group][chunk32][tap][cb][lane][8] or null
   int rs_wide;                          // wrs is packed for the eight-wave variant of the shape
-  int rs_nchw;                          // wrs is ONE 16-cout block of a 64 -> <= 4 channel output layer (conv_rs.hip NC build)
   const float* bias;                    // [cout_pad] virtual order
   const float* prelu;                   // [cout_pad] or null
   int act; float slope;

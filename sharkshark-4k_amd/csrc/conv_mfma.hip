@@ -729,8 +729,7 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
   const ProfEvent pe = ctx->prof_begin(st, PROF_CONV);
   // fp16 tile shapes <couts/32, rows per wave, waves>; see DESIGN.md 4.1 for how they were chosen
   // fp16 layers of a supported shape with a plain epilogue: register-stationary weights on the 16x16x32 MFMA
-  if (a.wrs && dtype == SS4K_F16 && !a.dbg && !a.bsvd_resid && a.act != ACT_RELU6 &&
-      (a.epi == EPI_NHWC || (a.epi == EPI_NCHW_F32 && a.rs_nchw))) {
+  if (a.wrs && dtype == SS4K_F16 && !a.dbg && a.epi == EPI_NHWC && !a.bsvd_resid && a.act != ACT_RELU6) {
     launch_conv3x3_rs(ctx, a, st);
   } else
 #ifdef SS4K_DEV

@@ -63,7 +63,6 @@ struct RsArgs {
   const char* res2; size_t r2_plane_bytes;
   int N, n0, H, W, ups2, tiles_x, tiles_y, reverse;   // n0: first frame of this launch (frame lanes)
   float slope, alpha, gamma;       // slope: LeakyReLU slope, 1 = no activation (PReLU: per channel, `prelu`)
-  float* out_nchw; int cout_real;  // NC builds: the network's output, fp32 NCHW, the first cout_real (<= 4) channels
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_addr_wave_uniform) {
@@ -103,9 +102,7 @@ __device__ __forceinline__ int swz(int col) { return ((col >> 2) & 1) << 1; }
 //     there (scaled by 1 / alpha) instead of being read from HBM a second time in the epilogue - at one wave
 //     per SIMD nothing would hide that latency.
 // RES: the epilogue reads residual(s) from memory (res1 unless RL, res2); built only where a network needs it.
-// NC:  the layer is a network's last conv (64 -> 3): 16 couts are computed instead of the LDS-weights kernel's 32, and the first
-//      cout_real of them leave as fp32 NCHW (the hand-off to the service glue) from the lanes that hold channels 0-3.
-template <int NCH, int ROWS, int CB, int CG, bool PR, bool RL, bool RES, bool NC = false>
+template <int NCH, int ROWS, int CB, int CG, bool PR, bool RL, bool RES>
 __global__ __launch_bounds__(64 * (TH / ROWS) * CG, (TH / ROWS) * CG / 4) void conv3x3_rs_kernel(const RsArgs a) {
   constexpr int RG = TH / ROWS, NW = RG * CG, COUT_WG = CG * CB * 16;
   constexpr int NDMA = STAGE_DMA / NW;        // DMA instructions per wave and stage (10 with four waves, 5 with eight)
@@ -119,7 +116,6 @@ __global__ __launch_bounds__(64 * (TH / ROWS) * CG, (TH / ROWS) * CG / 4) void c
   static_assert(NCH >= 2 && 2 * NCH <= MAX_PLANES, "the two-chunks-ahead prefetch needs at least two K-chunks per tile");
   static_assert(ROWS * 2 * CB * 4 + (NCH - NA) * 36 * CB <= 160, "VGPR budget: accumulators + VGPR-resident weights");
   static_assert(!RL || (CB == 1 && ROWS == 16), "RL is built for the conv5 shape: a wave owns one output plane of the whole tile");
-  static_assert(!NC || (CB == 1 && CG == 1 && !RES && !RL && !PR), "NC is built for one 16-cout block without residuals");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -331,21 +327,11 @@ __global__ __launch_bounds__(64 * (TH / ROWS) * CG, (TH / ROWS) * CG / 4) void c
             const float t = acc[mb][pb][cb][i], neg = t * slope_v[PR ? 4 * cb + i : 0];
             v[4 * cb + i] = (PR ? (t >= 0.f ? t : neg) : fmaxf(t, neg)) * (RL ? alpha * gamma : alpha);   // one slope in [0,1] unless PReLU
           }
-        if constexpr (NC) {
-          if (qe == 0 && x_ok[pb]) {
-            const size_t plane = (size_t)a.H * a.W;
-            float* o = a.out_nchw + (size_t)n * a.cout_real * plane + (size_t)(y0 + rg * ROWS + mb) * a.W + (x0 + 16 * pb + p);
+        rvec o;
 #pragma unroll
-            for (int k = 0; k < NV; ++k)
-              if (k < a.cout_real) o[(size_t)k * plane] = v[k];
-          }
-        } else {
-          rvec o;
-#pragma unroll
-          for (int k = 0; k < NV; k += 2)
-            o[k >> 1] = (unsigned)__half_as_ushort(__float2half(v[k])) | ((unsigned)__half_as_ushort(__float2half(v[k + 1])) << 16);
-          if (x_ok[pb]) __builtin_nontemporal_store(o, reinterpret_cast<rvec*>(outp + mb * row_bytes + pb * 512));
-        }
+        for (int k = 0; k < NV; k += 2)
+          o[k >> 1] = (unsigned)__half_as_ushort(__float2half(v[k])) | ((unsigned)__half_as_ushort(__float2half(v[k + 1])) << 16);
+        if (x_ok[pb]) __builtin_nontemporal_store(o, reinterpret_cast<rvec*>(outp + mb * row_bytes + pb * 512));
       }
     };
 
@@ -508,7 +494,7 @@ __global__ __launch_bounds__(64 * (TH / ROWS) * CG, (TH / ROWS) * CG / 4) void c
   wait_vm<0>();   // the trailing (zero) prefetches must have landed before the workgroup's LDS is released
 }
 
-template <int NCH, int ROWS, int CB, int CG, bool PR, bool RL = false, bool RES = false, bool NC = false>
+template <int NCH, int ROWS, int CB, int CG, bool PR, bool RL = false, bool RES = false>
 static void launch_t(ss4k_ctx* ctx, const ConvArgs& c, hipStream_t st) {
   SS4K_REQUIRE(RES || ((RL || !c.res1) && !c.res2), "internal: conv3x3_rs build without residual support");
   constexpr int RG = TH / ROWS, NW = RG * CG, COUT_WG = CG * CB * 16;
@@ -522,20 +508,19 @@ static void launch_t(ss4k_ctx* ctx, const ConvArgs& c, hipStream_t st) {
   }
   a.zero_page = c.zero_page; a.wrs = c.wrs; a.bias = c.bias; a.prelu = c.prelu;
   a.out = c.out + (size_t)c.out_plane0 * c.out_plane_bytes; a.out_plane_bytes = c.out_plane_bytes;
-  a.out_nchw = NC ? reinterpret_cast<float*>(c.out) : nullptr; a.cout_real = c.cout_real;
   a.res1 = c.res1 ? c.res1 + (size_t)c.r1_plane0 * c.r1_plane_bytes : nullptr; a.r1_plane_bytes = c.r1_plane_bytes;
   a.res2 = c.res2 ? c.res2 + (size_t)c.r2_plane0 * c.r2_plane_bytes : nullptr; a.r2_plane_bytes = c.r2_plane_bytes;
   a.N = c.N; a.n0 = c.n0; a.H = c.H; a.W = c.W; a.ups2 = c.ups2; a.reverse = c.reverse;
   a.tiles_x = (c.W + TW - 1) / TW;
   a.tiles_y = (c.H + TH - 1) / TH;
   a.slope = c.act == ACT_LRELU ? c.slope : 1.f; a.alpha = c.alpha; a.gamma = c.gamma;
-  const int groups = NC ? 1 : c.cout_pad / COUT_WG;
+  const int groups = c.cout_pad / COUT_WG;
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
-  const void* fn = reinterpret_cast<const void*>(&conv3x3_rs_kernel<NCH, ROWS, CB, CG, PR, RL, RES, NC>);
+  const void* fn = reinterpret_cast<const void*>(&conv3x3_rs_kernel<NCH, ROWS, CB, CG, PR, RL, RES>);
   if (ctx->lds_attr_set.insert(fn).second)
     SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int gx = std::min(ntiles, std::max(1, (int)(ctx->num_cu / groups * (c.grid_share > 0.f ? c.grid_share : 1.f))));
-  hipLaunchKernelGGL((conv3x3_rs_kernel<NCH, ROWS, CB, CG, PR, RL, RES, NC>), dim3(gx, groups), dim3(64 * NW), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_rs_kernel<NCH, ROWS, CB, CG, PR, RL, RES>), dim3(gx, groups), dim3(64 * NW), lds, st, a);
   SS4K_HIP(hipGetLastError());
 }
 
@@ -554,12 +539,6 @@ bool rs_config(int nplanes, int cout_pad, bool wide, int* nch, int* rows, int* c
 }
 
 void launch_conv3x3_rs(ss4k_ctx* ctx, const ConvArgs& a, hipStream_t st) {
-  if (a.epi == EPI_NCHW_F32) {   // a network's last conv: 64 -> <= 4 channels, fp32 NCHW out (weights packed as ONE 16-cout block)
-    SS4K_REQUIRE(a.wrs && a.nchunks0 + a.nchunks1 == 4 && a.cout_real <= 4 && !a.res1 && !a.res2 && !a.bsvd_resid && a.act == ACT_NONE && !a.ups2,
-                 "conv3x3_rs: the NCHW build takes a plain 64 -> <= 4 channel layer");
-    rs::launch_t<2, 4, 1, 1, false, false, false, true>(ctx, a, st);
-    return;
-  }
   int nch, rows, cb, cg;
   SS4K_REQUIRE(rs_config(a.nchunks0 + a.nchunks1, a.cout_pad, a.rs_wide != 0, &nch, &rows, &cb, &cg), "conv3x3_rs: unsupported layer shape");
   SS4K_REQUIRE(a.wrs && a.epi == EPI_NHWC && !a.bsvd_resid && a.act != ACT_RELU6, "conv3x3_rs: unsupported epilogue");

@@ -121,14 +121,6 @@ int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool h
     weight_bytes += wr.size();
     L.rs_wide = rs_wide;
   }
-  // a network's last conv (64 -> 3, fp32 NCHW out): the register-stationary kernel computes 16 couts for it instead of 32 and
-  // streams its 1440p input through the four-stage ring (rs_mask bit 6)
-  if (allow_rs && use_rs && desc.dtype == SS4K_F16 && cout <= 4 && s.nchunks0 + s.nchunks1 == 4 && ((rs_mask >> 6) & 1)) {
-    const std::vector<uint8_t> wr = pack_conv3x3_rs(s, w, 16, 2, 1, 1);
-    upload(L.wrs, wr.data(), wr.size());
-    weight_bytes += wr.size();
-    L.rs_nchw = true;
-  }
   if (chainable && chain_mode == 2 && desc.dtype == SS4K_F16 && p.nb == 2) {
     PackSpec s1 = s; s1.force_nb1 = 1;
     const PackedConv p1 = pack_conv3x3(s1, w, b, a);
@@ -271,7 +263,7 @@ void Model::build(const float* w, size_t n) {
           add_conv(pc, co, nf + c * g, c == 0 ? spec_plain(nf) : spec_concat(nf, c * g), false, /*allow_rs=*/true, /*chainable=*/true);
         }
     for (int i = 0; i < 4; ++i) add_conv(pc, nf, nf, spec_plain(nf), false, /*allow_rs=*/true);
-    add_conv(pc, 3, nf, spec_plain(nf), false, /*allow_rs=*/true);
+    add_conv(pc, 3, nf, spec_plain(nf), false);
   } else if (desc.kind == SS4K_SRVGG) {
     const int nf = desc.num_feat;
     add_conv(pc, nf, 3, spec_plain(3), true);
@@ -304,7 +296,7 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
   if (in1) { a.in1 = in1->p; a.in1_plane_bytes = in1->plane_bytes; a.in1_plane0 = in1->plane0; a.nchunks1 = L.nchunks1; }
   SS4K_REQUIRE((in1 != nullptr) == (L.nchunks1 > 0), "internal: conv segment mismatch");
   a.N = N; a.H = H; a.W = W; a.ups2 = o.ups2;
-  a.wpk = L.w.ptr; a.wrs = L.wrs.ptr; a.rs_wide = L.rs_wide ? 1 : 0; a.rs_nchw = L.rs_nchw ? 1 : 0; a.bias = L.bias.as<float>(); a.prelu = L.has_prelu ? L.prelu.as<float>() : nullptr;
+  a.wpk = L.w.ptr; a.wrs = L.wrs.ptr; a.rs_wide = L.rs_wide ? 1 : 0; a.bias = L.bias.as<float>(); a.prelu = L.has_prelu ? L.prelu.as<float>() : nullptr;
   a.act = o.act; a.slope = o.slope; a.alpha = o.alpha; a.gamma = o.gamma;
   if (o.res1) { a.res1 = o.res1->p; a.r1_plane_bytes = o.res1->plane_bytes; a.r1_plane0 = o.res1->plane0; }
   if (o.res2) { a.res2 = o.res2->p; a.r2_plane_bytes = o.res2->plane_bytes; a.r2_plane0 = o.res2->plane0; }

@@ -14,7 +14,6 @@ struct ConvLayer {
   DevBuf wch;              // 64-cout fp16 body layers: the weights once more as two 32-cout groups (conv_chain.hip)
   DevBuf wrs;              // conv_rs.hip weight order (fp16 layers of a supported shape, else empty)
   bool rs_wide = false;    // ... packed for the eight-wave variant
-  bool rs_nchw = false;    // ... one 16-cout block of an output layer (conv_rs.hip NC build)
   bool has_prelu = false;
   int cout_real = 0, cout_pad = 0, cin_real = 0, nchunks0 = 0, nchunks1 = 0;
 };
@@ -98,7 +97,7 @@ struct Model {
   void abort_forward(hipStream_t st) noexcept;
   void out_shape(int n, int h, int w, int* oc, int* oh, int* ow) const;
   int in_channels() const;
-  int rs_mask = 32 | 64;   // layer shapes routed to conv_rs.hip (bit per shape, models.cpp rs_shape_bit; bit 6: the 64 -> 3 output layer); default: RDB conv5 + output layer
+  int rs_mask = 32;        // layer shapes routed to conv_rs.hip (bit per shape, models.cpp rs_shape_bit); default: RDB conv5
   bool rs_wide = false;    // eight-wave variants of the 32-cout RS shapes (SS4K_RS_W8=1: A/B switch)
   bool use_rs = true;      // route eligible fp16 layers to the register-stationary kernel (SS4K_NO_RS=1: A/B switch)
   ~Model() {
