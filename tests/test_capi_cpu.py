@@ -103,3 +103,16 @@ def test_weight_tables_are_deterministic():
     blend = W.dni_blend(W.srvgg_table(0, num_conv=1), W.srvgg_table(1, num_conv=1), 0.25)
     k = "body.0.weight"
     assert np.allclose(blend[k], 0.25 * W.srvgg_table(0, num_conv=1)[k] + 0.75 * W.srvgg_table(1, num_conv=1)[k])
+
+
+def test_model_flag_constants_match_header():
+    """ss4k_model_desc.flags: the SS4K_MODEL_* bits the Python binding uses are the header's."""
+    text = open(os.path.join(ROOT, "include", "ss4k.h")).read()
+    hdr = {m.group(1): int(m.group(2)) for m in re.finditer(r"\bSS4K_MODEL_([A-Z0-9_]+)\s*=\s*(\d+)", text)}
+    want = {"FS_EXACT": _capi.MODEL_FS_EXACT, "ONE_CHAIN": _capi.MODEL_ONE_CHAIN, "TWO_CHAINS": _capi.MODEL_TWO_CHAINS,
+            "NO_RS": _capi.MODEL_NO_RS, "TILE_ROWS_16": _capi.MODEL_TILE_ROWS_16, "TILE_ROWS_20": _capi.MODEL_TILE_ROWS_20,
+            "NO_CHAIN": _capi.MODEL_NO_CHAIN, "CHAIN": _capi.MODEL_CHAIN}
+    for k, v in want.items():
+        assert hdr[k] == v, k
+    assert hdr["FLAGS_ALL"] == sum(want.values())
+    assert _capi.ModelDesc.flags.offset == 12 * 4 and _capi.make_desc(_capi.RRDBNET, flags=_capi.MODEL_CHAIN).flags == 128
