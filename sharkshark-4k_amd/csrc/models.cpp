@@ -2,6 +2,7 @@
 // the kernels in conv_mfma.hip / fsrcnn.hip.  Weights arrive as the reference's state_dict
 // flattened in key order (see sharkshark-4k_amd/weights.py) and are repacked once at creation.
 #include "models.h"
+#include "chain_plan.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -351,33 +352,18 @@ void Model::chain_record(const ConvArgs& a, const ConvLayer& L) {
   const char* wbase = a.cout_pad == 32 ? reinterpret_cast<const char*>(a.wpk) : L.wch.as<char>();
   ChainLayerRec rec{(int)chain_items.size(), groups, a.out + (size_t)a.out_plane0 * a.out_plane_bytes,
                     a.out + (size_t)(a.out_plane0 + a.cout_pad / 16) * a.out_plane_bytes, a.flops};
-  // K-chunks whose planes the PREVIOUS chain layer wrote: they must form the tail of the K loop (the dense block's newest
-  // growth planes do); anything else is polled for in front of the first chunk
+  // which K-chunks wait for what: chain_plan.h (pure host logic, unit-tested on the CPU)
   const int kl = (int)chain_layers.size();
   const unsigned cum_k = (unsigned)chain_items.size();                                  // units per tile of layers < k
   const unsigned cum_km1 = kl >= 1 ? (unsigned)chain_layers[kl - 1].first_item : 0u;    // ... of layers < k - 1
-  int newest = 0; unsigned need_old = cum_km1, need_new = cum_k;
-  if (kl >= 1) {
-    const ChainLayerRec& pv = chain_layers.back();
-    auto plane_of = [&](int c) {
-      return c < a.nchunks0 ? a.in0 + (size_t)(a.in0_plane0 + c) * a.in0_plane_bytes
-                            : a.in1 + (size_t)(a.in1_plane0 + c - a.nchunks0) * a.in1_plane_bytes;
-    };
-    auto is_new = [&](int c) { const char* pl = plane_of(c); return pl >= pv.out_lo && pl < pv.out_hi; };
-    int first = nch;
-    for (int c = nch - 1; c >= 0 && is_new(c); --c) first = c;
-    bool suffix_only = true;
-    for (int c = 0; c < first; ++c) suffix_only = suffix_only && !is_new(c);
-    newest = (suffix_only && first >= 2 && first < nch) ? first : 0;
-    // conv1 of an RDB: EVERY chunk is the previous layer's (conv5's) output, which came from two units per tile - planes 0-1
-    // from the first cout group, planes 2-3 from the second, published in that order (pub_need).  Chunks 0-1 then only wait
-    // for the first group's units (one unit short of the whole previous layer), chunks 2-3 for the second's: the unit starts
-    // without blocking and the wait for the second group hides under the first two chunks
-    if (pv.nitems == 2 && nch == 4 && a.nchunks1 == 0 && is_new(0) && plane_of(0) == pv.out_lo &&
-        plane_of(2) == pv.out_lo + 2 * a.in0_plane_bytes) {
-      newest = 2; need_old = cum_k - 1; need_new = cum_k;
-    }
-  }
+  std::vector<const char*> chunk_planes(nch);
+  for (int c = 0; c < nch; ++c)
+    chunk_planes[c] = c < a.nchunks0 ? a.in0 + (size_t)(a.in0_plane0 + c) * a.in0_plane_bytes
+                                     : a.in1 + (size_t)(a.in1_plane0 + c - a.nchunks0) * a.in1_plane_bytes;
+  ChainPrevLayer pvl{};
+  if (kl >= 1) pvl = ChainPrevLayer{chain_layers.back().out_lo, chain_layers.back().out_hi, chain_layers.back().nitems};
+  const ChainLayerPlan plan = chain_plan_layer(chunk_planes, kl >= 1 ? &pvl : nullptr, a.in0_plane_bytes, cum_k, cum_km1);
+  const int newest = plan.newest; const unsigned need_old = plan.need_old, need_new = plan.need_new;
   for (int g = 0; g < groups; ++g) {
     ChainItem it{};
     it.in0 = a.in0; it.in0_plane_bytes = a.in0_plane_bytes; it.in0_plane0 = a.in0_plane0; it.nchunks0 = a.nchunks0;
