@@ -136,6 +136,7 @@ struct ConvArgs {
                                         // over concurrent launches); N counts this launch's frames
   float grid_share;                     // size the persistent grid for this share of the chip's workgroup slots (0 = all)
   int mb_override;                      // 0: tile height of the 32-cout layers by image height; 4 / 5: rows per wave forced (A/B)
+  int s3;                               // 32-cout layers without residuals on the three-stage kernel (conv_s3.hip)
   int ups2;                             // input is the nearest-x2 upsampling of an (H/2, W/2) tensor
   const void* wpk;                      // packed weights [group][chunk][dx,ks][dy][nb][lane][E]
   const void* wrs;                      // conv_rs.hip layout [group][cout group][chunk32][tap][cb][lane][8] or null
@@ -195,6 +196,9 @@ int conv_chain_tiles(int N, int H, int W, int rows_per_wave, int* tiles_x, int* 
 // launchers (conv_mfma.hip)
 void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a, int dtype, hipStream_t st);
 int conv_cw(int dtype);  // channels per plane / K-chunk: 16
+// three-stage-ring build of the 32-cout tile body (conv_s3.hip)
+bool conv3x3_s3_eligible(const ConvArgs& a, int dtype);
+void launch_conv3x3_s3(ss4k_ctx* ctx, const ConvArgs& a, hipStream_t st);
 // register-stationary-weights kernel (conv_rs.hip): fp16, plain epilogue, selected layer shapes
 bool rs_config(int nplanes, int cout_pad, bool wide, int* nch, int* rows, int* cb, int* cg);
 void launch_conv3x3_rs(ss4k_ctx* ctx, const ConvArgs& a, hipStream_t st);

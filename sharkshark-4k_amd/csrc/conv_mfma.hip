@@ -780,6 +780,9 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
     const bool mb5 = dtype == SS4K_F16 && nb == 1 && ek == EK_PLAIN &&
                      (a.mb_override ? a.mb_override == 5 : (waste(20) < waste(16) - 1e-9 && tiles20 >= 2LL * ctx->num_cu));
 #ifdef SS4K_DEV
+    // experiment (SS4K_S3=1, dev library): three-stage ring of halo tiles, conv_s3.hip
+    if (a.s3 && conv3x3_s3_eligible(a, dtype)) launch_conv3x3_s3(ctx, a, st);
+    else
     // experiment (SS4K_MB=3, dev library): 12-row tiles at THREE workgroups per CU for the 32-cout layers
     if (a.mb_override == 3 && dtype == SS4K_F16 && nb == 1 && ek == EK_PLAIN) launch_t<__half, 1, 3, 4, 0, EK_PLAIN>(ctx, a, groups, st);
     else

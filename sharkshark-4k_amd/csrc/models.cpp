@@ -203,6 +203,7 @@ void Model::build(const float* w, size_t n) {
   if (const char* e = std::getenv("SS4K_RS_MASK")) rs_mask = std::atoi(e);       // A/B switch: which layer shapes take conv_rs.hip
   if (const char* e = std::getenv("SS4K_RS_W8")) rs_wide = e[0] == '1';          // A/B switch: eight-wave variants of the 32-cout shapes
   if (const char* e = std::getenv("SS4K_MB")) mb_override = std::atoi(e);
+  if (const char* e = std::getenv("SS4K_S3")) use_s3 = e[0] == '1';
   if (const char* e = std::getenv("SS4K_LANE_GRID")) lane_grid_share = (float)std::atof(e);   // A/B switch: grid of a lane's launch as a share of the chip's slots
   if (const char* e = std::getenv("SS4K_FAIL_AT_CONV")) fail_at_conv = std::atoi(e);   // fault injection: the k-th conv call of every
                                                                                         // other forward throws (tests the unwind of a forked forward)
@@ -304,7 +305,7 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
   a.bsvd_resid = o.bsvd_resid;
   a.epi = o.epi; a.out = o.out.p; a.out_plane_bytes = o.out.plane_bytes; a.out_plane0 = o.out.plane0;
   a.cout_real = L.cout_real; a.cout_pad = L.cout_pad;
-  a.dbg = dbg; a.dbg_buf = dbg_buf; a.mb_override = mb_override;
+  a.dbg = dbg; a.dbg_buf = dbg_buf; a.mb_override = mb_override; a.s3 = use_s3 ? 1 : 0;
   a.reverse = (flip_walk && (launch_parity ^= 1)) ? 1 : 0;
   const double flops = 2.0 * 9.0 * L.cin_real * L.cout_real * (double)H * W * (o.epi == EPI_NHWC_SUB2 ? 0.25 : 1.0);
   if (ctx->prof && !section_open) {   // conv section of this forward: first conv launch ... end of the last one, on the caller's stream
