@@ -137,6 +137,7 @@ struct ConvArgs {
   float grid_share;                     // size the persistent grid for this share of the chip's workgroup slots (0 = all)
   int mb_override;                      // 0: tile height of the 32-cout layers by image height; 4 / 5: rows per wave forced (A/B)
   int s3;                               // 32-cout layers without residuals on the three-stage kernel (conv_s3.hip)
+  int no_band;                          // dev experiment: tiles dealt round-robin over the workgroups instead of one contiguous band per XCD
   int ups2;                             // input is the nearest-x2 upsampling of an (H/2, W/2) tensor
   const void* wpk;                      // packed weights [group][chunk][dx,ks][dy][nb][lane][E]
   const void* wrs;                      // conv_rs.hip layout [group][cout group][chunk32][tap][cb][lane][8] or null

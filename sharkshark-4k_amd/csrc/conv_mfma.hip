@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
   // XCD-aware persistent tile walk: workgroups b and b+8 share an XCD (and its L2); give each XCD
   // a contiguous band of tiles so halo rows and the planes a layer just wrote are re-read from
   // the same L2.  Placement only changes speed, never results.
-  const bool banded = (gridDim.x % 8 == 0) && ntiles >= (int)gridDim.x;
+  const bool banded = (gridDim.x % 8 == 0) && ntiles >= (int)gridDim.x && !a.no_band;
   const int tpx = (ntiles + 7) / 8;
   // a.reverse walks the same tiles back to front (inside each XCD's band, so the band -> XCD map
   // stays): consecutive layers alternate direction, and a layer starts on the planes the previous

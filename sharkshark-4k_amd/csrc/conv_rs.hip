@@ -61,7 +61,7 @@ struct RsArgs {
   char* out; size_t out_plane_bytes;
   const char* res1; size_t r1_plane_bytes;
   const char* res2; size_t r2_plane_bytes;
-  int N, n0, H, W, ups2, tiles_x, tiles_y, reverse;   // n0: first frame of this launch (frame lanes)
+  int N, n0, H, W, ups2, tiles_x, tiles_y, reverse, no_band;   // n0: first frame of this launch (frame lanes)
   float slope, alpha, gamma;       // slope: LeakyReLU slope, 1 = no activation (PReLU: per channel, `prelu`)
 };
 
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64 * (TH / ROWS) * CG, (TH / ROWS) * CG / 4) void c
 
   // XCD-aware persistent tile walk (same as conv_mfma.hip): workgroups b and b+8 share an XCD; each
   // XCD gets a contiguous band of tiles.  Placement only changes speed, never results.
-  const bool banded = (gridDim.x % 8 == 0) && ntiles >= (int)gridDim.x;
+  const bool banded = (gridDim.x % 8 == 0) && ntiles >= (int)gridDim.x && !a.no_band;
   const int tpx = (ntiles + 7) / 8;
   auto tile_of = [&](int k) __attribute__((always_inline)) -> int {
     if (!banded) {
@@ -510,7 +510,7 @@ static void launch_t(ss4k_ctx* ctx, const ConvArgs& c, hipStream_t st) {
   a.out = c.out + (size_t)c.out_plane0 * c.out_plane_bytes; a.out_plane_bytes = c.out_plane_bytes;
   a.res1 = c.res1 ? c.res1 + (size_t)c.r1_plane0 * c.r1_plane_bytes : nullptr; a.r1_plane_bytes = c.r1_plane_bytes;
   a.res2 = c.res2 ? c.res2 + (size_t)c.r2_plane0 * c.r2_plane_bytes : nullptr; a.r2_plane_bytes = c.r2_plane_bytes;
-  a.N = c.N; a.n0 = c.n0; a.H = c.H; a.W = c.W; a.ups2 = c.ups2; a.reverse = c.reverse;
+  a.N = c.N; a.n0 = c.n0; a.H = c.H; a.W = c.W; a.ups2 = c.ups2; a.reverse = c.reverse; a.no_band = c.no_band;
   a.tiles_x = (c.W + TW - 1) / TW;
   a.tiles_y = (c.H + TH - 1) / TH;
   a.slope = c.act == ACT_LRELU ? c.slope : 1.f; a.alpha = c.alpha; a.gamma = c.gamma;

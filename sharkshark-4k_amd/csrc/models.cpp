@@ -306,6 +306,10 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
   a.epi = o.epi; a.out = o.out.p; a.out_plane_bytes = o.out.plane_bytes; a.out_plane0 = o.out.plane0;
   a.cout_real = L.cout_real; a.cout_pad = L.cout_pad;
   a.dbg = dbg; a.dbg_buf = dbg_buf; a.mb_override = mb_override; a.s3 = use_s3 ? 1 : 0;
+#ifdef SS4K_DEV
+  static const bool no_band = std::getenv("SS4K_NO_BAND") && std::getenv("SS4K_NO_BAND")[0] == '1';
+  a.no_band = no_band ? 1 : 0;
+#endif
   a.reverse = (flip_walk && (launch_parity ^= 1)) ? 1 : 0;
   const double flops = 2.0 * 9.0 * L.cin_real * L.cout_real * (double)H * W * (o.epi == EPI_NHWC_SUB2 ? 0.25 : 1.0);
   if (ctx->prof && !section_open) {   // conv section of this forward: first conv launch ... end of the last one, on the caller's stream
