@@ -300,6 +300,18 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_
   const fp16x2v pl = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf(h0, -2048.f, x0 * 2048.f), __builtin_fmaf(h1, -2048.f, x1 * 2048.f));
   hi = __builtin_bit_cast(uint32_t, ph); lo = __builtin_bit_cast(uint32_t, pl);
 }
+// fp16 mode (desc.dtype == SS4K_F16, the precision the reference's TensorRT engine runs this network in): operands are the
+// round-to-nearest fp16 of the value, one MFMA per product, fp32 accumulation; no lo part anywhere
+__device__ __forceinline__ uint32_t half2_rne(float x0, float x1) {
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
+  const f32x2v v = {x0, x1};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h16x2v));
+}
+template <bool SPLIT>
+__device__ __forceinline__ void pack2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  if constexpr (SPLIT) split2(x0, x1, hi, lo); else { hi = half2_rne(x0, x1); lo = 0u; }
+}
 __device__ __forceinline__ float dpp_shl1(float v) {   // lane i <- lane i + 1 (0 past the wave)
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
@@ -309,7 +321,7 @@ __device__ __forceinline__ float dpp_shr1(float v) {   // lane i <- lane i - 1
 
 template <int S> struct FsTailGeo { static constexpr int HALO = S == 2 ? 2 : 1, CI = 32 - 2 * HALO; };
 
-template <int S>
+template <int S, bool SPLIT>
 __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ in12, float* __restrict__ out,
                                                    const float* __restrict__ we, const float* __restrict__ be,
                                                    const float* __restrict__ ae, const float* __restrict__ wd, float bias,
@@ -345,7 +357,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
         const int i = 8 * (s4 & 1) + j + t, c = 32 * (s4 >> 1) + (i & 3) + 8 * (i >> 2) + 4 * kq;
         v[t] = (ord < (hs ? 36 : 45) && c < 56) ? wd[(ky * 9 + kx) * 56 + c] : 0.f;
       }
-      split2(v[0], v[1], vh[j >> 1], vl[j >> 1]);
+      pack2<SPLIT>(v[0], v[1], vh[j >> 1], vl[j >> 1]);
     }
     wd_hi[e] = make_uint4(vh[0], vh[1], vh[2], vh[3]); wd_lo[e] = make_uint4(vl[0], vl[1], vl[2], vl[3]);
   }
@@ -357,7 +369,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
       float v[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) { const int kin = 8 * kq + j + t; v[t] = (ch < 56 && kin < 12) ? we[kin * 56 + ch] : 0.f; }
-      split2(v[0], v[1], vh[j >> 1], vl[j >> 1]);
+      pack2<SPLIT>(v[0], v[1], vh[j >> 1], vl[j >> 1]);
     }
     we_hi[tid] = make_uint4(vh[0], vh[1], vh[2], vh[3]); we_lo[tid] = make_uint4(vl[0], vl[1], vl[2], vl[3]);
   }
@@ -373,11 +385,18 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
   const bool col_ok = px >= 0 && px < w;
   const bool interior = p >= HALO && p < 32 - HALO && px < w;
   // this lane's 8 input channels of its pixel (half 0: channels 0-7, half 1: 8-11 + zeros), fetched one row ahead
+  // (fp16 mode: the 12-channel tensor is fp16, 8 bytes per pixel and group; .x/.y of a0 and a1 carry the packed pairs)
   auto load_x = [&](int yy, float4& a0, float4& a1) {
     a0 = a1 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (yy >= 0 && yy < h && col_ok) {
-      const float4* src = reinterpret_cast<const float4*>(in12) + (size_t)plane * plane_px + (size_t)yy * w + px;
-      if (hh == 0) { a0 = src[0]; a1 = src[total]; } else a0 = src[2 * total];
+      if constexpr (SPLIT) {
+        const float4* src = reinterpret_cast<const float4*>(in12) + (size_t)plane * plane_px + (size_t)yy * w + px;
+        if (hh == 0) { a0 = src[0]; a1 = src[total]; } else a0 = src[2 * total];
+      } else {
+        const float2* src = reinterpret_cast<const float2*>(in12) + (size_t)plane * plane_px + (size_t)yy * w + px;
+        if (hh == 0) { const float2 u = src[0], v = src[total]; a0.x = u.x; a0.y = u.y; a1.x = v.x; a1.y = v.y; }
+        else { const float2 u = src[2 * total]; a0.x = u.x; a0.y = u.y; }
+      }
     }
   };
   typedef float fvS __attribute__((ext_vector_type(S)));
@@ -394,7 +413,12 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
     load_x(y + 1, n0, n1);
     if (row_ok) {
       uint4 xh, xl;
-      split2(g0.x, g0.y, xh.x, xl.x); split2(g0.z, g0.w, xh.y, xl.y); split2(g1.x, g1.y, xh.z, xl.z); split2(g1.z, g1.w, xh.w, xl.w);
+      if constexpr (SPLIT) {
+        split2(g0.x, g0.y, xh.x, xl.x); split2(g0.z, g0.w, xh.y, xl.y); split2(g1.x, g1.y, xh.z, xl.z); split2(g1.z, g1.w, xh.w, xl.w);
+      } else {
+        xh = make_uint4(__float_as_uint(g0.x), __float_as_uint(g0.y), __float_as_uint(g1.x), __float_as_uint(g1.y));
+        xl = make_uint4(0u, 0u, 0u, 0u);
+      }
       const f16x8v bxh = __builtin_bit_cast(f16x8v, xh), bxl = __builtin_bit_cast(f16x8v, xl);
       // E' = PReLU(We * X + be), split again: B operands of the four k-steps of the second product
       uint4 ebh[4], ebl[4];
@@ -408,8 +432,11 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
         }
         const f16x8v ah = __builtin_bit_cast(f16x8v, we_hi[b * 64 + lane]), al = __builtin_bit_cast(f16x8v, we_lo[b * 64 + lane]);
         E1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bxh, E1, 0, 0, 0);
-        f32x16v E2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bxl, zero16, 0, 0, 0);
-        E2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bxh, E2, 0, 0, 0);
+        f32x16v E2 = zero16;
+        if constexpr (SPLIT) {
+          E2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bxl, zero16, 0, 0, 0);
+          E2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bxh, E2, 0, 0, 0);
+        }
         float ev[16];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -417,7 +444,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
           const float sv[4] = {sl.x, sl.y, sl.z, sl.w};
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const float v = fmaf(E2[4 * k + t], LO, E1[4 * k + t]);
+            const float v = SPLIT ? fmaf(E2[4 * k + t], LO, E1[4 * k + t]) : E1[4 * k + t];
             ev[4 * k + t] = col_ok ? prelu(v, sv[t]) : 0.f;   // a column outside the image contributes nothing
           }
         }
@@ -425,7 +452,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
         for (int q = 0; q < 2; ++q) {
           uint32_t hq[4], lq[4];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) split2(ev[8 * q + 2 * t], ev[8 * q + 2 * t + 1], hq[t], lq[t]);
+          for (int t = 0; t < 4; ++t) pack2<SPLIT>(ev[8 * q + 2 * t], ev[8 * q + 2 * t + 1], hq[t], lq[t]);
           ebh[2 * b + q] = make_uint4(hq[0], hq[1], hq[2], hq[3]); ebl[2 * b + q] = make_uint4(lq[0], lq[1], lq[2], lq[3]);
         }
       }
@@ -438,11 +465,13 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
           const f16x8v ah = __builtin_bit_cast(f16x8v, wd_hi[(tb * 4 + s4) * 64 + lane]), al = __builtin_bit_cast(f16x8v, wd_lo[(tb * 4 + s4) * 64 + lane]);
           const f16x8v bh = __builtin_bit_cast(f16x8v, ebh[s4]), bl = __builtin_bit_cast(f16x8v, ebl[s4]);
           T1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, T1, 0, 0, 0);
-          T2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, T2, 0, 0, 0);
-          T2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, T2, 0, 0, 0);
+          if constexpr (SPLIT) {
+            T2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, T2, 0, 0, 0);
+            T2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, T2, 0, 0, 0);
+          }
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) T[tb][i] = fmaf(T2[i], LO, T1[i]);
+        for (int i = 0; i < 16; ++i) T[tb][i] = SPLIT ? fmaf(T2[i], LO, T1[i]) : T1[i];
       }
       // horizontal overlap-add in registers, then into the rows under construction
 #pragma unroll
@@ -478,6 +507,163 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// fp16-mode head: conv5x5(1->56)+PReLU -> conv1x1(56->12)+PReLU on v_mfma_f32_32x32x16_f16, fp16 operands, fp32 accumulation.
+//
+// A wave marches down a band of rows of a strip of 128 columns, on its own (a private ring of 8 input rows in LDS, fp16, zero
+// outside the image: no barriers).  First product, per 32 pixels: D[32 couts x 32 px] += A[32 x 16] * B[16 x 32 px], K = kernel row
+// dy (6 slots, 5 real) x 8 consecutive input columns: lane (n, kq) of K-step s supplies input row y - 2 + 2s + kq, columns
+// P + 2n - 2 .. P + 2n + 5 - ONE 16-byte window (4-byte aligned) that serves pixel P + 2n (taps in slots 0-4) AND pixel P + 2n + 1
+// (slots 1-5): two weight operands (shift 0 / 1), one pixel operand.  The bias rides in the spare K slot (s = 2, kq = 1 is
+// kernel row 5, which does not exist): its pixel operand is the constant 1 and its weight the bias; padded cout 56 has "bias"
+// 1 there, so the activation map carries a constant-1 channel that feeds the second product its bias the same way.
+// PReLU runs on packed fp16 (v_pk_max / min / fma_f16: 2 instructions per value with the conversion), and the packed activations
+// ARE the second product's B operand (same lane = same pixel; the shrink weights are permuted to the accumulator order, as in
+// the tail): D2[32 (12 real) x 32 px] = Ws[32 x 64] * E[64 x 32].  Output: fp16, group-major [3][pixel][4].
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+constexpr int FH_COLS = 128, FH_RING = 8, FH_ROWH = 136 + 8;   // ring row: columns X0 - 2 .. X0 + 133 (+ pad), fp16
+
+__device__ __forceinline__ uint32_t prelu_h2(uint32_t x, uint32_t a) {
+  const h16x2 v = __builtin_bit_cast(h16x2, x), sl = __builtin_bit_cast(h16x2, a), z = {(_Float16)0.f, (_Float16)0.f};
+  const h16x2 r = __builtin_elementwise_max(v, z) + sl * __builtin_elementwise_min(v, z);
+  return __builtin_bit_cast(uint32_t, r);
+}
+
+__global__ __launch_bounds__(256, 2) void k_fs_head_h(const float* __restrict__ in, uint2* __restrict__ out,
+                                                      const float* __restrict__ wf, const float* __restrict__ bf,
+                                                      const float* __restrict__ af, const float* __restrict__ ws,
+                                                      const float* __restrict__ bs, const float* __restrict__ as,
+                                                      int planes, int h, int w, int bands) {
+  __shared__ __attribute__((aligned(16))) _Float16 ring_all[4][FH_RING][FH_ROWH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, kq = lane >> 5;
+  const int strips = (w + FH_COLS - 1) / FH_COLS;
+  const int wid = blockIdx.x * 4 + wave;
+  const int strip = wid % strips, band = (wid / strips) % bands, plane = wid / (strips * bands);
+  const int rpb = (h + bands - 1) / bands, ylo = band * rpb, yhi = min(h, ylo + rpb);
+  if (plane >= planes || ylo >= yhi) return;   // whole waves leave: nothing below synchronises across waves
+  _Float16 (*ring)[FH_ROWH] = ring_all[wave];
+  const int X0 = strip * FH_COLS;
+
+  // first-product weights: [shift g][K-step s][cout block b]; lane (m = n, kq): slot j is tap (dy = 2s + kq, dx = j - g)
+  uint4 A1[2][3][2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int co = 32 * b + n, dy = 2 * s3 + kq;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int dx = j - g;
+          v[j] = 0.f;
+          if (dy < 5) { if (dx >= 0 && dx < 5 && co < 56) v[j] = wf[(dy * 5 + dx) * 56 + co]; }
+          else if (j == 0) v[j] = co < 56 ? bf[co] : co == 56 ? 1.f : 0.f;   // the bias slot (its pixel operand is the constant 1)
+        }
+        A1[g][s3][b] = make_uint4(half2_rne(v[0], v[1]), half2_rne(v[2], v[3]), half2_rne(v[4], v[5]), half2_rne(v[6], v[7]));
+      }
+  // second-product weights: K-step s4, slot j is the channel accumulator register i = 8*(s4&1) + j of block s4>>1 holds in lane half kq
+  uint4 A2[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = 8 * (s4 & 1) + j, ch = 32 * (s4 >> 1) + (i & 3) + 8 * (i >> 2) + 4 * kq;
+      v[j] = n < 12 ? (ch < 56 ? ws[ch * 12 + n] : ch == 56 ? bs[n] : 0.f) : 0.f;
+    }
+    A2[s4] = make_uint4(half2_rne(v[0], v[1]), half2_rne(v[2], v[3]), half2_rne(v[4], v[5]), half2_rne(v[6], v[7]));
+  }
+  // PReLU slopes of the channels this lane's accumulators hold, packed in pairs
+  uint32_t sl1[2][8], sl2[4];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      const int c0 = 32 * b + (i & 3) + 8 * (i >> 2) + 4 * kq;
+      sl1[b][i >> 1] = half2_rne(c0 < 56 ? af[c0] : 1.f, c0 + 1 < 56 ? af[c0 + 1] : 1.f);
+    }
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    const int c0 = (i & 3) + 8 * (i >> 2) + 4 * kq;
+    sl2[i >> 1] = half2_rne(c0 < 12 ? as[c0] : 1.f, c0 + 1 < 12 ? as[c0 + 1] : 1.f);
+  }
+
+  const size_t plane_px = (size_t)h * w, total = (size_t)planes * plane_px;
+  const float* src = in + (size_t)plane * plane_px;
+  uint2* dst = out + (size_t)plane * plane_px;
+  // loader: ring column c is image column X0 - 2 + c; a lane moves columns lane, lane + 64 and (lane < 8) lane + 128
+  auto fetch = [&](int y, float (&v)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int x = X0 - 2 + lane + 64 * k;
+      v[k] = (y >= 0 && y < h && x >= 0 && x < w && (k < 2 || lane < 8)) ? src[(size_t)y * w + x] : 0.f;
+    }
+  };
+  auto put = [&](int y, const float (&v)[3]) {
+    _Float16* row = ring[y & (FH_RING - 1)];
+    row[lane] = (_Float16)v[0]; row[lane + 64] = (_Float16)v[1];
+    if (lane < 8) row[lane + 128] = (_Float16)v[2];
+  };
+  float pre[3];
+  for (int y = ylo - 2; y < ylo + 2; ++y) { fetch(y, pre); put(y, pre); }
+  fetch(ylo + 2, pre);
+  const f32x16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const uint4 one_op = make_uint4(0x00003c00u, 0u, 0u, 0u);   // {1.0, 0, ...}: the bias slot's pixel operand
+  for (int y = ylo; y < yhi; ++y) {
+    put(y + 2, pre);
+    fetch(y + 3, pre);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int P = X0 + 64 * pass;
+      if (P >= w) break;   // wave-uniform
+      // pixel operands: 8 columns from ring column 64*pass + 2n of rows y - 2 + 2s + kq
+      uint4 B1[3];
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        const uint32_t* p32 = reinterpret_cast<const uint32_t*>(&ring[(y - 2 + 2 * s3 + kq) & (FH_RING - 1)][64 * pass + 2 * n]);
+        B1[s3] = make_uint4(p32[0], p32[1], p32[2], p32[3]);
+      }
+      if (kq == 1) B1[2] = one_op;
+      uint32_t o[2][4];   // [pixel parity][regs 0-1: channels of accumulator registers 0-3, 2-3: of registers 4-7]
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        uint32_t E[2][8];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          f32x16v acc = zero16;
+#pragma unroll
+          for (int s3 = 0; s3 < 3; ++s3)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A1[g][s3][b]), __builtin_bit_cast(f16x8v, B1[s3]), acc, 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) E[b][i >> 1] = prelu_h2(half2_rne(acc[i], acc[i + 1]), sl1[b][i >> 1]);
+        }
+        f32x16v d2 = zero16;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int b = s4 >> 1, o4 = 4 * (s4 & 1);
+          const uint4 e = make_uint4(E[b][o4], E[b][o4 + 1], E[b][o4 + 2], E[b][o4 + 3]);
+          d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A2[s4]), __builtin_bit_cast(f16x8v, e), d2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) o[g][i >> 1] = prelu_h2(half2_rne(d2[i], d2[i + 1]), sl2[i >> 1]);
+      }
+      // lane half 0 holds channel groups 0 (registers 0-3) and 2 (registers 4-7), lane half 1 group 1, of pixels P + 2n, P + 2n + 1
+      const int x = P + 2 * n;
+      uint2* row = dst + (size_t)y * w + x;
+      const size_t ga = (size_t)kq * total;
+      if (x + 1 < w) {
+        *reinterpret_cast<uint4*>(row + ga) = make_uint4(o[0][0], o[0][1], o[1][0], o[1][1]);
+        if (kq == 0) *reinterpret_cast<uint4*>(row + 2 * total) = make_uint4(o[0][2], o[0][3], o[1][2], o[1][3]);
+      } else if (x < w) {
+        row[ga] = make_uint2(o[0][0], o[0][1]);
+        if (kq == 0) row[2 * total] = make_uint2(o[0][2], o[0][3]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Production mapping stage: the four conv3x3(12->12)+PReLU layers in ONE kernel on the fp16 matrix rate (hi/lo-split
 // operands, three v_mfma_f32_16x16x32_f16 per product: see the tail above), intermediates never leaving the CU.
 //
@@ -495,6 +681,7 @@ constexpr int FM_ROWB = FM_RW * 64, FM_STAGEB = 4 * FM_ROWB, FM_LDS = 4 * FM_STA
 struct FsMapW { const float* w[4]; const float* b[4]; const float* a[4]; };
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ in, float* __restrict__ out, const FsMapW W,
                                                      int planes, int h, int w, int bands) {
   extern __shared__ __attribute__((aligned(16))) char fm_ring[];
@@ -523,7 +710,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
           const int tap = 2 * ks + (q >> 1), ch = 8 * (q & 1) + j + t2;
           v[t2] = (tap < 9 && ch < 12 && n < 12) ? wm[(tap * 12 + ch) * 12 + n] : 0.f;
         }
-        split2(v[0], v[1], vh[j >> 1], vl[j >> 1]);
+        pack2<SPLIT>(v[0], v[1], vh[j >> 1], vl[j >> 1]);
       }
       ah[ks] = make_uint4(vh[0], vh[1], vh[2], vh[3]); al[ks] = make_uint4(vl[0], vl[1], vl[2], vl[3]);
     }
@@ -557,18 +744,24 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
   const int lsw = ((lc + 1) >> 2) & 3;
   const int ld_hi = (lc + 1) * 64 + (((lg >> 1) ^ lsw) << 4) + 8 * (lg & 1);
   const int ld_lo = (lc + 1) * 64 + (((2 + (lg >> 1)) ^ lsw) << 4) + 8 * (lg & 1);
+  // (fp16 mode: input and output tensors are fp16, 8 bytes per pixel and group; a loaded row travels in .x/.y)
   auto load_row = [&](int r) -> float4 {   // relative row r = image row ylo - 4 + r
     const int y = ylo - 4 + r;
-    if (loader && lcol_ok && y >= 0 && y < h) return in4[lg * total + (size_t)y * w + lx];
-    return make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (loader && lcol_ok && y >= 0 && y < h) {
+      if constexpr (SPLIT) v = in4[lg * total + (size_t)y * w + lx];
+      else { const float2 u = (reinterpret_cast<const float2*>(in) + (size_t)plane * plane_px)[lg * total + (size_t)y * w + lx]; v.x = u.x; v.y = u.y; }
+    }
+    return v;
   };
   auto store_row = [&](int r, const float4& v) {
     if (!loader) return;
-    uint32_t h0, h1, l0, l1;
-    split2(v.x, v.y, h0, l0); split2(v.z, v.w, h1, l1);
+    uint32_t h0, h1, l0 = 0u, l1 = 0u;
+    if constexpr (SPLIT) { split2(v.x, v.y, h0, l0); split2(v.z, v.w, h1, l1); }
+    else { h0 = __float_as_uint(v.x); h1 = __float_as_uint(v.y); }
     char* row = fm_ring + (r & 3) * FM_ROWB;   // ring of layer 0
     *reinterpret_cast<uint2*>(row + ld_hi) = make_uint2(h0, h1);
-    *reinterpret_cast<uint2*>(row + ld_lo) = make_uint2(l0, l1);
+    if constexpr (SPLIT) *reinterpret_cast<uint2*>(row + ld_lo) = make_uint2(l0, l1);
   };
   __syncthreads();   // rings are zero
   store_row(0, load_row(0)); store_row(1, load_row(1));
@@ -604,7 +797,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
 #pragma unroll
           for (int ks = 0; ks < 5; ++ks) {
             fh[ks] = *reinterpret_cast<const uint4*>(ph[ks] + u * 1024);
-            fl[ks] = *reinterpret_cast<const uint4*>(pl[ks] + u * 1024);
+            if constexpr (SPLIT) fl[ks] = *reinterpret_cast<const uint4*>(pl[ks] + u * 1024);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -612,11 +805,13 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
             const f16x8v bh = __builtin_bit_cast(f16x8v, fh[ks]), bl = __builtin_bit_cast(f16x8v, fl[ks]);
             const f16x8v wh = __builtin_bit_cast(f16x8v, ah[ks]), wl = __builtin_bit_cast(f16x8v, al[ks]);
             d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh, d1, 0, 0, 0);
-            d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, d2, 0, 0, 0);
-            d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, d2, 0, 0, 0);
+            if constexpr (SPLIT) {
+              d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, d2, 0, 0, 0);
+              d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, d2, 0, 0, 0);
+            }
           }
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = prelu(fmaf(d2[i], LO, d1[i]), slo[i]);
+          for (int i = 0; i < 4; ++i) v[i] = prelu(SPLIT ? fmaf(d2[i], LO, d1[i]) : d1[i], slo[i]);
           const int xu = x0 - FM_HALO + 16 * u;   // wave-uniform: only units that straddle the image edge mask
           if (xu < 0 || xu + 15 >= w) {
             const bool ok = x >= 0 && x < w;       // a column outside the image is zero padding for the next layer
@@ -627,12 +822,13 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
         if (st < 3) {
           if (q < 3) {
             uint32_t h0, h1, l0, l1;
-            split2(v[0], v[1], h0, l0); split2(v[2], v[3], h1, l1);
+            pack2<SPLIT>(v[0], v[1], h0, l0); pack2<SPLIT>(v[2], v[3], h1, l1);
             *reinterpret_cast<uint2*>(dst + u * 1024 + wr_hi) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(dst + u * 1024 + wr_lo) = make_uint2(l0, l1);
+            if constexpr (SPLIT) *reinterpret_cast<uint2*>(dst + u * 1024 + wr_lo) = make_uint2(l0, l1);
           }
         } else if (row_in && q < 3 && y >= ylo && y < yhi && x >= x0 && x < x0 + FM_CI && x < w) {
-          out4[q * total + (size_t)y * w + x] = make_float4(v[0], v[1], v[2], v[3]);
+          if constexpr (SPLIT) out4[q * total + (size_t)y * w + x] = make_float4(v[0], v[1], v[2], v[3]);
+          else (reinterpret_cast<uint2*>(out) + (size_t)plane * plane_px)[q * total + (size_t)y * w + x] = make_uint2(half2_rne(v[0], v[1]), half2_rne(v[2], v[3]));
         }
       }
     }
@@ -641,7 +837,8 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
 }
 
 void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const float* in, float* out, int planes, int h,
-                    int w, float* ws12a, float* ws12b, bool exact, hipStream_t st) {
+                    int w, float* ws12a, float* ws12b, int mode, hipStream_t st) {
+  const bool exact = mode == FS_MODE_EXACT, half = mode == FS_MODE_HALF;
   const size_t total = (size_t)planes * h * w;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   // exact (SS4K_FS_EXACT=1 when the model was built): the exact-fp32 kernels - vector-ALU mapping layers, fp32-MFMA tail with
@@ -652,6 +849,15 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
   // per-stage timing for bench.py's stage rooflines (ss4k_prof_read_kind); algorithmic FLOPs per LR pixel and plane:
   // head 2 * (25 * 56 + 56 * 12), mapping 2 * 4 * 9 * 12 * 12, tail 2 * (12 * 56 + 81 * 56)  (12 464 MAC in all)
   ProfEvent pe = ctx->prof_begin(st, PROF_FS_HEAD);
+  if (half) {
+    const int hstrips = (w + FH_COLS - 1) / FH_COLS;
+    // two waves per SIMD over the chip, bands of at least 8 rows (every band re-reads 4 halo rows)
+    const int hb0 = std::max(1, std::min((h + 7) / 8, 8 * ctx->num_cu / std::max(1, planes * hstrips)));
+    const int hbands = (h + (h + hb0 - 1) / hb0 - 1) / ((h + hb0 - 1) / hb0);
+    const unsigned hwaves = (unsigned)(planes * hbands * hstrips);
+    hipLaunchKernelGGL(k_fs_head_h, dim3((hwaves + 3) / 4), block, 0, st, in, reinterpret_cast<uint2*>(ws12a), W.w_feat, W.b_feat,
+                       W.a_feat, W.w_shrink, W.b_shrink, W.a_shrink, planes, h, w, hbands);
+  } else
   hipLaunchKernelGGL(k_fs_head, grid, block, 0, st, in, ws12a, W.w_feat, W.b_feat, W.a_feat, W.w_shrink, W.b_shrink,
                      W.a_shrink, planes, h, w);
   ctx->prof_end(pe, st, 4144.0 * (double)total);
@@ -671,9 +877,12 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
     // at most one round of workgroups at three per CU (a second, partly filled round costs a whole march); every band
     // re-does 8 halo rows plus 6 steps of pipeline fill
     const int mbands = std::max(1, std::min((h + 31) / 32, 3 * ctx->num_cu / std::max(1, planes * mstrips)));
-    const void* fn = reinterpret_cast<const void*>(&k_fs_maps4);
-    if (ctx->lds_attr_set.insert(fn).second) SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, FM_LDS));
-    hipLaunchKernelGGL(k_fs_maps4, dim3((unsigned)(planes * mbands * mstrips)), block, FM_LDS, st, cur, nxt, mw, planes, h, w, mbands);
+    auto launch_maps = [&](auto kern) {
+      const void* fn = reinterpret_cast<const void*>(kern);
+      if (ctx->lds_attr_set.insert(fn).second) SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, FM_LDS));
+      hipLaunchKernelGGL(kern, dim3((unsigned)(planes * mbands * mstrips)), block, FM_LDS, st, cur, nxt, mw, planes, h, w, mbands);
+    };
+    if (half) launch_maps(&k_fs_maps4<false>); else launch_maps(&k_fs_maps4<true>);
     std::swap(cur, nxt);
   }
   ctx->prof_end(pe, st, 10368.0 * (double)total);
@@ -689,8 +898,8 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
     hipLaunchKernelGGL(kern, tgrid, block, lds, st, cur, out, W.w_expand, W.b_expand, W.a_expand, W.w_deconv, W.b_deconv,
                        planes, h, w, bands);
   };
-  if (factor == 2) { if (exact) launch_tail(k_fs_tail<2>, 2); else launch_tail(k_fs_tail_r<2>, 2); }
-  else { if (exact) launch_tail(k_fs_tail<4>, 4); else launch_tail(k_fs_tail_r<4>, 4); }
+  if (factor == 2) { if (exact) launch_tail(k_fs_tail<2>, 2); else if (half) launch_tail(k_fs_tail_r<2, false>, 2); else launch_tail(k_fs_tail_r<2, true>, 2); }
+  else { if (exact) launch_tail(k_fs_tail<4>, 4); else if (half) launch_tail(k_fs_tail_r<4, false>, 4); else launch_tail(k_fs_tail_r<4, true>, 4); }
   ctx->prof_end(pe, st, 10416.0 * (double)total);
   SS4K_HIP(hipGetLastError());
 }

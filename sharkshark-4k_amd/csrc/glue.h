@@ -56,7 +56,10 @@ struct FsrcnnWeights {
   const float* w_deconv; // [81][56]  (ky*9+kx), cin
   float b_deconv;
 };
+// mode: fp32 accuracy on the fp16 matrix rate (hi/lo-split operands, the default of an SS4K_F32 model), the exact-fp32 kernels, or
+// plain fp16 operands with fp32 accumulation (an SS4K_F16 model: the precision the reference's TensorRT engine runs FSRCNN in)
+enum { FS_MODE_SPLIT = 0, FS_MODE_EXACT = 1, FS_MODE_HALF = 2 };
 void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const float* in, float* out, int planes, int h,
-                    int w, float* ws12a, float* ws12b, bool exact, hipStream_t st);
+                    int w, float* ws12a, float* ws12b, int mode, hipStream_t st);
 
 }  // namespace ss4k

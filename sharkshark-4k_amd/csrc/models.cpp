@@ -74,7 +74,6 @@ static void validate_desc(const ss4k_model_desc& d) {
   switch (d.kind) {
     case SS4K_FSRCNN:
       SS4K_REQUIRE(d.scale == 2 || d.scale == 4, "FSRCNN scale must be 2 or 4");
-      SS4K_REQUIRE(d.dtype == SS4K_F32, "FSRCNN runs in fp32 (vector-ALU path)");
       break;
     case SS4K_RRDBNET:
       SS4K_REQUIRE(d.scale == 1 || d.scale == 2 || d.scale == 4, "RRDBNet scale must be 1, 2 or 4");
@@ -598,7 +597,8 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
     if (acts.size() < 2) acts.resize(2);
     if (plan_only) { plan_bytes.assign(2, px * 12 * 4); return; }
     acts[0].ensure(px * 12 * 4); acts[1].ensure(px * 12 * 4);
-    fsrcnn_forward(ctx, fsw, desc.scale, in, out, n, h, w, acts[0].as<float>(), acts[1].as<float>(), fs_exact, st);
+    fsrcnn_forward(ctx, fsw, desc.scale, in, out, n, h, w, acts[0].as<float>(), acts[1].as<float>(),
+                   fs_exact ? FS_MODE_EXACT : f16 ? FS_MODE_HALF : FS_MODE_SPLIT, st);
     return;
   }
   lanes_begin(n, h, w, st);

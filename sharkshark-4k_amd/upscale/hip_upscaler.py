@@ -42,7 +42,7 @@ class HipUpscalerService(BaseUpscalerService):
                  upscaler_model="realesrgan", batch_size=1, jit_mode="hip", lr_hr_resize=True,
                  # knobs the reference hard-codes
                  scale=4, model_name=None, dtype="f16", weights=None, checkpoint_dir: Optional[str] = None,
-                 lr_shape=None, single_mode=None, seed=0):
+                 lr_shape=None, single_mode=None, seed=0, model_flags=0):
         if jit_mode not in (None, "hip"):
             raise Exception(f"jit_mode={jit_mode!r}: this build has one backend, 'hip'")
         if upscaler_model not in ("fsrcnn", "realesrgan"):
@@ -67,6 +67,7 @@ class HipUpscalerService(BaseUpscalerService):
         self.weights = weights if isinstance(weights, str) or weights is None else dict(weights)
         self.checkpoint_dir = checkpoint_dir
         self.seed = seed
+        self.model_flags = int(model_flags)  # SS4K_MODEL_* routing switches for the SR model (include/ss4k.h)
         super().__init__()
 
     # worker side -----------------------------------------------------------------------------
@@ -87,7 +88,7 @@ class HipUpscalerService(BaseUpscalerService):
             self.model = factory.build_model_esrgan(
                 self.ctx, model_name=self.model_name or factory.DEFAULT_REALESRGAN, denoise_rate=self.denoise_rate,
                 weights=spec("sr"), weights_wdn=spec("sr_wdn") if self.weights != "synthetic" else None, dtype=self.dtype,
-                seed=self.seed, checkpoint_dir=self.checkpoint_dir)
+                seed=self.seed, checkpoint_dir=self.checkpoint_dir, flags=self.model_flags)
         self.denoise_model = None
         # quirk kept from the reference: with 'realesrgan' the batched path never denoises even when
         # denoising=True (fsrcnn_upscaler.py:109,168-233); the BSVD model is only used per-frame.

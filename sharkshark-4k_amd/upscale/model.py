@@ -83,9 +83,11 @@ def fsrcnn_table_from(weights: WeightSpec, factor: int = 4, seed: int = 0, check
 
 
 def build_model_fsrcnn(ctx: _capi.Context, factor: int = 4, weights: WeightSpec = None, seed: int = 0,
-                       checkpoint_dir: Optional[str] = None):
+                       checkpoint_dir: Optional[str] = None, dtype="f32", flags: int = 0):
+    """dtype 'f32' (default): fp32 accuracy (the 1e-3 / 1e-4 parity bar against the CPU forward).  'f16': fp16 operands with
+    fp32 accumulation - the precision the reference's TensorRT engine runs this network in (fsrcnn/factory.py:47-69)."""
     table = fsrcnn_table_from(weights, factor, seed, checkpoint_dir)
-    desc = _capi.make_desc(_capi.FSRCNN, _capi.F32, scale=factor)
+    desc = _capi.make_desc(_capi.FSRCNN, _dtype(dtype), scale=factor, flags=flags)
     return _capi.Model(ctx, desc, W.flatten(table, W.fsrcnn_keys()))
 
 
@@ -123,14 +125,15 @@ def esrgan_table_from(model_name: str = DEFAULT_REALESRGAN, denoise_rate: float 
 
 def build_model_esrgan(ctx: _capi.Context, model_name: str = DEFAULT_REALESRGAN, denoise_rate: float = 0.5,
                        weights: WeightSpec = None, dtype="f16", seed: int = 0, weights_wdn: WeightSpec = None,
-                       checkpoint_dir: Optional[str] = None, **arch_overrides):
+                       checkpoint_dir: Optional[str] = None, flags: int = 0, **arch_overrides):
+    """flags: SS4K_MODEL_* routing switches (include/ss4k.h), e.g. _capi.MODEL_CHAIN for 1-2-frame RRDBNet jobs."""
     arch, kw, table = esrgan_table_from(model_name, denoise_rate, weights, seed, weights_wdn, checkpoint_dir, **arch_overrides)
     if arch == "rrdbnet":
         desc = _capi.make_desc(_capi.RRDBNET, _dtype(dtype), scale=kw["scale"], num_feat=kw["num_feat"],
-                               num_block=kw["num_block"], num_grow_ch=kw["num_grow_ch"])
+                               num_block=kw["num_block"], num_grow_ch=kw["num_grow_ch"], flags=flags)
         return _capi.Model(ctx, desc, W.flatten(table, W.rrdbnet_keys(kw["num_block"])))
     desc = _capi.make_desc(_capi.SRVGG, _dtype(dtype), scale=kw["upscale"], num_feat=kw["num_feat"],
-                           num_block=kw["num_conv"])
+                           num_block=kw["num_conv"], flags=flags)
     return _capi.Model(ctx, desc, W.flatten(table, W.srvgg_keys(kw["num_conv"])))
 
 

@@ -96,3 +96,19 @@ def test_chain_two_contexts_on_two_streams_do_not_deadlock(ctx):
         assert torch.equal(o, want)
     del m2
     ctx2.close()
+
+
+def test_service_model_flags_route_to_the_chain(ctx):
+    """The drop-in service passes model_flags through to the library: a one-frame realesrgan job with
+    model_flags=MODEL_CHAIN gives the uint8 frames of the default route within 1 LSB (conv5's summation order differs)."""
+    from sharkshark4k_amd.upscale.hip_upscaler import HipUpscalerService
+    tab = W.rrdbnet_table(13, scale=2)
+    frames = torch.from_numpy(smooth_u8(7, (1, 72, 104, 3))).cuda()
+    outs = []
+    for fl in (0, CHAIN):
+        svc = HipUpscalerService(device=0, denoising=False, upscaler_model="realesrgan", scale=2, lr_shape=(72, 104),
+                                 model_name="RealESRGAN_x2plus", weights={"sr": tab}, lr_hr_resize=False, model_flags=fl)
+        svc.proc_init()
+        outs.append(svc.upscale(frames).cpu().to(torch.int16))
+    assert outs[0].shape == (1, 144, 208, 3)
+    assert int((outs[0] - outs[1]).abs().max()) <= 1

@@ -14,7 +14,7 @@ from sharkshark4k_amd.upscale import model as factory
 from oracle import nets as onets
 from oracle import service as osvc
 from tests.conftest import load_golden, manifest
-from tests.helpers import assert_close, assert_u8_close, psnr, rrdb_small_table, smooth_u8
+from tests.helpers import assert_close, assert_u8_close, psnr, record_measured, rrdb_small_table, smooth_u8
 from tests.test_oracle_golden import _t91, oracle_service_from_manifest
 
 pytestmark = pytest.mark.gpu
@@ -576,3 +576,24 @@ def test_fused_tails_full_size_identical(ctx):
     a, b = up_f(frames), up_u(frames)
     d = (a.int() - b.int()).abs()
     assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-4, (int(d.max()), float((d > 0).float().mean()))
+
+
+# ------------------------------------------------------------------------------ FSRCNN in fp16 (the reference engine's precision)
+@pytest.mark.parametrize("factor,tag,shape", [(2, "t91", (3, 1, 150, 333)), (4, "t91", (3, 1, 97, 130)), (2, "syn", (12, 1, 64, 260)),
+                                              (2, "syn", (1, 1, 5, 7)), (4, "syn", (2, 1, 33, 129)), (2, "t91", (1, 1, 256, 256))])
+def test_fsrcnn_f16_mode_vs_oracle(ctx, factor, tag, shape):
+    """dtype f16 (fp16 operands, fp32 accumulation, fp16 intermediates; head on MFMA with the bias in a spare K slot): judged by
+    PSNR against the fp32 CPU forward, like the fp16 RRDBNet path; ragged shapes cover partial strips, bands and both tile parities."""
+    table = _t91(factor) if tag == "t91" else W.fsrcnn_table(seed=factor)
+    m = factory.build_model_fsrcnn(ctx, factor=factor, weights=table, dtype="f16")
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[2]))
+    with torch.no_grad():
+        want = onets.fsrcnn(x, table, factor)
+    got = m(x.cuda()).float().cpu()
+    assert got.shape == want.shape and torch.isfinite(got).all()
+    peak = float(want.abs().max())
+    p = psnr(got / peak, want / peak)
+    err = float((got - want).abs().max())
+    record_measured(f"fsrcnn_f16_x{factor}_{tag}_{shape[2]}x{shape[3]}", psnr_db=p, max_abs_err=err, peak=peak)
+    print(f"fsrcnn f16 x{factor} {tag} {shape}: PSNR {p:.1f} dB, max |d| {err:.3g} of peak {peak:.3g}")
+    assert p > 55.0 and err < 1e-2 * max(1.0, peak)
