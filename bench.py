@@ -17,6 +17,7 @@ BEFORE it touches any GPU, waits for them and relays rank 0's JSON line.  Prints
 from __future__ import annotations
 
 import argparse
+import math
 import json
 import os
 import sys
@@ -41,6 +42,7 @@ CONV_KERNEL_NAME = ("3x3 implicit-GEMM conv, all launches of a step: ss4k::conv3
 
 WORKLOADS = {
     "rrdbnet": "RealESRGAN RRDBNet x2 (23 blocks) 720p->1440p fp16 [BASELINE configs[2]]",
+    "fsrcnn_f16": "FSRCNN x2 720p->1440p in the reference engine's precision: fp16 operands and intermediates, fp32 accumulation; all three stages on fp16 MFMA (dtype f16; PSNR against the fp32 CPU forward reported) [BASELINE configs[1] at TensorRT-fp16 precision]",
     "fsrcnn": "FSRCNN x2 720p->1440p, fp32 tensors; head exact fp32 (vector ALUs), mapping + transposed conv on fp16 MFMA with hi/lo-split operands and fp32 accumulation (fp32-grade: ~1e-6 of the exact kernels) [BASELINE configs[1]]",
     "pipeline": "BSVD denoise + RealESRGAN RRDBNet x2 720p->1440p fp16, per-frame path [BASELINE configs[3]]",
     "srvgg": "SRVGGNetCompact realesr-general-x4v3 x4 + bicubic to 1440p fp16 (the reference's shipped default)",
@@ -56,10 +58,10 @@ def build_upscaler(ctx, workload, device, lr_shape=(720, 1280), flags=0):
         n = sum(int(np.prod(v.shape)) for v in table.values()) if table is not None else 0
         return flat, n
     rank = int(os.environ.get("RANK", "0"))
-    if workload == "fsrcnn":
+    if workload in ("fsrcnn", "fsrcnn_f16"):
         table = W.fsrcnn_table(0)
         flat = sharding.broadcast_weights(W.flatten(table, W.fsrcnn_keys()) if rank == 0 else None, 12809, device)
-        sr = _capi.Model(ctx, _capi.make_desc(_capi.FSRCNN, _capi.F32, scale=2), flat)
+        sr = _capi.Model(ctx, _capi.make_desc(_capi.FSRCNN, _capi.F16 if workload == "fsrcnn_f16" else _capi.F32, scale=2), flat)
         up = _capi.Upscaler(ctx, sr, lr_shape, None, True, True, None, 1.0)
         return up, (sr,), 74784.0 * px
     if workload in ("rrdbnet", "pipeline"):
@@ -105,11 +107,12 @@ def cpu_baseline(workload, gpu_ctx, seconds_budget=14.0):
     # a short sweep on a 180x320 crop (below)
     ncores = os.cpu_count() or 1
     torch.set_num_threads(min(16, ncores))
-    if workload == "fsrcnn":
+    if workload in ("fsrcnn", "fsrcnn_f16"):
         table = W.fsrcnn_table(0)
         def make(crop):
             osv = osvc.OracleUpscaler(lambda x: onets.fsrcnn(x, table, 2), upscaler_model="fsrcnn", lr_shape=crop)
-            sr = _capi.Model(gpu_ctx, _capi.make_desc(_capi.FSRCNN, _capi.F32, scale=2), W.flatten(table, W.fsrcnn_keys()))
+            sr = _capi.Model(gpu_ctx, _capi.make_desc(_capi.FSRCNN, _capi.F16 if workload == "fsrcnn_f16" else _capi.F32, scale=2),
+                             W.flatten(table, W.fsrcnn_keys()))
             return osv, _capi.Upscaler(gpu_ctx, sr, crop, None, True, True, None, 1.0), sr
     else:
         table = W.rrdbnet_table(0, scale=2)
@@ -247,18 +250,23 @@ def conv_roofline(ctx, up, frames, out, psteps=3):
             "concurrent_launches": ms / sec_ms, "conv_ms_per_step": sec_ms / psteps}
 
 
-def fsrcnn_stage_rooflines(ctx, up, frames, out, psteps=3):
+def fsrcnn_stage_rooflines(ctx, up, frames, out, psteps=3, half=False):
     """FSRCNN's three stages timed live (events around each stage on the launch stream), each against the unit that bounds it:
     the head runs exact fp32 on the vector ALUs (157.3 TFLOP/s); mapping and tail run on the fp16 matrix cores with hi/lo-split
-    operands - three MFMAs per product, so their algorithmic bound is the dense fp16 peak / 3."""
+    operands - three MFMAs per product, so their algorithmic bound is the dense fp16 peak / 3.  half (dtype f16): every stage is
+    one fp16 MFMA per product, against the dense fp16 peak."""
     ctx.prof_reset(); ctx.prof_enable(True)
     for _ in range(psteps):
         up(frames, out)
     torch.cuda.synchronize()
     stages = {}
-    for kind, name, peak, unit in ((1, "head (5x5 conv 1->56 + 1x1 56->12, exact fp32, vector ALUs)", F32_VECTOR_PEAK_TFLOPS, "fp32 vector peak"),
+    table = ((1, "head (5x5 conv 1->56 + 1x1 56->12, fp16 MFMA)", MFMA_F16_DENSE_PEAK_TFLOPS, "dense fp16 MFMA peak"),
+             (2, "mapping (4 x conv3x3 12->12, fp16 MFMA)", MFMA_F16_DENSE_PEAK_TFLOPS, "dense fp16 MFMA peak"),
+             (3, "tail (1x1 12->56 + 9x9 transposed conv, fp16 MFMA)", MFMA_F16_DENSE_PEAK_TFLOPS, "dense fp16 MFMA peak")) if half else (
+                                  (1, "head (5x5 conv 1->56 + 1x1 56->12, exact fp32, vector ALUs)", F32_VECTOR_PEAK_TFLOPS, "fp32 vector peak"),
                                    (2, "mapping (4 x conv3x3 12->12, fp16 MFMA, hi/lo split)", MFMA_F16_DENSE_PEAK_TFLOPS / 3, "dense fp16 MFMA peak / 3"),
-                                   (3, "tail (1x1 12->56 + 9x9 transposed conv, fp16 MFMA, hi/lo split)", MFMA_F16_DENSE_PEAK_TFLOPS / 3, "dense fp16 MFMA peak / 3")):
+                                   (3, "tail (1x1 12->56 + 9x9 transposed conv, fp16 MFMA, hi/lo split)", MFMA_F16_DENSE_PEAK_TFLOPS / 3, "dense fp16 MFMA peak / 3"))
+    for kind, name, peak, unit in table:
         n, ms, fl = ctx.prof_read_kind(kind)
         if n > 0 and ms > 0:
             ach = fl / (ms * 1e-3) / 1e12
@@ -371,10 +379,10 @@ def main():
                                   "concurrent_launches": rl["concurrent_launches"],
                                   "frames_per_launch": args.batch * 351.0 / rl["launches_per_step"],
                                   "kernel_time_share_of_step": rl["conv_ms_per_step"] / (1000.0 * elapsed / args.steps)}
-        elif args.workload == "fsrcnn":
+        elif args.workload in ("fsrcnn", "fsrcnn_f16"):
             # FSRCNN: three stages, each against the unit that bounds it (fsrcnn_stage_rooflines); the line's roofline is the
             # stage that takes the longest
-            stages = fsrcnn_stage_rooflines(ctx, up, frames, out)
+            stages = fsrcnn_stage_rooflines(ctx, up, frames, out, half=args.workload == "fsrcnn_f16")
             if stages:
                 name, dom = max(stages.items(), key=lambda kv: kv[1]["ms_per_step"])
                 result["roofline"] = {"bound": "mfma", "achieved": dom["achieved_tflops"], "peak": dom["peak_tflops"], "unit": "TFLOP/s",
@@ -385,6 +393,7 @@ def main():
         # same way (short, outside the headline timing); conv-based ones carry their own roofline fraction
         also = {}
         for name, wl, nb, shape, reps in (("fsrcnn", "fsrcnn", args.batch, (720, 1280), 10),
+                                          ("fsrcnn_f16", "fsrcnn_f16", args.batch, (720, 1280), 10),
                                           ("pipeline", "pipeline", args.batch, (720, 1280), 10),
                                           ("srvgg", "srvgg", args.batch, (720, 1280), 10),
                                           ("rrdbnet_n1", "rrdbnet", 1, (720, 1280), 20),
@@ -406,7 +415,7 @@ def main():
             also[name] = {"workload": WORKLOADS[wl] + (", body as one chained launch (SS4K_MODEL_CHAIN)" if name.endswith("_chain") else ""),
                           "frames_per_step": nb, "fps": reps * nb / dt,
                           "net_tflops": fpf * reps * nb / dt / 1e12}
-            if wl != "fsrcnn":
+            if not wl.startswith("fsrcnn"):
                 rl = conv_roofline(ctx, up2, fr2, out2, psteps=2)
                 if rl is not None:
                     also[name]["conv_tflops"] = rl["achieved"]; also[name]["conv_frac_of_peak"] = rl["frac"]
@@ -414,8 +423,19 @@ def main():
             else:
                 # algorithmic fp32 FLOPs against the fp32 vector / matrix peak that bounds an exact-fp32 implementation (the
                 # fp16-split stages are not bound by it: context, not a roofline fraction)
-                also[name]["frac_of_fp32_peak"] = also[name]["net_tflops"] / F32_VECTOR_PEAK_TFLOPS
-                also[name]["stages"] = fsrcnn_stage_rooflines(ctx, up2, fr2, out2)
+                if wl == "fsrcnn":
+                    also[name]["frac_of_fp32_peak"] = also[name]["net_tflops"] / F32_VECTOR_PEAK_TFLOPS
+                else:
+                    # the fp16 mode's uint8 frames against the fp32-accurate mode's on the same job
+                    up3, keep3, _ = build_upscaler(ctx, "fsrcnn", device, lr_shape=shape)
+                    out3 = torch.empty_like(out2)
+                    up3(fr2, out3); up2(fr2, out2); torch.cuda.synchronize()
+                    d = out2.to(torch.int16) - out3.to(torch.int16)
+                    mse = float((d.float() ** 2).mean())
+                    also[name]["u8_vs_f32_mode"] = {"psnr_db": None if mse == 0 else 10 * math.log10(255.0 ** 2 / mse),
+                                                    "max_lsb": int(d.abs().max()), "frac_differing": float((d != 0).float().mean())}
+                    del up3, keep3, out3
+                also[name]["stages"] = fsrcnn_stage_rooflines(ctx, up2, fr2, out2, half=wl == "fsrcnn_f16")
             del out2, fr2
             if name != "rrdbnet_n1":
                 del up2, keep2

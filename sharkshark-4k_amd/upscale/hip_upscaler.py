@@ -42,7 +42,7 @@ class HipUpscalerService(BaseUpscalerService):
                  upscaler_model="realesrgan", batch_size=1, jit_mode="hip", lr_hr_resize=True,
                  # knobs the reference hard-codes
                  scale=4, model_name=None, dtype="f16", weights=None, checkpoint_dir: Optional[str] = None,
-                 lr_shape=None, single_mode=None, seed=0, model_flags=0):
+                 lr_shape=None, single_mode=None, seed=0, model_flags=0, fsrcnn_dtype="f32"):
         if jit_mode not in (None, "hip"):
             raise Exception(f"jit_mode={jit_mode!r}: this build has one backend, 'hip'")
         if upscaler_model not in ("fsrcnn", "realesrgan"):
@@ -67,6 +67,7 @@ class HipUpscalerService(BaseUpscalerService):
         self.weights = weights if isinstance(weights, str) or weights is None else dict(weights)
         self.checkpoint_dir = checkpoint_dir
         self.seed = seed
+        self.fsrcnn_dtype = fsrcnn_dtype  # 'f32': fp32-accurate (parity bar); 'f16': the reference engine's precision, ~2x the rate
         self.model_flags = int(model_flags)  # SS4K_MODEL_* routing switches for the SR model (include/ss4k.h)
         super().__init__()
 
@@ -83,7 +84,7 @@ class HipUpscalerService(BaseUpscalerService):
             return "synthetic" if self.weights == "synthetic" else (self.weights or {}).get(name)
         if self.upscaler_model == "fsrcnn":
             self.model = factory.build_model_fsrcnn(self.ctx, factor=self.scale, weights=spec("sr"), seed=self.seed,
-                                                    checkpoint_dir=self.checkpoint_dir)
+                                                    checkpoint_dir=self.checkpoint_dir, dtype=self.fsrcnn_dtype, flags=self.model_flags)
         else:
             self.model = factory.build_model_esrgan(
                 self.ctx, model_name=self.model_name or factory.DEFAULT_REALESRGAN, denoise_rate=self.denoise_rate,
