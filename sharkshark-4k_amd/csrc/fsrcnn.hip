@@ -836,6 +836,146 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp16-mode mapping stage: the same four-layer row march (wave s is layer s, four-row rings in LDS, one barrier per row),
+// re-shaped so that a row costs a wave ~12 MFMAs and ~60 other instructions instead of 15 + 270:
+//   * records are 16 fp16 slots = 32 bytes per pixel (12 channels, slot 12 = the constant 1 that carries the bias, 3 spare);
+//   * v_mfma_f32_32x32x16_f16 with the 32 rows = (pixel parity g, 16 cout slots) and the 32 columns = pixel PAIRS: K = a window of
+//     four columns (x - 1 .. x + 2 of the even pixel x) x 16 slots per kernel row, 12 K-steps per row of 64 pixels; the weight
+//     operand holds tap dx = c - g at window column c (a two-pixel Toeplitz block), so lane (n, hh) ends up with all 16 slots
+//     of pixel 2n + hh: its record for the next layer, written with two 16-byte stores;
+//   * layer s keeps input row R in ring slot (R + 2s) & 3, so at step t EVERY layer reads slots (t-1, t, t+1) & 3 and writes
+//     slot (t+2) & 3 of the next ring: with the step loop unrolled by four all LDS offsets are immediates;
+//   * PReLU on packed fp16.
+// 16-byte chunk q of a ring row sits at a chunk with its low two bits XOR-ed by higher bits of q (mh_chunk): a wave's 16-byte reads at a
+// 64-byte lane stride spread over all banks.
+constexpr int MH_COLS = 64, MH_HALO = 4, MH_CI = MH_COLS - 2 * MH_HALO, MH_REC = MH_COLS + 2;
+constexpr int MH_ROWB = MH_REC * 32, MH_STAGEB = 4 * MH_ROWB, MH_LDS = 4 * MH_STAGEB;
+__device__ __forceinline__ int mh_chunk(int q) {
+#ifdef SS4K_MH_SWZ_OLD
+  return (q ^ ((q >> 4) & 3)) * 16;
+#else
+  // reads stay conflict-free (the four 16-lane groups of ds_read_b128), the 16-byte record writes drop from 2-way to 1.5-way
+  return (q ^ (((q >> 4) & 1) | ((((q >> 3) ^ (q >> 5)) & 1) << 1))) * 16;
+#endif
+}
+
+__global__ __launch_bounds__(256, 4) void k_fs_maps4_h(const uint2* __restrict__ in, uint2* __restrict__ out, const FsMapW W,
+                                                       int planes, int h, int w, int bands) {
+  extern __shared__ __attribute__((aligned(16))) char mh_ring[];
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
+  const int st = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's layer
+  const int strips = (w + MH_CI - 1) / MH_CI;
+  const int strip = blockIdx.x % strips, band = (blockIdx.x / strips) % bands, plane = blockIdx.x / (strips * bands);
+  const int rpb = (h + bands - 1) / bands, ylo = band * rpb, yhi = min(h, ylo + rpb);
+  if (plane >= planes || ylo >= yhi) return;
+  const int x0 = strip * MH_CI;
+  for (int e = tid; e < MH_LDS / 16; e += 256) reinterpret_cast<uint4*>(mh_ring)[e] = make_uint4(0u, 0u, 0u, 0u);
+
+  // weights of this wave's layer: row m = (co & 3) + 8 * (co >> 2) + 4 * g (the accumulator register order, so lane half g holds
+  // pixel g's slots 0..15 in registers 0..15); K-step (dy, c): window column c, slot 8 * hh + j
+  uint4 A[3][4];
+  {
+    const float* wm = W.w[st]; const float* bm = W.b[st];
+    const int g = (n >> 2) & 1, co = (n & 3) + 4 * (n >> 3);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int slot = 8 * hh + j, dx = c - g;
+          v[j] = 0.f;
+          if (co < 12) {
+            if (slot < 12) { if (dx >= 0 && dx < 3) v[j] = wm[((dy * 3 + dx) * 12 + slot) * 12 + co]; }
+            else if (slot == 12 && dy == 1 && dx == 1) v[j] = bm[co];   // the pixel's own record, constant-1 slot
+          }
+        }
+        A[dy][c] = make_uint4(half2_rne(v[0], v[1]), half2_rne(v[2], v[3]), half2_rne(v[4], v[5]), half2_rne(v[6], v[7]));
+      }
+  }
+  uint32_t slp[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) slp[j] = half2_rne(W.a[st][2 * j], W.a[st][2 * j + 1]);
+  // pixel operand of K-step (dy, c): record 2n + c (record = ring column + 1: record 0 and 65 are the zero borders), chunk hh
+  int rd[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) rd[c] = st * MH_STAGEB + mh_chunk(2 * (2 * n + c) + hh);
+  // this lane's output pixel: ring column 2n + hh, its record's two chunks in the next layer's ring
+  const int oc = 2 * n + hh, X = x0 - MH_HALO + oc;
+  const int wr0 = (st + 1) * MH_STAGEB + mh_chunk(2 * (oc + 1)), wr1 = (st + 1) * MH_STAGEB + mh_chunk(2 * (oc + 1) + 1);
+  const bool edge = x0 - MH_HALO < 0 || x0 - MH_HALO + MH_COLS > w;   // wave-uniform: this strip has columns outside the image
+  const bool col_in = X >= 0 && X < w;
+
+  const size_t plane_px = (size_t)h * w, total = (size_t)planes * plane_px;
+  const uint2* src = in + (size_t)plane * plane_px;
+  uint2* dst = out + (size_t)plane * plane_px;
+  // input loader: thread tid < 192 moves channel group lg = tid / 64 (8 bytes) of ring column lc = tid % 64; threads 192..255 write
+  // the constant-1 slots of the row
+  const int lg = tid >> 6, lc = tid & 63, lx = x0 - MH_HALO + lc;
+  const bool lcol_in = lx >= 0 && lx < w;
+  const int ld_off = mh_chunk(2 * (lc + 1) + (lg >> 1)) + 8 * (lg & 1);
+  auto load_row = [&](int r) -> uint2 {   // relative row r = image row ylo - 4 + r
+    const int y = ylo - 4 + r;
+    if (!(lcol_in && y >= 0 && y < h)) return make_uint2(0u, 0u);
+    if (lg == 3) return make_uint2(0x00003c00u, 0u);
+    return src[(size_t)lg * total + (size_t)y * w + lx];
+  };
+  auto store_row = [&](int slot, const uint2& v) { *reinterpret_cast<uint2*>(mh_ring + slot * MH_ROWB + ld_off) = v; };
+  __syncthreads();   // rings are zero
+  store_row(0, load_row(0)); store_row(1, load_row(1));
+  // four input rows in flight: a step is shorter than a trip to HBM, so row t + 2 was requested four steps before it is stored
+  uint2 nxt[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) nxt[(i + 2) & 3] = load_row(i + 2);
+  __syncthreads();
+  const f32x16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int nsteps = (yhi - ylo) + 4 + 6;   // layer 3 reaches relative row (yhi - ylo) + 3 at step that + 6
+  const int rlast = (yhi - ylo) + 3 + (3 - st);
+  for (int t0 = 0; t0 < nsteps; t0 += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u;
+      if (t >= nsteps) break;   // uniform over the workgroup
+      // input row t + 2 goes into layer 0's ring (slot (t + 2) & 3) while rows t - 1 .. t + 1 are being read; row t + 6 is requested
+      store_row((u + 2) & 3, nxt[(u + 2) & 3]);
+      nxt[(u + 2) & 3] = load_row(t + 6);
+      const int r = t - 2 * st;   // this layer's output row (wave-uniform)
+      if (r >= 0 && r <= rlast) {
+        const int y = ylo - 4 + r;
+        const bool row_in = y >= 0 && y < h;
+        uint32_t E[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        if (row_in) {   // wave-uniform
+          f32x16v acc = zero16;
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const uint4 b = *reinterpret_cast<const uint4*>(mh_ring + rd[c] + ((u + 3 + dy) & 3) * MH_ROWB);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A[dy][c]), __builtin_bit_cast(f16x8v, b), acc, 0, 0, 0);
+            }
+#pragma unroll
+          for (int j = 0; j < 6; ++j) E[j] = prelu_h2(half2_rne(acc[2 * j], acc[2 * j + 1]), slp[j]);
+          E[6] = 0x00003c00u;
+          if (edge && !col_in) {   // a column outside the image is zero padding for the next layer
+#pragma unroll
+            for (int j = 0; j < 7; ++j) E[j] = 0u;
+          }
+        }
+        if (st < 3) {
+          *reinterpret_cast<uint4*>(mh_ring + wr0 + ((u + 2) & 3) * MH_ROWB) = make_uint4(E[0], E[1], E[2], E[3]);
+          *reinterpret_cast<uint4*>(mh_ring + wr1 + ((u + 2) & 3) * MH_ROWB) = make_uint4(E[4], E[5], E[6], E[7]);
+        } else if (row_in && y >= ylo && y < yhi && oc >= MH_HALO && oc < MH_HALO + MH_CI && X < w) {
+          uint2* o = dst + (size_t)y * w + X;
+          o[0] = make_uint2(E[0], E[1]); o[total] = make_uint2(E[2], E[3]); o[2 * total] = make_uint2(E[4], E[5]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const float* in, float* out, int planes, int h,
                     int w, float* ws12a, float* ws12b, int mode, hipStream_t st) {
   const bool exact = mode == FS_MODE_EXACT, half = mode == FS_MODE_HALF;
@@ -882,7 +1022,17 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
       if (ctx->lds_attr_set.insert(fn).second) SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, FM_LDS));
       hipLaunchKernelGGL(kern, dim3((unsigned)(planes * mbands * mstrips)), block, FM_LDS, st, cur, nxt, mw, planes, h, w, mbands);
     };
-    if (half) launch_maps(&k_fs_maps4<false>); else launch_maps(&k_fs_maps4<true>);
+    if (half) {
+      const int hs = (w + MH_CI - 1) / MH_CI;
+      int hb = std::max(1, std::min((h + 31) / 32, 4 * ctx->num_cu / std::max(1, planes * hs)));   // one round at four per CU
+#ifdef SS4K_DEV
+      if (const char* e = std::getenv("SS4K_MH_BANDS")) hb = std::max(1, std::atoi(e));
+#endif
+      const void* fn = reinterpret_cast<const void*>(&k_fs_maps4_h);
+      if (ctx->lds_attr_set.insert(fn).second) SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MH_LDS));
+      hipLaunchKernelGGL(k_fs_maps4_h, dim3((unsigned)(planes * hb * hs)), block, MH_LDS, st, reinterpret_cast<const uint2*>(cur),
+                         reinterpret_cast<uint2*>(nxt), mw, planes, h, w, hb);
+    } else launch_maps(&k_fs_maps4<true>);
     std::swap(cur, nxt);
   }
   ctx->prof_end(pe, st, 10368.0 * (double)total);

@@ -1,0 +1,7 @@
+export TMPDIR=/tmp
+O=gpurun_out/fs16
+mkdir -p $O
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/sq -- python3 bench.py --workload fsrcnn_f16 --steps 2 --warmup 1 --no-roofline --no-cpu-baseline > /dev/null 2>&1
+python3 tools/pmc_summary.py $O/sq $O/fs16_sq.json
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq2 -- python3 bench.py --workload fsrcnn_f16 --steps 2 --warmup 1 --no-roofline --no-cpu-baseline > /dev/null 2>&1
+python3 tools/pmc_summary.py $O/sq2 $O/fs16_sq2.json
