@@ -308,6 +308,12 @@ __device__ __forceinline__ uint32_t half2_rne(float x0, float x1) {
   const f32x2v v = {x0, x1};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h16x2v));
 }
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t prelu_h2(uint32_t x, uint32_t a) {
+  const h16x2 v = __builtin_bit_cast(h16x2, x), sl = __builtin_bit_cast(h16x2, a), z = {(_Float16)0.f, (_Float16)0.f};
+  const h16x2 r = __builtin_elementwise_max(v, z) + sl * __builtin_elementwise_min(v, z);
+  return __builtin_bit_cast(uint32_t, r);
+}
 template <bool SPLIT>
 __device__ __forceinline__ void pack2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
   if constexpr (SPLIT) split2(x0, x1, hi, lo); else { hi = half2_rne(x0, x1); lo = 0u; }
@@ -368,7 +374,11 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
     for (int j = 0; j < 8; j += 2) {
       float v[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) { const int kin = 8 * kq + j + t; v[t] = (ch < 56 && kin < 12) ? we[kin * 56 + ch] : 0.f; }
+      for (int t = 0; t < 2; ++t) {
+        const int kin = 8 * kq + j + t;
+        v[t] = (ch < 56 && kin < 12) ? we[kin * 56 + ch] : 0.f;
+        if (!SPLIT && ch < 56 && kin == 12) v[t] = be[ch];   // fp16 mode: input slot 12 is the constant 1 (0 outside the image)
+      }
       pack2<SPLIT>(v[0], v[1], vh[j >> 1], vl[j >> 1]);
     }
     we_hi[tid] = make_uint4(vh[0], vh[1], vh[2], vh[3]); we_lo[tid] = make_uint4(vl[0], vl[1], vl[2], vl[3]);
@@ -378,6 +388,17 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
   const int ws = strip * 4 + wave;   // this wave's strip of CI interior columns; nothing below synchronises
   if (ws >= wstrips) return;
 
+  // fp16 mode: PReLU slopes of the expand channels this lane's accumulators hold, packed in pairs (registers instead of LDS reads)
+  uint32_t slp[2][8];
+  if constexpr (!SPLIT) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        const int c0 = 32 * b + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        slp[b][i >> 1] = half2_rne(bea[64 + c0], bea[64 + c0 + 1]);
+      }
+  }
   const size_t plane_px = (size_t)h * w, total = (size_t)planes * plane_px;
   const int OW = S * w, OH = S * h;
   float* oplane = out + (size_t)plane * OH * OW;
@@ -417,11 +438,25 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
         split2(g0.x, g0.y, xh.x, xl.x); split2(g0.z, g0.w, xh.y, xl.y); split2(g1.x, g1.y, xh.z, xl.z); split2(g1.z, g1.w, xh.w, xl.w);
       } else {
         xh = make_uint4(__float_as_uint(g0.x), __float_as_uint(g0.y), __float_as_uint(g1.x), __float_as_uint(g1.y));
+        if (hh == 1 && col_ok) xh.z = 0x00003c00u;   // slot 12 = 1: carries the expand bias; a column outside the image stays all zero
         xl = make_uint4(0u, 0u, 0u, 0u);
       }
       const f16x8v bxh = __builtin_bit_cast(f16x8v, xh), bxl = __builtin_bit_cast(f16x8v, xl);
       // E' = PReLU(We * X + be), split again: B operands of the four k-steps of the second product
       uint4 ebh[4], ebl[4];
+      if constexpr (!SPLIT) {
+        // one MFMA per block, bias through the constant-1 slot (so E' of a column outside the image is PReLU(0) = 0), PReLU on packed fp16
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const f16x8v ah = __builtin_bit_cast(f16x8v, we_hi[b * 64 + lane]);
+          const f32x16v E1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bxh, zero16, 0, 0, 0);
+          uint32_t e[8];
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) e[i >> 1] = prelu_h2(half2_rne(E1[i], E1[i + 1]), slp[b][i >> 1]);
+          ebh[2 * b] = make_uint4(e[0], e[1], e[2], e[3]); ebh[2 * b + 1] = make_uint4(e[4], e[5], e[6], e[7]);
+          ebl[2 * b] = ebl[2 * b + 1] = make_uint4(0u, 0u, 0u, 0u);
+        }
+      } else
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         f32x16v E1;
@@ -519,14 +554,8 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
 // PReLU runs on packed fp16 (v_pk_max / min / fma_f16: 2 instructions per value with the conversion), and the packed activations
 // ARE the second product's B operand (same lane = same pixel; the shrink weights are permuted to the accumulator order, as in
 // the tail): D2[32 (12 real) x 32 px] = Ws[32 x 64] * E[64 x 32].  Output: fp16, group-major [3][pixel][4].
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 constexpr int FH_COLS = 128, FH_RING = 8, FH_ROWH = 136 + 8;   // ring row: columns X0 - 2 .. X0 + 133 (+ pad), fp16
 
-__device__ __forceinline__ uint32_t prelu_h2(uint32_t x, uint32_t a) {
-  const h16x2 v = __builtin_bit_cast(h16x2, x), sl = __builtin_bit_cast(h16x2, a), z = {(_Float16)0.f, (_Float16)0.f};
-  const h16x2 r = __builtin_elementwise_max(v, z) + sl * __builtin_elementwise_min(v, z);
-  return __builtin_bit_cast(uint32_t, r);
-}
 
 __global__ __launch_bounds__(256, 2) void k_fs_head_h(const float* __restrict__ in, uint2* __restrict__ out,
                                                       const float* __restrict__ wf, const float* __restrict__ bf,
@@ -1040,7 +1069,7 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
   pe = ctx->prof_begin(st, PROF_FS_TAIL);
   const int ci = exact ? FS_CI : 4 * (factor == 2 ? FsTailGeo<2>::CI : FsTailGeo<4>::CI);   // interior LR columns per workgroup
   const int strips = (w + ci - 1) / ci;
-  // one round of workgroups at three per CU; every band re-does 4 halo rows
+  // one round of workgroups at three per CU; every band re-does 4 halo rows (fp16 mode: 4, 5 or 6 per CU measured, no gain)
   const int bands = std::max(1, std::min((h + 15) / 16, 3 * ctx->num_cu / std::max(1, planes * strips)));
   const dim3 tgrid((unsigned)(planes * bands * strips));
   auto launch_tail = [&](auto kern, int S) {
