@@ -49,7 +49,9 @@ enum ss4k_model_kind {
 /* arithmetic/storage type of activations and weights inside the network.
  * F32: fp32 storage, exact-fp32 MFMA (parity gate, rtol 1e-3 / atol 1e-4 vs PyTorch CPU).
  * F16: fp16 storage, fp32 accumulate (what RealESRGANer(half=True) + TensorRT fp16 does,
- *      realesrgan/factory.py:168,206-230). */
+ *      realesrgan/factory.py:168,206-230).  FSRCNN with F16 (fsrcnn/factory.py:47-69 builds a TensorRT fp16 engine):
+ *      fp16 operands and intermediates, fp32 accumulation, input and output planes stay fp32; FSRCNN with F32 is
+ *      fp32-grade (hi/lo-split fp16 MFMA or, SS4K_MODEL_FS_EXACT, exact-fp32 kernels). */
 enum ss4k_dtype { SS4K_F32 = 0, SS4K_F16 = 1 };
 
 typedef struct ss4k_model_desc {
