@@ -88,7 +88,9 @@ enum {
   SS4K_MODEL_NO_CHAIN = 64,     /* RRDBNet body of 1- and 2-frame jobs as one launch per layer instead of the cross-layer
                                    chain kernel (csrc/conv_chain.hip); bit-identical results */
   SS4K_MODEL_CHAIN = 128,       /* ... chain kernel for every fp16 job size that fits it */
-  SS4K_MODEL_FLAGS_ALL = 255
+  SS4K_MODEL_NO_PAIR = 256,     /* BSVD: the full-resolution layer pairs (inc, outc) as two launches each instead of the fused
+                                   row-marching kernel (conv_pair.hip); bit-identical results */
+  SS4K_MODEL_FLAGS_ALL = 511
 };
 
 int ss4k_abi_version(void);

@@ -196,6 +196,23 @@ int conv_chain_tiles(int N, int H, int W, int rows_per_wave, int* tiles_x, int* 
 
 // launchers (conv_mfma.hip)
 void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a, int dtype, hipStream_t st);
+// conv_pair.hip: two chained full-resolution 3x3 layers (32 channels wide) as one row-marching launch
+struct PairArgs {
+  const char* in; size_t in_plane_bytes; int in_plane0, planes_a;   // conv A input: planes_a (1 | 2) 16-channel planes
+  const char* wA; const float* biasA;                               // packed fragments (pack.cpp, nb = 1) and bias of conv A (32 couts, ReLU6)
+  const char* wB; const float* biasB;                               // ... of conv B (2 K-chunks, 32 couts)
+  const char* res; size_t res_plane_bytes; int res_plane0;          // epi 1 | 2: the denoiser's skip tensor (channels 0..2: skip - conv)
+  const char* zero_page;                                            // >= 16 zero bytes: DMA source of the zero padding
+  char* out; size_t out_plane_bytes; int out_plane0;
+  int epi;                                                          // conv B: 0 ReLU6 -> planes, 1 residual -> planes, 2 residual -> NCHW fp32
+  int cout_real;                                                    // epi 2: output channels
+  int n0, N, H, W, bands;
+  float grid_share;
+  double flops;
+};
+bool conv3x3_pair_eligible(int planes_a, int cout_pad_a, int nchunks_b, int cout_pad_b);
+void launch_conv3x3_pair(ss4k_ctx* ctx, const PairArgs& a, hipStream_t st);
+
 int conv_cw(int dtype);  // channels per plane / K-chunk: 16
 // three-stage-ring build of the 32-cout tile body (conv_s3.hip)
 bool conv3x3_s3_eligible(const ConvArgs& a, int dtype);

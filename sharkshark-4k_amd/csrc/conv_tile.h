@@ -117,6 +117,15 @@ template <> __device__ __forceinline__ void store8<float>(char* p, const float* 
   }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a full workgroup fence: it also drains the vector-memory counter
+// (s_waitcnt vmcnt(0)), i.e. waits for every global load still in flight and every store - which serialises a row prefetch
+// that is meant to stay in flight across several barriers.  Use where waves exchange data through LDS alone.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <typename T>
 __device__ __forceinline__ f32x16 mma(const uint4& w, const uint4& x, f32x16 acc) {
   if constexpr (sizeof(T) == 2) {

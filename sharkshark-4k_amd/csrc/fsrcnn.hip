@@ -9,6 +9,7 @@
 //   tail  = conv1x1(12->56)+PReLU -> ConvTranspose 9x9 stride s   (fused, exact-fp32 MFMA: k_fs_tail)
 #include "common.h"
 #include "glue.h"
+#include "conv_tile.h"
 
 namespace ss4k {
 
@@ -710,7 +711,6 @@ constexpr int FM_ROWB = FM_RW * 64, FM_STAGEB = 4 * FM_ROWB, FM_LDS = 4 * FM_STA
 struct FsMapW { const float* w[4]; const float* b[4]; const float* a[4]; };
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <bool SPLIT>
 __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ in, float* __restrict__ out, const FsMapW W,
                                                      int planes, int h, int w, int bands) {
   extern __shared__ __attribute__((aligned(16))) char fm_ring[];
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
           const int tap = 2 * ks + (q >> 1), ch = 8 * (q & 1) + j + t2;
           v[t2] = (tap < 9 && ch < 12 && n < 12) ? wm[(tap * 12 + ch) * 12 + n] : 0.f;
         }
-        pack2<SPLIT>(v[0], v[1], vh[j >> 1], vl[j >> 1]);
+        split2(v[0], v[1], vh[j >> 1], vl[j >> 1]);
       }
       ah[ks] = make_uint4(vh[0], vh[1], vh[2], vh[3]); al[ks] = make_uint4(vl[0], vl[1], vl[2], vl[3]);
     }
@@ -773,24 +773,18 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
   const int lsw = ((lc + 1) >> 2) & 3;
   const int ld_hi = (lc + 1) * 64 + (((lg >> 1) ^ lsw) << 4) + 8 * (lg & 1);
   const int ld_lo = (lc + 1) * 64 + (((2 + (lg >> 1)) ^ lsw) << 4) + 8 * (lg & 1);
-  // (fp16 mode: input and output tensors are fp16, 8 bytes per pixel and group; a loaded row travels in .x/.y)
   auto load_row = [&](int r) -> float4 {   // relative row r = image row ylo - 4 + r
     const int y = ylo - 4 + r;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (loader && lcol_ok && y >= 0 && y < h) {
-      if constexpr (SPLIT) v = in4[lg * total + (size_t)y * w + lx];
-      else { const float2 u = (reinterpret_cast<const float2*>(in) + (size_t)plane * plane_px)[lg * total + (size_t)y * w + lx]; v.x = u.x; v.y = u.y; }
-    }
-    return v;
+    if (loader && lcol_ok && y >= 0 && y < h) return in4[lg * total + (size_t)y * w + lx];
+    return make_float4(0.f, 0.f, 0.f, 0.f);
   };
   auto store_row = [&](int r, const float4& v) {
     if (!loader) return;
-    uint32_t h0, h1, l0 = 0u, l1 = 0u;
-    if constexpr (SPLIT) { split2(v.x, v.y, h0, l0); split2(v.z, v.w, h1, l1); }
-    else { h0 = __float_as_uint(v.x); h1 = __float_as_uint(v.y); }
+    uint32_t h0, h1, l0, l1;
+    split2(v.x, v.y, h0, l0); split2(v.z, v.w, h1, l1);
     char* row = fm_ring + (r & 3) * FM_ROWB;   // ring of layer 0
     *reinterpret_cast<uint2*>(row + ld_hi) = make_uint2(h0, h1);
-    if constexpr (SPLIT) *reinterpret_cast<uint2*>(row + ld_lo) = make_uint2(l0, l1);
+    *reinterpret_cast<uint2*>(row + ld_lo) = make_uint2(l0, l1);
   };
   __syncthreads();   // rings are zero
   store_row(0, load_row(0)); store_row(1, load_row(1));
@@ -826,7 +820,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
 #pragma unroll
           for (int ks = 0; ks < 5; ++ks) {
             fh[ks] = *reinterpret_cast<const uint4*>(ph[ks] + u * 1024);
-            if constexpr (SPLIT) fl[ks] = *reinterpret_cast<const uint4*>(pl[ks] + u * 1024);
+            fl[ks] = *reinterpret_cast<const uint4*>(pl[ks] + u * 1024);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -834,13 +828,11 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
             const f16x8v bh = __builtin_bit_cast(f16x8v, fh[ks]), bl = __builtin_bit_cast(f16x8v, fl[ks]);
             const f16x8v wh = __builtin_bit_cast(f16x8v, ah[ks]), wl = __builtin_bit_cast(f16x8v, al[ks]);
             d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh, d1, 0, 0, 0);
-            if constexpr (SPLIT) {
-              d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, d2, 0, 0, 0);
-              d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, d2, 0, 0, 0);
-            }
+            d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, d2, 0, 0, 0);
+            d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, d2, 0, 0, 0);
           }
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = prelu(SPLIT ? fmaf(d2[i], LO, d1[i]) : d1[i], slo[i]);
+          for (int i = 0; i < 4; ++i) v[i] = prelu(fmaf(d2[i], LO, d1[i]), slo[i]);
           const int xu = x0 - FM_HALO + 16 * u;   // wave-uniform: only units that straddle the image edge mask
           if (xu < 0 || xu + 15 >= w) {
             const bool ok = x >= 0 && x < w;       // a column outside the image is zero padding for the next layer
@@ -851,13 +843,12 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
         if (st < 3) {
           if (q < 3) {
             uint32_t h0, h1, l0, l1;
-            pack2<SPLIT>(v[0], v[1], h0, l0); pack2<SPLIT>(v[2], v[3], h1, l1);
+            split2(v[0], v[1], h0, l0); split2(v[2], v[3], h1, l1);
             *reinterpret_cast<uint2*>(dst + u * 1024 + wr_hi) = make_uint2(h0, h1);
-            if constexpr (SPLIT) *reinterpret_cast<uint2*>(dst + u * 1024 + wr_lo) = make_uint2(l0, l1);
+            *reinterpret_cast<uint2*>(dst + u * 1024 + wr_lo) = make_uint2(l0, l1);
           }
         } else if (row_in && q < 3 && y >= ylo && y < yhi && x >= x0 && x < x0 + FM_CI && x < w) {
-          if constexpr (SPLIT) out4[q * total + (size_t)y * w + x] = make_float4(v[0], v[1], v[2], v[3]);
-          else (reinterpret_cast<uint2*>(out) + (size_t)plane * plane_px)[q * total + (size_t)y * w + x] = make_uint2(half2_rne(v[0], v[1]), half2_rne(v[2], v[3]));
+          out4[q * total + (size_t)y * w + x] = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
     }
@@ -945,13 +936,20 @@ __global__ __launch_bounds__(256, 4) void k_fs_maps4_h(const uint2* __restrict__
   const int lg = tid >> 6, lc = tid & 63, lx = x0 - MH_HALO + lc;
   const bool lcol_in = lx >= 0 && lx < w;
   const int ld_off = mh_chunk(2 * (lc + 1) + (lg >> 1)) + 8 * (lg & 1);
+  // Every load is UNCONDITIONAL (address clamped into the image, the value replaced when it is stored): a load under a branch makes
+  // hipcc wait with vmcnt(0), which also waits for the rows requested after it and turns the four-row prefetch into none
+  const size_t lsrc = (size_t)min(lg, 2) * total + (size_t)min(max(lx, 0), w - 1);
   auto load_row = [&](int r) -> uint2 {   // relative row r = image row ylo - 4 + r
-    const int y = ylo - 4 + r;
-    if (!(lcol_in && y >= 0 && y < h)) return make_uint2(0u, 0u);
-    if (lg == 3) return make_uint2(0x00003c00u, 0u);
-    return src[(size_t)lg * total + (size_t)y * w + lx];
+    return src[lsrc + (size_t)min(max(ylo - 4 + r, 0), h - 1) * w];
   };
-  auto store_row = [&](int slot, const uint2& v) { *reinterpret_cast<uint2*>(mh_ring + slot * MH_ROWB + ld_off) = v; };
+  auto store_row = [&](int r, uint2 v) {   // into slot r & 3
+    const int y = ylo - 4 + r;
+    const bool in_img = lcol_in && y >= 0 && y < h;
+    uint2 o;   // (component-wise selects: selecting between whole values makes hipcc select between their addresses in scratch)
+    o.x = in_img ? (lg == 3 ? 0x00003c00u : v.x) : 0u;
+    o.y = (in_img && lg != 3) ? v.y : 0u;
+    *reinterpret_cast<uint2*>(mh_ring + (r & 3) * MH_ROWB + ld_off) = o;
+  };
   __syncthreads();   // rings are zero
   store_row(0, load_row(0)); store_row(1, load_row(1));
   // four input rows in flight: a step is shorter than a trip to HBM, so row t + 2 was requested four steps before it is stored
@@ -968,7 +966,7 @@ __global__ __launch_bounds__(256, 4) void k_fs_maps4_h(const uint2* __restrict__
       const int t = t0 + u;
       if (t >= nsteps) break;   // uniform over the workgroup
       // input row t + 2 goes into layer 0's ring (slot (t + 2) & 3) while rows t - 1 .. t + 1 are being read; row t + 6 is requested
-      store_row((u + 2) & 3, nxt[(u + 2) & 3]);
+      store_row(t + 2, nxt[(u + 2) & 3]);
       nxt[(u + 2) & 3] = load_row(t + 6);
       const int r = t - 2 * st;   // this layer's output row (wave-uniform)
       if (r >= 0 && r <= rlast) {
@@ -977,13 +975,19 @@ __global__ __launch_bounds__(256, 4) void k_fs_maps4_h(const uint2* __restrict__
         uint32_t E[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
         if (row_in) {   // wave-uniform
           f32x16v acc = zero16;
+          // the four pixel operands of a kernel row are read together, then its four MFMAs issue; the next row's reads overlap them
+          // (left to itself hipcc re-uses one register quad: read, wait, MFMA, twelve times over)
 #pragma unroll
-          for (int dy = 0; dy < 3; ++dy)
+          for (int dy = 0; dy < 3; ++dy) {
+            uint4 b[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const uint4 b = *reinterpret_cast<const uint4*>(mh_ring + rd[c] + ((u + 3 + dy) & 3) * MH_ROWB);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A[dy][c]), __builtin_bit_cast(f16x8v, b), acc, 0, 0, 0);
-            }
+            for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const uint4*>(mh_ring + rd[c] + ((u + 3 + dy) & 3) * MH_ROWB);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A[dy][c]), __builtin_bit_cast(f16x8v, b[c]), acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
 #pragma unroll
           for (int j = 0; j < 6; ++j) E[j] = prelu_h2(half2_rne(acc[2 * j], acc[2 * j + 1]), slp[j]);
           E[6] = 0x00003c00u;
@@ -1000,7 +1004,7 @@ __global__ __launch_bounds__(256, 4) void k_fs_maps4_h(const uint2* __restrict__
           o[0] = make_uint2(E[0], E[1]); o[total] = make_uint2(E[2], E[3]); o[2 * total] = make_uint2(E[4], E[5]);
         }
       }
-      __syncthreads();
+      lds_barrier();   // not __syncthreads(): the prefetched rows stay in flight across it (conv_tile.h)
     }
   }
 }
@@ -1046,11 +1050,6 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
     // at most one round of workgroups at three per CU (a second, partly filled round costs a whole march); every band
     // re-does 8 halo rows plus 6 steps of pipeline fill
     const int mbands = std::max(1, std::min((h + 31) / 32, 3 * ctx->num_cu / std::max(1, planes * mstrips)));
-    auto launch_maps = [&](auto kern) {
-      const void* fn = reinterpret_cast<const void*>(kern);
-      if (ctx->lds_attr_set.insert(fn).second) SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, FM_LDS));
-      hipLaunchKernelGGL(kern, dim3((unsigned)(planes * mbands * mstrips)), block, FM_LDS, st, cur, nxt, mw, planes, h, w, mbands);
-    };
     if (half) {
       const int hs = (w + MH_CI - 1) / MH_CI;
       int hb = std::max(1, std::min((h + 31) / 32, 4 * ctx->num_cu / std::max(1, planes * hs)));   // one round at four per CU
@@ -1061,7 +1060,11 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
       if (ctx->lds_attr_set.insert(fn).second) SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MH_LDS));
       hipLaunchKernelGGL(k_fs_maps4_h, dim3((unsigned)(planes * hb * hs)), block, MH_LDS, st, reinterpret_cast<const uint2*>(cur),
                          reinterpret_cast<uint2*>(nxt), mw, planes, h, w, hb);
-    } else launch_maps(&k_fs_maps4<true>);
+    } else {
+      const void* fn = reinterpret_cast<const void*>(&k_fs_maps4);
+      if (ctx->lds_attr_set.insert(fn).second) SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, FM_LDS));
+      hipLaunchKernelGGL(k_fs_maps4, dim3((unsigned)(planes * mbands * mstrips)), block, FM_LDS, st, cur, nxt, mw, planes, h, w, mbands);
+    }
     std::swap(cur, nxt);
   }
   ctx->prof_end(pe, st, 10368.0 * (double)total);

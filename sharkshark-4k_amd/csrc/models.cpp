@@ -192,6 +192,7 @@ void Model::build(const float* w, size_t n) {
   SS4K_REQUIRE(!((fl & SS4K_MODEL_NO_CHAIN) && (fl & SS4K_MODEL_CHAIN)), "desc.flags: NO_CHAIN and CHAIN exclude each other");
   if (fl & SS4K_MODEL_NO_CHAIN) chain_mode = 1;
   if (fl & SS4K_MODEL_CHAIN) chain_mode = 2;
+  if (fl & SS4K_MODEL_NO_PAIR) use_pair = false;
   if (!(fl & (SS4K_MODEL_ONE_CHAIN | SS4K_MODEL_TWO_CHAINS)))
     if (const char* e = std::getenv("SS4K_LANES")) lanes_mode = std::max(0, std::min(2, std::atoi(e)));
   if (const char* e = std::getenv("SS4K_FS_EXACT")) fs_exact = fs_exact || e[0] == '1';
@@ -343,6 +344,53 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
     a.flops = flops * a.N;
     launch_conv3x3(ctx, a, desc.dtype, l == 0 ? st : ctx->lane_stream());
   }
+}
+
+// ---- fused layer pair (conv_pair.hip) ---------------------------------------------------------------------------------
+bool Model::conv_pair(int li, const Tens& in0, int N, int H, int W, const ConvOpts& o, hipStream_t st) {
+  const ConvLayer& A = layers[li]; const ConvLayer& B = layers[li + 1];
+  const bool plain_b = o.epi == EPI_NHWC && o.act == ACT_RELU6 && !o.res1 && !o.res2 && !o.bsvd_resid;
+  const bool resid_b = (o.epi == EPI_NHWC || o.epi == EPI_NCHW_F32) && o.act == ACT_NONE && o.res1 && !o.res2 && o.bsvd_resid && o.alpha == 1.f;
+  if (!use_pair || desc.dtype != SS4K_F16 || dbg || o.ups2 || !(plain_b || resid_b) || A.nchunks1 || B.nchunks1 || A.has_prelu || B.has_prelu ||
+      !conv3x3_pair_eligible(A.nchunks0, A.cout_pad, B.nchunks0, B.cout_pad) || (o.epi == EPI_NCHW_F32 && B.cout_real > 8))
+    return false;
+  if (plan_only) return true;
+#ifdef SS4K_DEV
+  if (fail_at_conv > 0 && ++conv_calls == fail_at_conv) throw Error(SS4K_EINVAL, "injected failure (SS4K_FAIL_AT_CONV)");
+#endif
+  PairArgs a{};
+  a.in = in0.p; a.in_plane_bytes = in0.plane_bytes; a.in_plane0 = in0.plane0; a.planes_a = A.nchunks0;
+  a.wA = reinterpret_cast<const char*>(A.w.ptr); a.biasA = A.bias.as<float>();
+  a.wB = reinterpret_cast<const char*>(B.w.ptr); a.biasB = B.bias.as<float>();
+  if (o.res1) { a.res = o.res1->p; a.res_plane_bytes = o.res1->plane_bytes; a.res_plane0 = o.res1->plane0; }
+  a.out = o.out.p; a.out_plane_bytes = o.out.plane_bytes; a.out_plane0 = o.out.plane0;
+  a.epi = plain_b ? 0 : (o.epi == EPI_NHWC ? 1 : 2);
+  a.zero_page = ctx->zero_page();
+  a.cout_real = B.cout_real;
+  a.H = H; a.W = W;
+  const double flops = 2.0 * 9.0 * ((double)A.cin_real * A.cout_real + (double)B.cin_real * B.cout_real) * (double)H * W;
+  if (ctx->prof && !section_open) {
+    section = ctx->prof_get_events();
+    SS4K_HIP(hipEventRecord(section.a, st));
+    section_open = true;
+  }
+  if (cur_lanes <= 1 || N != cur_n) {
+    a.n0 = 0; a.N = N; a.flops = flops * N;
+    launch_conv3x3_pair(ctx, a, st);
+    return true;
+  }
+  if (!forked) {
+    SS4K_HIP(hipEventRecord(ctx->lane_fork(), st));
+    SS4K_HIP(hipStreamWaitEvent(ctx->lane_stream(), ctx->lane_fork(), 0));
+    forked = true;
+  }
+  for (int l = 0; l < 2; ++l) {
+    a.n0 = N * l / 2; a.N = N * (l + 1) / 2 - a.n0;
+    a.grid_share = lane_grid_share;
+    a.flops = flops * a.N;
+    launch_conv3x3_pair(ctx, a, l == 0 ? st : ctx->lane_stream());
+  }
+  return true;
 }
 
 // ---- cross-layer chain (conv_chain.hip) ---------------------------------------------------------------------------------
@@ -715,8 +763,11 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
       const Tens rest{t.p, t.plane_bytes, t.plane0 + lead};
       conv(li++, S, planes_for(c) > lead ? &rest : nullptr, N, H, W, relu6(outT), st);
     };
-    conv(li++, IN, nullptr, n, h, w, relu6(I0), st);                                   // inc.convblock.0
-    conv(li++, I0, nullptr, n, h, w, relu6(X0), st);                                   // inc.convblock.3
+    if (conv_pair(li, IN, n, h, w, relu6(X0), st)) li += 2;                            // inc.convblock.0 + .3 fused (conv_pair.hip)
+    else {
+      conv(li++, IN, nullptr, n, h, w, relu6(I0), st);                                 // inc.convblock.0
+      conv(li++, I0, nullptr, n, h, w, relu6(X0), st);                                 // inc.convblock.3
+    }
     { ConvOpts o = relu6(D0); o.epi = EPI_NHWC_SUB2; conv(li++, X0, nullptr, n, h, w, o, st); }   // downc0 stride 2
     bibuf(D0, c1, n, h2, w2, Ma);
     bibuf(Ma, c1, n, h2, w2, X1);
@@ -729,10 +780,13 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
     bibuf(S1, c1, n, h2, w2, Ma);                     // upc1.memconv
     bibuf(Ma, c1, n, h2, w2, D0);
     { ConvOpts o; o.epi = EPI_NHWC_PS2; o.res1 = &X0; o.out = S0; conv(li++, D0, nullptr, n, h2, w2, o, st); }  // PixelShuffle + skip2
-    conv(li++, S0, nullptr, n, h, w, relu6(O0), st);                                   // outc.convblock.0
     { ConvOpts o; o.res1 = &IN; o.bsvd_resid = 1;
       if (blk == 0) { o.out = MID; } else { o.epi = EPI_NCHW_F32; o.out = nchw_out(); }
-      conv(li++, O0, nullptr, n, h, w, o, st); }                                       // outc.convblock.3 + residual
+      if (conv_pair(li, S0, n, h, w, o, st)) li += 2;                                  // outc.convblock.0 + .3 + residual fused
+      else {
+        conv(li++, S0, nullptr, n, h, w, relu6(O0), st);                               // outc.convblock.0
+        conv(li++, O0, nullptr, n, h, w, o, st);                                       // outc.convblock.3 + residual
+      } }
   }
   lanes_join(st, true);
 }

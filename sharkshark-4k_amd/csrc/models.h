@@ -75,6 +75,7 @@ struct Model {
   void lanes_join(hipStream_t st, bool end_of_forward);
   // cross-layer chain (conv_chain.hip): the RRDB body of small fp16 jobs as ONE persistent launch.  While chain_rec is set,
   // conv() records work items instead of launching; chain_run() resolves the dependencies and launches the chain.
+  bool use_pair = true;        // BSVD: inc / outc layer pairs as one fused launch each (conv_pair.hip); SS4K_MODEL_NO_PAIR: two launches
   int chain_mode = 1;          // 1: never (default, SS4K_MODEL_NO_CHAIN); 2: the RRDB body of every fp16 job (SS4K_MODEL_CHAIN)
   bool chain_rec = false;
   struct ChainLayerRec { int first_item, nitems; const char* out_lo; const char* out_hi; double flops; };
@@ -121,6 +122,8 @@ struct Model {
   int rec() const { return conv_rec_bytes(desc.dtype); }  // bytes per pixel record of a plane
   int planes_for(int channels) const { return (channels + cw() - 1) / cw(); }
   void conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, const ConvOpts& o, hipStream_t st);
+  // layers li (ReLU6) and li + 1 (options o) as one fused launch; false (nothing done) if the pair does not fit the fused kernel
+  bool conv_pair(int li, const Tens& in0, int N, int H, int W, const ConvOpts& o, hipStream_t st);
   Tens act(int idx, size_t pixels, int channels);
   void pack_in(const float* in, const Tens& dst, int nplanes, int n, int c, int h, int w, int r, hipStream_t st);
 };

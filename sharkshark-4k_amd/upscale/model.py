@@ -152,12 +152,12 @@ def bsvd_table_from(weights: WeightSpec, seed: int = 0, variant: str = "bsvd-32"
 
 
 def build_denoise_model(ctx: _capi.Context, weights: WeightSpec = None, dtype="f16", seed: int = 0,
-                        stream: bool = False, variant: str = "bsvd-32", checkpoint_dir: Optional[str] = None):
+                        stream: bool = False, variant: str = "bsvd-32", checkpoint_dir: Optional[str] = None, flags: int = 0):
     """``stream=False``: the model the service calls, one independent frame per call (F = 1,
     ``fsrcnn_upscaler.py:277``).  ``stream=True``: ``BSVD.forward`` on ``(N,F,4,H,W)`` clips, all N*F
     frames run through the bidirectional buffers as one stream (``bsvd/model.py:515-580``)."""
     kw = BSVD_VARIANTS[variant]
     table = bsvd_table_from(weights, seed, variant, checkpoint_dir)
     desc = _capi.make_desc(_capi.BSVD, _dtype(dtype), scale=1, bsvd_stream=stream, bsvd_chns=kw["chns"],
-                           bsvd_mid_ch=kw["mid_ch"], bsvd_interm_ch=kw["interm_ch"])
+                           bsvd_mid_ch=kw["mid_ch"], bsvd_interm_ch=kw["interm_ch"], flags=flags)
     return _capi.Model(ctx, desc, W.flatten(table, W.bsvd_keys(**kw)))
