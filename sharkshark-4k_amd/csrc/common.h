@@ -203,6 +203,7 @@ struct PairArgs {
   const char* wB; const float* biasB;                               // ... of conv B (2 K-chunks, 32 couts)
   const char* res; size_t res_plane_bytes; int res_plane0;          // epi 1 | 2: the denoiser's skip tensor (channels 0..2: skip - conv)
   const char* zero_page;                                            // >= 16 zero bytes: DMA source of the zero padding
+  unsigned long long* dbg_buf;                                      // dev library, SS4K_PAIR_STAMP=1: per-wave phase cycle counters
   char* out; size_t out_plane_bytes; int out_plane0;
   int epi;                                                          // conv B: 0 ReLU6 -> planes, 1 residual -> planes, 2 residual -> NCHW fp32
   int cout_real;                                                    // epi 2: output channels

@@ -16,6 +16,9 @@
 #include "common.h"
 #include "conv_tile.h"
 #include <type_traits>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 namespace ss4k {
 namespace pair {
@@ -25,11 +28,16 @@ constexpr int OUTC = 62, RECS = 66, REC = 32, ROWB = RECS * REC;
 // barrier: at ~2 us to HBM under load and ~4 KB per row the bytes in flight per CU, not the MFMAs, set the rate (six slots:
 // 2.6-3 TB/s; the one-launch-per-layer kernel, which requests a whole tile at once, reaches 4.5)
 constexpr int PAIR_NS = 6;
+#ifndef PAIR_SWAP_SHIFT
+#define PAIR_SWAP_SHIFT 8
+#endif
 __device__ __forceinline__ int rec_off(int p, int h) { return p * REC + ((h ^ (((p >> 2) ^ (p >> 3)) & 1)) << 4); }
 
 enum { EPI_RELU6 = 0, EPI_RESID = 1, EPI_RESID_NCHW = 2 };
+// min(max(v, 0), 6) as one v_med3_f32 (the same value for every non-NaN v, and a NaN accumulator is not a result to preserve)
+__device__ __forceinline__ float relu6(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 6.f); }
 
-template <int PA, int EPI>
+template <int PA, int EPI, bool STAMP = false>
 __global__ __launch_bounds__(256, 3) void conv3x3_pair_kernel(const PairArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool RES = EPI != EPI_RELU6;
@@ -41,7 +49,22 @@ __global__ __launch_bounds__(256, 3) void conv3x3_pair_kernel(const PairArgs a) 
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of the rings (DMA destination)
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), unit = wave & 1;
-  const bool roleA = wave < 2;
+  // dev build, STAMP: cycles of this wave per phase (s_memtime): [0] DMA issue, [1] operand reads + MFMAs, [2] epilogue, [3] vmcnt wait, [4] barrier
+  unsigned long long ph[5] = {0, 0, 0, 0, 0}, tlast = 0;
+  auto stamp = [&](int k) {
+    if constexpr (STAMP) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (k >= 0) ph[k] += t - tlast;
+      tlast = t;
+    }
+  };
+  // conv A on waves 0, 1 and conv B on 2, 3 - swapped on every other group of 256 workgroups: a workgroup's waves go to fixed SIMDs, and
+  // with one assignment everywhere two SIMDs of every CU would carry all the conv A waves (measured: 3500 cycles per row there, the
+  // conv B waves 2100 of them idle at the barrier)
+  const bool roleA = (wave < 2) != (((blockIdx.x >> PAIR_SWAP_SHIFT) & 1) != 0);
   const int strips = (a.W + OUTC - 1) / OUTC;
   const int strip = blockIdx.x % strips, band = (blockIdx.x / strips) % a.bands, frame = a.n0 + blockIdx.x / (strips * a.bands);
   const int rpb = (a.H + a.bands - 1) / a.bands, ylo = band * rpb, yhi = min(a.H, ylo + rpb);
@@ -78,15 +101,16 @@ __global__ __launch_bounds__(256, 3) void conv3x3_pair_kernel(const PairArgs a) 
   // vmcnt(0) for any load under a branch or whose register is copied, and __syncthreads() drains the counter too - either turns the
   // prefetch into a round trip to HBM per row (measured: 2.0-2.6 us per row against 0.8 us of MFMA time).
   // A row is 132*PA 16-byte pieces, contiguous in the ring (piece e = plane*132 + record*2 + physical half): DMA instruction k moves
-  // pieces 64k..64k+63, lane by lane; wave 0 issues the even k, wave 1 the odd k and the skip row.  Zero padding = the zero page.
+  // pieces 64k..64k+63, lane by lane; the conv B waves issue them (they have the slack: the conv A waves carry the fp16 conversion and the
+  // LDS stores of the inter row), one the even k, the other the odd k and the skip row.  Zero padding = the zero page.
   constexpr int NPIECE = 132 * PA, NK = (NPIECE + 63) / 64, MAXD = 3;
   size_t dsrc[MAXD]; bool dok[MAXD]; int dk[MAXD];   // this wave's DMA instructions of one row: source (column part), lane valid, k (-1: none, NK: skip row)
   int nd = 0;   // how many of them exist (wave-uniform)
 #pragma unroll
   for (int i = 0; i < MAXD; ++i) {
-    const int k = 2 * i + wave;   // waves 0, 1 only (others never issue)
+    const int k = 2 * i + unit;   // conv B waves only (the others never issue)
     dk[i] = -1; dok[i] = false; dsrc[i] = 0;
-    if (wave < 2 && k < NK) {
+    if (!roleA && k < NK) {
       const int e = 64 * k + lane, ec = min(e, NPIECE - 1), pl = ec / 132, rem = ec - pl * 132, rec = rem >> 1;
       const int hf = (rem & 1) ^ (((rec >> 2) ^ (rec >> 3)) & 1);   // the logical half that sits at this physical position (rec_off)
       const int x = x0 - 2 + rec;
@@ -95,7 +119,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_pair_kernel(const PairArgs a) 
       nd = i + 1;
     }
   }
-  if (RES && wave == 1) {   // the skip row: lane = pixel x0 + lane, channels 0..7
+  if (RES && !roleA && unit == 1) {   // the skip row: lane = pixel x0 + lane, channels 0..7
     dk[nd] = NK; dok[nd] = true;
     dsrc[nd] = (size_t)a.res_plane0 * a.res_plane_bytes + ((size_t)frame * a.H * a.W + min(x0 + lane, a.W - 1)) * REC;
     ++nd;
@@ -103,16 +127,21 @@ __global__ __launch_bounds__(256, 3) void conv3x3_pair_kernel(const PairArgs a) 
   nd = __builtin_amdgcn_readfirstlane(nd);
   const int npiece_last = NPIECE - 64 * (NK - 1);   // lanes of the last row instruction that carry a piece
   // issue the DMA bundle of input row r (image row ylo-2+r) into slot sl_in, and the skip row of step r-2 (image row ylo+r-5) into sl_res
-  auto issue = [&](int r, int sl_in, int sl_res) {
+  const size_t row_bytes = (size_t)a.W * REC;
+  const char* rowsrc[MAXD];   // source of input row r (advanced by one image row per bundle; rows outside the image are never dereferenced)
+#pragma unroll
+  for (int i = 0; i < MAXD; ++i) rowsrc[i] = a.in + dsrc[i] + (ptrdiff_t)(ylo - 2) * (ptrdiff_t)row_bytes;
+  auto issue = [&](int r, int sl_in, int sl_res) {   // called with r = 0, 1, 2, ... in order
     const int y = ylo - 2 + r, yr = min(max(ylo + r - 5, 0), a.H - 1);
     const bool row_in = y >= 0 && y < a.H;
 #pragma unroll
     for (int i = 0; i < MAXD; ++i) {
       if (i < nd) {   // wave-uniform
         if (dk[i] == NK) {
-          dma16(a.res + dsrc[i] + (size_t)yr * a.W * REC, __builtin_amdgcn_readfirstlane(lds0 + NS * IN_SLOTB + 4 * MID_SLOTB + sl_res * 1024));
+          dma16(a.res + dsrc[i] + (size_t)yr * row_bytes, __builtin_amdgcn_readfirstlane(lds0 + NS * IN_SLOTB + 4 * MID_SLOTB + sl_res * 1024));
         } else {
-          const char* p = (row_in && dok[i]) ? a.in + dsrc[i] + (size_t)(row_in ? y : 0) * a.W * REC : a.zero_page;
+          const char* p = (row_in && dok[i]) ? rowsrc[i] : a.zero_page;
+          rowsrc[i] += row_bytes;
           const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + sl_in * IN_SLOTB + dk[i] * 1024);
           if (dk[i] < NK - 1 || lane < npiece_last) dma16(p, dst);   // the last instruction of a row is partly filled: masked lanes move nothing
         }
@@ -128,7 +157,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_pair_kernel(const PairArgs a) 
   };
   auto wrap = [](int v) { return v >= NS ? v - NS : v; };
   __syncthreads();   // rings are zero (and every zero store has landed before the first DMA may overwrite it)
-  if (wave < 2) {
+  if (!roleA) {
     for (int r = 0; r < AH; ++r) issue(r, r, wrap(r + NS - 2));   // skip row of step r-2 -> slot (r-2) mod NS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -146,8 +175,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_pair_kernel(const PairArgs a) 
     for (int u = 0; u < 4; ++u) {
       const int t = t0 + u;
       if (t >= nsteps) break;   // uniform over the workgroup
+      stamp(-1);
       if constexpr (ROLE_A) {
-        issue(t + AH, wrap(s6 + AH), wrap(s6 + AH - 2));   // input row t+AH; skip row of step t+AH-2
         if (t <= rows + 1) {
           const int yq = ylo - 1 + t;
           uint4 o0 = make_uint4(0u, 0u, 0u, 0u), o1 = o0;
@@ -172,19 +201,21 @@ __global__ __launch_bounds__(256, 3) void conv3x3_pair_kernel(const PairArgs a) 
               for (int i = 0; i < 9; ++i) acc = mma<__half>(Wt[c * 9 + i], b[i], acc);
               __builtin_amdgcn_sched_barrier(0);
             }
+            stamp(1);
             __half* h0 = reinterpret_cast<__half*>(&o0); __half* h1 = reinterpret_cast<__half*>(&o1);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-              h0[i] = __float2half(a_col_in ? fminf(fmaxf(acc[i], 0.f), 6.f) : 0.f);       // a column outside the image: padding too
-              h1[i] = __float2half(a_col_in ? fminf(fmaxf(acc[8 + i], 0.f), 6.f) : 0.f);
+              h0[i] = __float2half(a_col_in ? relu6(acc[i]) : 0.f);       // a column outside the image: padding too
+              h1[i] = __float2half(a_col_in ? relu6(acc[8 + i]) : 0.f);
             }
           }
           char* dst = mid_ring + u * MID_SLOTB + wr;
           *reinterpret_cast<uint4*>(dst) = o0;
           *reinterpret_cast<uint4*>(dst + ROWB) = o1;
         }
-        wait_bundles();
       } else {
+        issue(t + AH, wrap(s6 + AH), wrap(s6 + AH - 2));   // input row t+AH; skip row of step t+AH-2
+        stamp(0);
         const int P = t - 3, y = ylo + P;
         if (P >= 0 && y < yhi) {
           f32x16 acc;
@@ -203,6 +234,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_pair_kernel(const PairArgs a) 
             for (int i = 0; i < 9; ++i) acc = mma<__half>(Wt[c * 9 + i], b[i], acc);
             __builtin_amdgcn_sched_barrier(0);
           }
+          stamp(1);
           if (b_ok) {
             const size_t ipix = ((size_t)frame * a.H + y) * a.W + xo;
             float v0[8], v1[8];
@@ -210,7 +242,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_pair_kernel(const PairArgs a) 
             for (int i = 0; i < 8; ++i) { v0[i] = acc[i]; v1[i] = acc[8 + i]; }
             if constexpr (EPI == EPI_RELU6) {
 #pragma unroll
-              for (int i = 0; i < 8; ++i) { v0[i] = fminf(fmaxf(v0[i], 0.f), 6.f); v1[i] = fminf(fmaxf(v1[i], 0.f), 6.f); }
+              for (int i = 0; i < 8; ++i) { v0[i] = relu6(v0[i]); v1[i] = relu6(v1[i]); }
             } else if (h == 0) {   // channels 0..2: skip - conv (bsvd/model.py:436-442); the others pass through
               const uint2 rr = *reinterpret_cast<const uint2*>(res_ring + s6 * 1024 + pcol * 16);
               const __half* rh = reinterpret_cast<const __half*>(&rr);
@@ -231,14 +263,26 @@ __global__ __launch_bounds__(256, 3) void conv3x3_pair_kernel(const PairArgs a) 
             }
           }
         }
+        stamp(2);
+        wait_bundles();   // this wave's stores count too: they only make the wait stricter
+        stamp(3);
       }
       s6 = wrap(s6 + 1);
+      stamp(2);
       lds_barrier();   // not __syncthreads(): DMA bundles (and conv B's stores) stay in flight across it
+      stamp(4);
     }
   }
   };
   if (roleA) march(std::true_type{}); else march(std::false_type{});
-  if (wave < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may land after the workgroup has given its LDS back
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may land after the workgroup has given its LDS back
+  if constexpr (STAMP) {
+    if (lane == 0 && a.dbg_buf && blockIdx.x < 1024) {
+      unsigned long long* o = a.dbg_buf + ((size_t)blockIdx.x * 4 + wave) * 8;
+      for (int k = 0; k < 5; ++k) o[k] = ph[k];
+      o[5] = (unsigned long long)nsteps; o[6] = roleA ? 1 : 0;
+    }
+  }
 }
 
 template <int PA, int EPI>
@@ -251,6 +295,33 @@ static void launch_t(ss4k_ctx* ctx, const PairArgs& a0, hipStream_t st) {
   // one round of workgroups at two or three per CU (times this launch's share of the chip); a band re-does 4 input rows and 3 steps
   const int slots = std::max(1, (int)(per_cu * ctx->num_cu * (a.grid_share > 0.f ? a.grid_share : 1.f)));
   a.bands = std::max(1, std::min((a.H + 15) / 16, slots / std::max(1, a.N * strips)));
+#ifdef SS4K_DEV
+  static const bool stamp_mode = std::getenv("SS4K_PAIR_STAMP") && std::getenv("SS4K_PAIR_STAMP")[0] == '1';
+  if (stamp_mode) {   // phase cycle counters of every wave of the first 1024 workgroups, printed per role
+    static unsigned long long* dbuf = nullptr;
+    if (!dbuf) SS4K_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), 1024 * 4 * 8 * 8));
+    SS4K_HIP(hipMemsetAsync(dbuf, 0, 1024 * 4 * 8 * 8, st));
+    a.dbg_buf = dbuf;
+    const void* fs = reinterpret_cast<const void*>(&conv3x3_pair_kernel<PA, EPI, true>);
+    if (ctx->lds_attr_set.insert(fs).second) SS4K_HIP(hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((conv3x3_pair_kernel<PA, EPI, true>), dim3((unsigned)(a.N * a.bands * strips)), dim3(256), lds, st, a);
+    SS4K_HIP(hipStreamSynchronize(st));
+    std::vector<unsigned long long> hb(1024 * 4 * 8);
+    SS4K_HIP(hipMemcpy(hb.data(), dbuf, hb.size() * 8, hipMemcpyDeviceToHost));
+    double acc[2][5] = {{0}}; double steps[2] = {0, 0};
+    for (int wg = 0; wg < 1024; ++wg) for (int w = 0; w < 4; ++w) {
+      const unsigned long long* o = &hb[((size_t)wg * 4 + w) * 8];
+      if (!o[5]) continue;
+      const int r = o[6] ? 0 : 1;
+      for (int k = 0; k < 5; ++k) acc[r][k] += (double)o[k];
+      steps[r] += (double)o[5];
+    }
+    for (int r = 0; r < 2; ++r) if (steps[r] > 0)
+      std::fprintf(stderr, "[pair<%d,%d> %s] shader cycles per row (s_memtime): dma issue %.0f  reads+mfma %.0f  epilogue %.0f  vmcnt wait %.0f  barrier %.0f\n",
+                   PA, EPI, r == 0 ? "conv A waves" : "conv B waves", acc[r][0] / steps[r], acc[r][1] / steps[r], acc[r][2] / steps[r], acc[r][3] / steps[r], acc[r][4] / steps[r]);
+    return;
+  }
+#endif
   const void* fn = reinterpret_cast<const void*>(&conv3x3_pair_kernel<PA, EPI>);
   if (ctx->lds_attr_set.insert(fn).second) SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((conv3x3_pair_kernel<PA, EPI>), dim3((unsigned)(a.N * a.bands * strips)), dim3(256), lds, st, a);
