@@ -773,13 +773,17 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
   const int lsw = ((lc + 1) >> 2) & 3;
   const int ld_hi = (lc + 1) * 64 + (((lg >> 1) ^ lsw) << 4) + 8 * (lg & 1);
   const int ld_lo = (lc + 1) * 64 + (((2 + (lg >> 1)) ^ lsw) << 4) + 8 * (lg & 1);
+  // unconditional loads (address clamped into the image, zero selected when the row is stored): a load under a branch makes hipcc wait
+  // with vmcnt(0), and the barrier below is the LDS-only one - so the fetched row really stays in flight across a step
+  const size_t lsrc = (size_t)min(lg, 2) * total + (size_t)min(max(lx, 0), w - 1);
   auto load_row = [&](int r) -> float4 {   // relative row r = image row ylo - 4 + r
-    const int y = ylo - 4 + r;
-    if (loader && lcol_ok && y >= 0 && y < h) return in4[lg * total + (size_t)y * w + lx];
-    return make_float4(0.f, 0.f, 0.f, 0.f);
+    return in4[lsrc + (size_t)min(max(ylo - 4 + r, 0), h - 1) * w];
   };
-  auto store_row = [&](int r, const float4& v) {
+  auto store_row = [&](int r, float4 v) {
     if (!loader) return;
+    const int y = ylo - 4 + r;
+    const bool in_img = lcol_ok && y >= 0 && y < h;
+    v.x = in_img ? v.x : 0.f; v.y = in_img ? v.y : 0.f; v.z = in_img ? v.z : 0.f; v.w = in_img ? v.w : 0.f;
     uint32_t h0, h1, l0, l1;
     split2(v.x, v.y, h0, l0); split2(v.z, v.w, h1, l1);
     char* row = fm_ring + (r & 3) * FM_ROWB;   // ring of layer 0
@@ -852,7 +856,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
         }
       }
     }
-    __syncthreads();
+    lds_barrier();   // LDS-only (conv_tile.h): the fetched row and layer 3's stores stay in flight across it
   }
 }
 
