@@ -745,10 +745,10 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
   int li = 0;
   for (int blk = 0; blk < 2; ++blk) {
     const Tens IN = blk == 0 ? IN0 : MID;
-    Tens I0 = act(2, px, desc.bsvd_interm_ch), X0 = act(3, px, c0);
+    Tens X0 = act(3, px, c0);   // (I0 and O0, the tensors inside the inc / outc pairs, exist only when the pairs run as two launches)
     Tens D0 = act(4, px2, c1), Ma = act(5, px2, c1), X1 = act(6, px2, c1);
     Tens D1 = act(7, px4, c2), Mb = act(8, px4, c2), X2 = act(9, px4, c2), Mc = act(10, px4, c2);
-    Tens S1 = act(11, px2, c1), S0 = act(12, px, c0), O0 = act(13, px, c0);
+    Tens S1 = act(11, px2, c1), S0 = act(12, px, c0);
     auto relu6 = [&](Tens outT) { ConvOpts o; o.act = ACT_RELU6; o.out = outT; return o; };
     // masked conv input: skip the planes that only hold dead channels (see spec_masked)
     auto masked = [&](const Tens& t, int c) { return Tens{t.p, t.plane_bytes, t.plane0 + (c / 4) / cw()}; };
@@ -765,6 +765,7 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
     };
     if (conv_pair(li, IN, n, h, w, relu6(X0), st)) li += 2;                            // inc.convblock.0 + .3 fused (conv_pair.hip)
     else {
+      Tens I0 = act(2, px, desc.bsvd_interm_ch);
       conv(li++, IN, nullptr, n, h, w, relu6(I0), st);                                 // inc.convblock.0
       conv(li++, I0, nullptr, n, h, w, relu6(X0), st);                                 // inc.convblock.3
     }
@@ -784,6 +785,7 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
       if (blk == 0) { o.out = MID; } else { o.epi = EPI_NCHW_F32; o.out = nchw_out(); }
       if (conv_pair(li, S0, n, h, w, o, st)) li += 2;                                  // outc.convblock.0 + .3 + residual fused
       else {
+        Tens O0 = act(13, px, c0);
         conv(li++, S0, nullptr, n, h, w, relu6(O0), st);                               // outc.convblock.0
         conv(li++, O0, nullptr, n, h, w, o, st);                                       // outc.convblock.3 + residual
       } }
