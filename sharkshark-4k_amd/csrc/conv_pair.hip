@@ -27,7 +27,7 @@ constexpr int OUTC = 62, RECS = 66, REC = 32, ROWB = RECS * REC;
 // Input ring slots.  A row is requested NS-1 steps before conv A first reads it and NS-4 rows' requests may be in flight across a
 // barrier: at ~2 us to HBM under load and ~4 KB per row the bytes in flight per CU, not the MFMAs, set the rate (six slots:
 // 2.6-3 TB/s; the one-launch-per-layer kernel, which requests a whole tile at once, reaches 4.5)
-constexpr int PAIR_NS = 6;
+template <int PA> constexpr int pair_ns() { return PA == 2 ? 7 : 10; }   // the most that keeps three workgroups per CU
 #ifndef PAIR_SWAP_SHIFT
 #define PAIR_SWAP_SHIFT 8
 #endif
@@ -41,7 +41,7 @@ template <int PA, int EPI, bool STAMP = false>
 __global__ __launch_bounds__(256, 3) void conv3x3_pair_kernel(const PairArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool RES = EPI != EPI_RELU6;
-  constexpr int IN_SLOTB = PA * ROWB, MID_SLOTB = 2 * ROWB, NS = PAIR_NS, AH = NS - 1;
+  constexpr int IN_SLOTB = PA * ROWB, MID_SLOTB = 2 * ROWB, NS = pair_ns<PA>(), AH = NS - 1;
   char* in_ring = smem;                        // [NS rows][PA planes][66 records]: rows t..t+2 being read, t+3..t+NS-1 landing
   char* mid_ring = smem + NS * IN_SLOTB;       // [4 rows][2 planes][66 records]
   char* res_ring = mid_ring + 4 * MID_SLOTB;   // [NS rows][64 pixels] x 16 bytes: channels 0..7 of the skip tensor (residual epilogues)
@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_pair_kernel(const PairArgs a) 
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), unit = wave & 1;
   // dev build, STAMP: cycles of this wave per phase (s_memtime): [0] DMA issue, [1] operand reads + MFMAs, [2] epilogue, [3] vmcnt wait, [4] barrier
-  unsigned long long ph[5] = {0, 0, 0, 0, 0}, tlast = 0;
+  unsigned long long ph[5] = {0, 0, 0, 0, 0}, tlast = 0, rt0 = 0, ct0 = 0;
+  if constexpr (STAMP) { rt0 = __builtin_amdgcn_s_memrealtime(); ct0 = __builtin_amdgcn_s_memtime(); }
   auto stamp = [&](int k) {
     if constexpr (STAMP) {
       unsigned long long t;
@@ -281,13 +282,14 @@ __global__ __launch_bounds__(256, 3) void conv3x3_pair_kernel(const PairArgs a) 
       unsigned long long* o = a.dbg_buf + ((size_t)blockIdx.x * 4 + wave) * 8;
       for (int k = 0; k < 5; ++k) o[k] = ph[k];
       o[5] = (unsigned long long)nsteps; o[6] = roleA ? 1 : 0;
+      o[7] = ((__builtin_amdgcn_s_memtime() - ct0) << 20) / (__builtin_amdgcn_s_memrealtime() - rt0 + 1);   // shader cycles per 100 MHz tick, x 2^20
     }
   }
 }
 
 template <int PA, int EPI>
 static void launch_t(ss4k_ctx* ctx, const PairArgs& a0, hipStream_t st) {
-  constexpr size_t lds = (size_t)(PAIR_NS * PA + 8) * ROWB + (EPI != EPI_RELU6 ? PAIR_NS * 1024 : 0);
+  constexpr size_t lds = (size_t)(pair_ns<PA>() * PA + 8) * ROWB + (EPI != EPI_RELU6 ? pair_ns<PA>() * 1024 : 0);
   constexpr int per_cu = (int)std::min<size_t>(3, 160 * 1024 / lds);
   static_assert(per_cu >= 2, "LDS budget");
   PairArgs a = a0;
@@ -308,14 +310,16 @@ static void launch_t(ss4k_ctx* ctx, const PairArgs& a0, hipStream_t st) {
     SS4K_HIP(hipStreamSynchronize(st));
     std::vector<unsigned long long> hb(1024 * 4 * 8);
     SS4K_HIP(hipMemcpy(hb.data(), dbuf, hb.size() * 8, hipMemcpyDeviceToHost));
-    double acc[2][5] = {{0}}; double steps[2] = {0, 0};
+    double acc[2][5] = {{0}}; double steps[2] = {0, 0}; double clk = 0; int nclk = 0;
     for (int wg = 0; wg < 1024; ++wg) for (int w = 0; w < 4; ++w) {
       const unsigned long long* o = &hb[((size_t)wg * 4 + w) * 8];
       if (!o[5]) continue;
       const int r = o[6] ? 0 : 1;
+      clk += (double)o[7] / 1048576.0 * 100.0; ++nclk;
       for (int k = 0; k < 5; ++k) acc[r][k] += (double)o[k];
       steps[r] += (double)o[5];
     }
+    if (nclk) std::fprintf(stderr, "[pair<%d,%d>] shader clock %.0f MHz (s_memtime / s_memrealtime)\n", PA, EPI, clk / nclk);
     for (int r = 0; r < 2; ++r) if (steps[r] > 0)
       std::fprintf(stderr, "[pair<%d,%d> %s] shader cycles per row (s_memtime): dma issue %.0f  reads+mfma %.0f  epilogue %.0f  vmcnt wait %.0f  barrier %.0f\n",
                    PA, EPI, r == 0 ? "conv A waves" : "conv B waves", acc[r][0] / steps[r], acc[r][1] / steps[r], acc[r][2] / steps[r], acc[r][3] / steps[r], acc[r][4] / steps[r]);
