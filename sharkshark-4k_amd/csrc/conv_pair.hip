@@ -4,10 +4,10 @@
 // records per pixel and layer at 4.5 TB/s - and the 32-channel tensor between them is half of that traffic; here it lives in
 // an LDS ring and never reaches HBM.
 //
-// A workgroup marches down a band of rows of a strip of 62 output columns.  Waves 0, 1 are conv A (inter columns
-// x0-1 .. x0+62 in two 32-pixel units), waves 2, 3 conv B (output columns x0 .. x0+61, two units, the last two columns of
-// the second one discarded); a ten-row ring of input rows (filled by LDS-DMA nine rows ahead) and a four-row ring of inter rows
-// in LDS, one LDS-only barrier per row.  Arithmetic is the per-launch kernel's, operation for operation (conv_mfma.hip): fp32
+// A workgroup marches down a band of rows of a strip of 62 output columns.  Two waves are conv A (inter columns
+// x0-1 .. x0+62 in two 32-pixel units), two are conv B (output columns x0 .. x0+61, two units, the last two columns of
+// the second one discarded); a ring of 7 | 10 input rows (filled by LDS-DMA six | nine rows ahead) and a four-row ring of inter
+// rows in LDS, one LDS-only barrier per row.  Arithmetic is the per-launch kernel's, operation for operation (conv_mfma.hip): fp32
 // accumulators start from the bias, MFMAs in (K-chunk, dx, dy) order on the SAME packed weight fragments (pack.cpp: a lane's
 // 16-byte fragment is read straight from the layer's blob into registers - 72 registers hold a 32 -> 32 layer), ReLU6, fp16
 // round-to-nearest of the inter tensor - so the pair is BIT-IDENTICAL to the two launches it replaces.
@@ -24,10 +24,10 @@ namespace ss4k {
 namespace pair {
 
 constexpr int OUTC = 62, RECS = 66, REC = 32, ROWB = RECS * REC;
-// Input ring slots.  A row is requested NS-1 steps before conv A first reads it and NS-4 rows' requests may be in flight across a
-// barrier: at ~2 us to HBM under load and ~4 KB per row the bytes in flight per CU, not the MFMAs, set the rate (six slots:
-// 2.6-3 TB/s; the one-launch-per-layer kernel, which requests a whole tile at once, reaches 4.5)
-template <int PA> constexpr int pair_ns() { return PA == 2 ? 7 : 10; }   // the most that keeps three workgroups per CU
+// Input ring slots: a row is requested NS-1 steps before conv A first reads it and NS-4 rows' requests may be in flight across a
+// barrier.  7 (two input planes) / 10 (one) are the most that keep three workgroups per CU; ten slots at two per CU were slower.
+template <int PA> constexpr int pair_ns() { return PA == 2 ? 7 : 10; }
+// roles are swapped on every other group of 2^PAIR_SWAP_SHIFT workgroups (see roleA)
 #ifndef PAIR_SWAP_SHIFT
 #define PAIR_SWAP_SHIFT 8
 #endif
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_pair_kernel(const PairArgs a) 
   const int xo = x0 + pcol;                       // conv B: output column
   const bool b_ok = pcol < OUTC && xo < a.W;
 
-  // Input rows (and the skip tensor's) arrive by LDS-DMA, issued by the two conv A waves NS-1 rows ahead and awaited with a COUNTED
+  // Input rows (and the skip tensor's) arrive by LDS-DMA, issued NS-1 rows ahead and awaited with a COUNTED
   // s_waitcnt (NS-4 rows' worth may stay in flight across the barrier).  Loads through registers did not work here: hipcc waits with
   // vmcnt(0) for any load under a branch or whose register is copied, and __syncthreads() drains the counter too - either turns the
   // prefetch into a round trip to HBM per row (measured: 2.0-2.6 us per row against 0.8 us of MFMA time).
