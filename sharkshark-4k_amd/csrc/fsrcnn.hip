@@ -10,6 +10,8 @@
 #include "common.h"
 #include "glue.h"
 #include "conv_tile.h"
+#include <cstdio>
+#include <vector>
 
 namespace ss4k {
 
@@ -884,9 +886,23 @@ __device__ __forceinline__ int mh_chunk(int q) {
 #endif
 }
 
+template <bool STAMP>
 __global__ __launch_bounds__(256, 4) void k_fs_maps4_h(const uint2* __restrict__ in, uint2* __restrict__ out, const FsMapW W,
-                                                       int planes, int h, int w, int bands) {
+                                                       int planes, int h, int w, int bands, unsigned long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) char mh_ring[];
+  // dev build, STAMP: cycles of this wave per phase (s_memtime): [0] loader, [1] operand reads + MFMAs, [2] epilogue + stores, [3] barrier
+  unsigned long long ph[4] = {0, 0, 0, 0}, tlast = 0, rt0 = 0, ct0 = 0;
+  if constexpr (STAMP) { rt0 = __builtin_amdgcn_s_memrealtime(); ct0 = __builtin_amdgcn_s_memtime(); }
+  auto stamp = [&](int k) {
+    if constexpr (STAMP) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (k >= 0) ph[k] += t - tlast;
+      tlast = t;
+    }
+  };
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
   const int st = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's layer
   const int strips = (w + MH_CI - 1) / MH_CI;
@@ -964,14 +980,18 @@ __global__ __launch_bounds__(256, 4) void k_fs_maps4_h(const uint2* __restrict__
   const f32x16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int nsteps = (yhi - ylo) + 4 + 6;   // layer 3 reaches relative row (yhi - ylo) + 3 at step that + 6
   const int rlast = (yhi - ylo) + 3 + (3 - st);
+  unsigned long long pre = 0;
+  if constexpr (STAMP) pre = __builtin_amdgcn_s_memtime() - ct0;
   for (int t0 = 0; t0 < nsteps; t0 += 4) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int t = t0 + u;
       if (t >= nsteps) break;   // uniform over the workgroup
       // input row t + 2 goes into layer 0's ring (slot (t + 2) & 3) while rows t - 1 .. t + 1 are being read; row t + 6 is requested
+      stamp(-1);
       store_row(t + 2, nxt[(u + 2) & 3]);
       nxt[(u + 2) & 3] = load_row(t + 6);
+      stamp(0);
       const int r = t - 2 * st;   // this layer's output row (wave-uniform)
       if (r >= 0 && r <= rlast) {
         const int y = ylo - 4 + r;
@@ -992,6 +1012,7 @@ __global__ __launch_bounds__(256, 4) void k_fs_maps4_h(const uint2* __restrict__
               acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A[dy][c]), __builtin_bit_cast(f16x8v, b[c]), acc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
+          stamp(1);
 #pragma unroll
           for (int j = 0; j < 6; ++j) E[j] = prelu_h2(half2_rne(acc[2 * j], acc[2 * j + 1]), slp[j]);
           E[6] = 0x00003c00u;
@@ -1008,7 +1029,17 @@ __global__ __launch_bounds__(256, 4) void k_fs_maps4_h(const uint2* __restrict__
           o[0] = make_uint2(E[0], E[1]); o[total] = make_uint2(E[2], E[3]); o[2 * total] = make_uint2(E[4], E[5]);
         }
       }
+      stamp(2);
       lds_barrier();   // not __syncthreads(): the prefetched rows stay in flight across it (conv_tile.h)
+      stamp(3);
+    }
+  }
+  if constexpr (STAMP) {
+    if (lane == 0 && dbg && blockIdx.x < 1024) {
+      unsigned long long* o = dbg + ((size_t)blockIdx.x * 4 + st) * 8;
+      for (int k = 0; k < 4; ++k) o[k] = ph[k];
+      o[5] = (unsigned long long)nsteps; o[4] = pre; o[6] = __builtin_amdgcn_s_memtime() - ct0;
+      o[7] = ((__builtin_amdgcn_s_memtime() - ct0) << 20) / (__builtin_amdgcn_s_memrealtime() - rt0 + 1);
     }
   }
 }
@@ -1060,10 +1091,38 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
 #ifdef SS4K_DEV
       if (const char* e = std::getenv("SS4K_MH_BANDS")) hb = std::max(1, std::atoi(e));
 #endif
-      const void* fn = reinterpret_cast<const void*>(&k_fs_maps4_h);
-      if (ctx->lds_attr_set.insert(fn).second) SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MH_LDS));
-      hipLaunchKernelGGL(k_fs_maps4_h, dim3((unsigned)(planes * hb * hs)), block, MH_LDS, st, reinterpret_cast<const uint2*>(cur),
-                         reinterpret_cast<uint2*>(nxt), mw, planes, h, w, hb);
+#ifdef SS4K_DEV
+      static const bool stamp_mode = std::getenv("SS4K_FS_STAMP") && std::getenv("SS4K_FS_STAMP")[0] == '1';
+      if (stamp_mode) {   // phase cycle counters of every wave of the first 1024 workgroups, printed per layer
+        static unsigned long long* dbuf = nullptr;
+        if (!dbuf) SS4K_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), 1024 * 4 * 8 * 8));
+        SS4K_HIP(hipMemsetAsync(dbuf, 0, 1024 * 4 * 8 * 8, st));
+        const void* fs = reinterpret_cast<const void*>(&k_fs_maps4_h<true>);
+        if (ctx->lds_attr_set.insert(fs).second) SS4K_HIP(hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, MH_LDS));
+        hipLaunchKernelGGL(k_fs_maps4_h<true>, dim3((unsigned)(planes * hb * hs)), block, MH_LDS, st, reinterpret_cast<const uint2*>(cur),
+                           reinterpret_cast<uint2*>(nxt), mw, planes, h, w, hb, dbuf);
+        SS4K_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> hbuf(1024 * 4 * 8);
+        SS4K_HIP(hipMemcpy(hbuf.data(), dbuf, hbuf.size() * 8, hipMemcpyDeviceToHost));
+        for (int l = 0; l < 4; ++l) {
+          double acc[4] = {0, 0, 0, 0}, steps = 0, clk = 0, pre = 0, tot = 0; int nw = 0;
+          for (int wg = 0; wg < 1024; ++wg) {
+            const unsigned long long* o = &hbuf[((size_t)wg * 4 + l) * 8];
+            if (!o[5]) continue;
+            for (int k = 0; k < 4; ++k) acc[k] += (double)o[k];
+            steps += (double)o[5]; clk += (double)o[7] / 1048576.0 * 100.0; pre += (double)o[4]; tot += (double)o[6]; ++nw;
+          }
+          if (nw) std::fprintf(stderr, "[k_fs_maps4_h layer %d] %.0f MHz; wave life %.0f cycles of which before the row loop %.0f; per row: loader %.0f  reads+mfma %.0f  epilogue+stores %.0f  barrier %.0f\n",
+                               l, clk / nw, tot / nw, pre / nw, acc[0] / steps, acc[1] / steps, acc[2] / steps, acc[3] / steps);
+        }
+      } else
+#endif
+      {
+        const void* fn = reinterpret_cast<const void*>(&k_fs_maps4_h<false>);
+        if (ctx->lds_attr_set.insert(fn).second) SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MH_LDS));
+        hipLaunchKernelGGL(k_fs_maps4_h<false>, dim3((unsigned)(planes * hb * hs)), block, MH_LDS, st, reinterpret_cast<const uint2*>(cur),
+                           reinterpret_cast<uint2*>(nxt), mw, planes, h, w, hb, nullptr);
+      }
     } else {
       const void* fn = reinterpret_cast<const void*>(&k_fs_maps4);
       if (ctx->lds_attr_set.insert(fn).second) SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, FM_LDS));
