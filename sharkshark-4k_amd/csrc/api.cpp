@@ -92,8 +92,12 @@ struct Upscaler {
       lrp = lr.as<float>();
     }
     int oc, H, W; sr->out_shape(n, lh, lw, &oc, &H, &W);
-    hr.ensure((size_t)P * H * W * 4);
+    // fp16 HR tensor where the network's tail can write one (an fp16 SRVGG): the fused path below makes four passes over it (x4 on
+    // 720p: 2880 x 5120 x 3 per frame), half the bytes each.  The fp32 parity path (taps) and fp32 models keep fp32.
+    const bool hr16 = !taps_on && sr->can_half_out();
+    hr.ensure((size_t)P * H * W * (hr16 ? 2 : 4));
     float* hrp = hr.as<float>();
+    __half* hrh = hr.as<__half>();
     SS4K_REQUIRE(P <= STATS_MAX_PLANES, "too many frames in one job");
     st_hr.ensure(P * 8); st_lr.ensure(P * 8); st_acc.ensure(sizeof(double) * 2 * P * STATS_SLOTS);
     const int mh = H / 8, mw = W / 8;
@@ -104,12 +108,14 @@ struct Upscaler {
     const bool resize = cfg.out_h > 0 && cfg.lr_hr_resize && !(cfg.out_h == H && cfg.out_w == W);
     const double tm0 = now_ms();
     if (!taps_on) sr->out_stats_acc = st_acc.as<double>();   // statistics of hr ride along with its producer where it can
+    sr->out_half = hr16;
     sr->forward(lrp, hrp, n, lh, lw, st);
     enq_model_ms = now_ms() - tm0; enq_denoise_ms = 0;
     sr->out_stats_acc = nullptr;
     if (!taps_on) {
       // ---- fused path: the HR tensor is written once by the network, then read by the statistics (unless they rode
       // along), by the area reduction and by ONE tail pass; every per-element expression is the unfused path's
+      SS4K_REQUIRE(!hr16 || sr->out_stats_done, "internal: the fp16 HR tensor's statistics must ride along with its producer");
       if (sr->out_stats_done) op_plane_stats_finish(st_acc.as<double>(), st_hr.as<float>(), P, H * W, st);
       else op_plane_stats(st_acc.as<double>(), hrp, st_hr.as<float>(), P, H * W, st);
       op_plane_stats(st_acc.as<double>(), lrp, st_lr.as<float>(), P, lh * lw, st);
@@ -118,16 +124,21 @@ struct Upscaler {
         const size_t sm = (size_t)P * mh * mw * 4;
         lb.ensure(sm); hb.ensure(sm); lbb.ensure(sm); hbb.ensure(sm);
         op_area(lrp, lb.as<float>(), P, lh, lw, mh, mw, st);
-        op_area_normalized(hrp, hb.as<float>(), P, H, W, mh, mw, st_hr.as<float>(), st_lr.as<float>(), st);
+        if (hr16) op_area_normalized(hrh, hb.as<float>(), P, H, W, mh, mw, st_hr.as<float>(), st_lr.as<float>(), st);
+        else op_area_normalized(hrp, hb.as<float>(), P, H, W, mh, mw, st_hr.as<float>(), st_lr.as<float>(), st);
         color_diff(P, mh, mw, st);
         diff = hb.as<float>();
       }
       if (!resize) {
         // normalise, - diff, clamp, * 255 -> uint8 NHWC in one read of hr
-        op_tail_fused(hrp, out, diff, n, 3, H, W, mh, mw, st_hr.as<float>(), st_lr.as<float>(), st);
+        if (hr16) op_tail_fused(hrh, out, diff, n, 3, H, W, mh, mw, st_hr.as<float>(), st_lr.as<float>(), st);
+        else op_tail_fused(hrp, out, diff, n, 3, H, W, mh, mw, st_hr.as<float>(), st_lr.as<float>(), st);
+      } else if (hr16) {
+        op_tail_fused(hrh, static_cast<uint8_t*>(nullptr), diff, n, 3, H, W, mh, mw, st_hr.as<float>(), st_lr.as<float>(), st);
+        op_bicubic_u8(hrh, out, n, 3, H, W, cfg.out_h, cfg.out_w, st);
       } else {
         // normalise, - diff, clamp in place (bicubic reads 16 neighbours of the finished tensor), then bicubic -> uint8
-        op_tail_fused(hrp, nullptr, diff, n, 3, H, W, mh, mw, st_hr.as<float>(), st_lr.as<float>(), st);
+        op_tail_fused(hrp, static_cast<uint8_t*>(nullptr), diff, n, 3, H, W, mh, mw, st_hr.as<float>(), st_lr.as<float>(), st);
         op_bicubic_u8(hrp, out, n, 3, H, W, cfg.out_h, cfg.out_w, st);
       }
       return;
@@ -214,7 +225,7 @@ struct Upscaler {
       const bool rs_ = cfg.out_h > 0 && !(cfg.out_h == H && cfg.out_w == W);
       if (!rs_) op_tail_fused(hrp, out, nullptr, n, 3, H, W, 1, 1, st_hr.as<float>(), st_lr.as<float>(), st);
       else {
-        op_tail_fused(hrp, nullptr, nullptr, n, 3, H, W, 1, 1, st_hr.as<float>(), st_lr.as<float>(), st);
+        op_tail_fused(hrp, static_cast<uint8_t*>(nullptr), nullptr, n, 3, H, W, 1, 1, st_hr.as<float>(), st_lr.as<float>(), st);
         op_bicubic_u8(hrp, out, n, 3, H, W, cfg.out_h, cfg.out_w, st);
       }
       return;

@@ -15,12 +15,16 @@ constexpr int STATS_MAX_PLANES = 4096;
 constexpr int STATS_SLOTS = 32;
 void op_plane_stats(double* acc, const float* in, float* stats, int planes, int hw, hipStream_t st);
 void op_plane_stats_finish(const double* acc, float* stats, int planes, int hw, hipStream_t st);
-void op_area_normalized(const float* in, float* out, int planes, int h, int w, int oh, int ow, const float* st_hr, const float* st_lr,
+// HT: element type of the network's HR output tensor (float, or __half where the network's tail can write it)
+template <typename HT>
+void op_area_normalized(const HT* in, float* out, int planes, int h, int w, int oh, int ow, const float* st_hr, const float* st_lr,
                         hipStream_t st);
 // fused tails (see glue.hip): any of st_hr/st_lr (normalise), diff (local colour match), out_u8 (final frame) may be null
-void op_tail_fused(float* hr, uint8_t* out_u8, const float* diff, int n, int c, int h, int w, int dh, int dw, const float* st_hr,
+template <typename HT>
+void op_tail_fused(HT* hr, uint8_t* out_u8, const float* diff, int n, int c, int h, int w, int dh, int dw, const float* st_hr,
                    const float* st_lr, hipStream_t st);
-void op_bicubic_u8(const float* in, uint8_t* out, int n, int c, int h, int w, int oh, int ow, hipStream_t st);
+template <typename HT>
+void op_bicubic_u8(const HT* in, uint8_t* out, int n, int c, int h, int w, int oh, int ow, hipStream_t st);
 void op_normalize(float* x, const float* st_hr, const float* st_lr, int planes, int hw, hipStream_t st);
 void op_depthwise_reflect(const float* in, float* out, const float* taps_dev, int planes, int h, int w, int k,
                           int clamp01, const float* blend_src, float blend_a, float blend_b, hipStream_t st);
@@ -34,8 +38,8 @@ void op_clamp01(float* x, size_t n, hipStream_t st);
 void op_f32nchw_to_u8nhwc(const float* in, uint8_t* out, int n, int c, int h, int w, hipStream_t st);
 template <typename T>
 void op_pack_input(const float* in, T* out, int n, int c, int h, int w, int r, int nplanes, hipStream_t st);
-template <typename T>
-void op_ps_nchw_addbase(const T* src, float* out, const float* base, int n, int h, int w, int r, int cq, double* stats_acc, hipStream_t st);
+template <typename T, typename HT>
+void op_ps_nchw_addbase(const T* src, HT* out, const float* base, int n, int h, int w, int r, int cq, double* stats_acc, hipStream_t st);
 
 void op_temporal_shift(const void* in, void* out, int nplanes, int frames, size_t frame_px, int slots_per_record,
                        int ch_per_plane, int fold, hipStream_t st);

@@ -23,6 +23,26 @@ __device__ __forceinline__ NormCoef norm_coef(const float* __restrict__ st_hr, c
   return NormCoef{st_hr[2 * pl], st_hr[2 * pl + 1] + 1e-8f, st_lr[2 * pl], st_lr[2 * pl + 1]};
 }
 __device__ __forceinline__ float norm_px(float v, const NormCoef& k) { return (v - k.mh) / k.sh * k.sl + k.ml; }
+// The network's HR output tensor is fp32, or fp16 for an fp16 model whose tail can write it (SRVGG: half the bytes of the four
+// passes over a 2880 x 5120 tensor): element / 4-element access for both
+template <typename HT> __device__ __forceinline__ float hr_ld(const HT* p) { return (float)*p; }
+template <typename HT> __device__ __forceinline__ void hr_st(HT* p, float v) { *p = (HT)v; }
+template <typename HT> __device__ __forceinline__ float4 hr_ld4(const HT* p);
+template <> __device__ __forceinline__ float4 hr_ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 hr_ld4<__half>(const __half* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  const __half2* hh = reinterpret_cast<const __half2*>(&u);
+  const float2 a = __half22float2(hh[0]), b = __half22float2(hh[1]);
+  return make_float4(a.x, a.y, b.x, b.y);
+}
+template <typename HT> __device__ __forceinline__ void hr_st4(HT* p, const float4& v);
+template <> __device__ __forceinline__ void hr_st4<float>(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ __forceinline__ void hr_st4<__half>(__half* p, const float4& v) {
+  uint2 u;
+  __half2* hh = reinterpret_cast<__half2*>(&u);
+  hh[0] = __floats2half2_rn(v.x, v.y); hh[1] = __floats2half2_rn(v.z, v.w);
+  *reinterpret_cast<uint2*>(p) = u;
+}
 
 // ------------------------------------------------------------------ u8 NHWC -> f32 NCHW (/255)
 __global__ void k_u8nhwc_to_f32nchw(const uint8_t* __restrict__ in, float* __restrict__ out, int n, int h,
@@ -44,41 +64,41 @@ __device__ __forceinline__ int a_end(int i, int in, int out) { return (int)ceilf
 
 // one block row per output row (blockIdx.y = oy, blockIdx.z = plane): no per-element divisions.
 // NORM: the input is read through the channel-statistics normalisation (the normalised tensor is never written)
-template <bool NORM>
-__global__ void k_area(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int oh,
+template <bool NORM, typename HT = float>
+__global__ void k_area(const HT* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int oh,
                        int ow, const float* __restrict__ st_hr, const float* __restrict__ st_lr) {
   const int oy = blockIdx.y, pl = blockIdx.z;
   NormCoef nk{};
   if constexpr (NORM) nk = norm_coef(st_hr, st_lr, pl);
   const int y0 = a_start(oy, h, oh), y1 = a_end(oy, h, oh);
-  const float* src = in + (size_t)pl * h * w;
+  const HT* src = in + (size_t)pl * h * w;
   float* dst = out + ((size_t)pl * oh + oy) * ow;
   for (int ox = blockIdx.x * blockDim.x + threadIdx.x; ox < ow; ox += gridDim.x * blockDim.x) {
     const int x0 = a_start(ox, w, ow), x1 = a_end(ox, w, ow);
     float sum = 0.f;
     for (int y = y0; y < y1; ++y)
-      for (int x = x0; x < x1; ++x) sum += NORM ? norm_px(src[(size_t)y * w + x], nk) : src[(size_t)y * w + x];
+      for (int x = x0; x < x1; ++x) sum += NORM ? norm_px(hr_ld(src + (size_t)y * w + x), nk) : hr_ld(src + (size_t)y * w + x);
     dst[ox] = sum / (float)(y1 - y0) / (float)(x1 - x0);
   }
 }
 // Whole-number windows of KX = 4 or 8 columns (the service's HR -> H/8 map, x2 -> lr_shape reductions): the same sums in
 // the same order (rows outer, columns inner), the window's columns fetched as 16-byte loads - the scalar form issues KX
 // four-byte loads per row whose lanes sit 4*KX bytes apart
-template <bool NORM, int KX>
-__global__ void k_area_whole(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int oh, int ow, int ky,
+template <bool NORM, int KX, typename HT = float>
+__global__ void k_area_whole(const HT* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int oh, int ow, int ky,
                              const float* __restrict__ st_hr, const float* __restrict__ st_lr) {
   const int oy = blockIdx.y, pl = blockIdx.z;
   NormCoef nk{};
   if constexpr (NORM) nk = norm_coef(st_hr, st_lr, pl);
-  const float* src = in + ((size_t)pl * h + (size_t)oy * ky) * w;
+  const HT* src = in + ((size_t)pl * h + (size_t)oy * ky) * w;
   float* dst = out + ((size_t)pl * oh + oy) * ow;
   for (int ox = blockIdx.x * blockDim.x + threadIdx.x; ox < ow; ox += gridDim.x * blockDim.x) {
     float sum = 0.f;
     for (int y = 0; y < ky; ++y) {
-      const float4* rp = reinterpret_cast<const float4*>(src + (size_t)y * w + (size_t)ox * KX);
+      const HT* rp = src + (size_t)y * w + (size_t)ox * KX;
 #pragma unroll
       for (int q = 0; q < KX / 4; ++q) {
-        const float4 v = rp[q];
+        const float4 v = hr_ld4<HT>(rp + 4 * q);
         sum += NORM ? norm_px(v.x, nk) : v.x; sum += NORM ? norm_px(v.y, nk) : v.y;
         sum += NORM ? norm_px(v.z, nk) : v.z; sum += NORM ? norm_px(v.w, nk) : v.w;
       }
@@ -86,14 +106,14 @@ __global__ void k_area_whole(const float* __restrict__ in, float* __restrict__ o
     dst[ox] = sum / (float)ky / (float)KX;
   }
 }
-template <bool NORM>
-static bool area_whole(const float* in, float* out, int planes, int h, int w, int oh, int ow, const float* st_hr, const float* st_lr,
+template <bool NORM, typename HT = float>
+static bool area_whole(const HT* in, float* out, int planes, int h, int w, int oh, int ow, const float* st_hr, const float* st_lr,
                        hipStream_t st) {
   if (h % oh || w % ow || (reinterpret_cast<uintptr_t>(in) & 15)) return false;
   const int ky = h / oh, kx = w / ow;
   const dim3 g((unsigned)std::min((ow + 255) / 256, 64), (unsigned)oh, (unsigned)planes);
-  if (kx == 4) hipLaunchKernelGGL((k_area_whole<NORM, 4>), g, dim3(256), 0, st, in, out, planes, h, w, oh, ow, ky, st_hr, st_lr);
-  else if (kx == 8) hipLaunchKernelGGL((k_area_whole<NORM, 8>), g, dim3(256), 0, st, in, out, planes, h, w, oh, ow, ky, st_hr, st_lr);
+  if (kx == 4) hipLaunchKernelGGL((k_area_whole<NORM, 4, HT>), g, dim3(256), 0, st, in, out, planes, h, w, oh, ow, ky, st_hr, st_lr);
+  else if (kx == 8) hipLaunchKernelGGL((k_area_whole<NORM, 8, HT>), g, dim3(256), 0, st, in, out, planes, h, w, oh, ow, ky, st_hr, st_lr);
   else return false;
   return true;
 }
@@ -107,12 +127,15 @@ void op_area(const float* in, float* out, int planes, int h, int w, int oh, int 
   if (area_whole<false>(in, out, planes, h, w, oh, ow, nullptr, nullptr, st)) { SS4K_LAUNCH_OK(); return; }
   hipLaunchKernelGGL(k_area<false>, grid_rows(ow, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow, nullptr, nullptr); SS4K_LAUNCH_OK();
 }
-void op_area_normalized(const float* in, float* out, int planes, int h, int w, int oh, int ow, const float* st_hr, const float* st_lr,
+template <typename HT>
+void op_area_normalized(const HT* in, float* out, int planes, int h, int w, int oh, int ow, const float* st_hr, const float* st_lr,
                         hipStream_t st) {
   SS4K_REQUIRE(oh <= 65535 && planes <= 65535, "area: grid limits");
-  if (area_whole<true>(in, out, planes, h, w, oh, ow, st_hr, st_lr, st)) { SS4K_LAUNCH_OK(); return; }
-  hipLaunchKernelGGL(k_area<true>, grid_rows(ow, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow, st_hr, st_lr); SS4K_LAUNCH_OK();
+  if (area_whole<true, HT>(in, out, planes, h, w, oh, ow, st_hr, st_lr, st)) { SS4K_LAUNCH_OK(); return; }
+  hipLaunchKernelGGL((k_area<true, HT>), grid_rows(ow, oh, planes), dim3(256), 0, st, in, out, planes, h, w, oh, ow, st_hr, st_lr); SS4K_LAUNCH_OK();
 }
+template void op_area_normalized<float>(const float*, float*, int, int, int, int, int, const float*, const float*, hipStream_t);
+template void op_area_normalized<__half>(const __half*, float*, int, int, int, int, int, const float*, const float*, hipStream_t);
 
 // ------------------------------------------------------------------ per-plane mean / unbiased std
 __global__ void k_stats_partial(const float* __restrict__ in, double* __restrict__ acc, int hw) {
@@ -356,8 +379,8 @@ void op_bicubic(const float* in, float* out, int planes, int h, int w, int oh, i
 // with exactly the per-element expressions of the stand-alone kernels (k_normalize, k_bilinear, k_clamp01,
 // k_f32nchw_to_u8nhwc), so the frames are bit-identical to the unfused path.
 // U8: write uint8 NHWC (three planes of a pixel by one thread); else write the clamped float back in place.
-template <bool NORM, bool DIFF, bool U8>
-__global__ void k_tail_fused(float* __restrict__ hr, uint8_t* __restrict__ out, const float* __restrict__ diff, int n, int c, int h, int w,
+template <bool NORM, bool DIFF, bool U8, typename HT = float>
+__global__ void k_tail_fused(HT* __restrict__ hr, uint8_t* __restrict__ out, const float* __restrict__ diff, int n, int c, int h, int w,
                              int dh, int dw, const float* __restrict__ st_hr, const float* __restrict__ st_lr) {
   const int oy = blockIdx.y, img = blockIdx.z;
   // bilinear, align_corners=False: same arithmetic as k_bilinear
@@ -372,7 +395,7 @@ __global__ void k_tail_fused(float* __restrict__ hr, uint8_t* __restrict__ out, 
     for (int k = 0; k < c; ++k) {
       const int pl = img * c + k;
       const size_t idx = ((size_t)pl * h + oy) * w + ox;
-      float v = hr[idx];
+      float v = hr_ld(hr + idx);
       if constexpr (NORM) v = norm_px(v, norm_coef(st_hr, st_lr, pl));
       if constexpr (DIFF) {
         const float* r0 = diff + ((size_t)pl * dh + y0) * dw; const float* r1 = diff + ((size_t)pl * dh + y1) * dw;
@@ -381,14 +404,14 @@ __global__ void k_tail_fused(float* __restrict__ hr, uint8_t* __restrict__ out, 
       }
       v = fminf(fmaxf(v, 0.f), 1.f);
       if constexpr (U8) out[(((size_t)img * h + oy) * w + ox) * c + k] = (uint8_t)(fminf(fmaxf(v, 0.f), 1.f) * 255.f);
-      else hr[idx] = v;
+      else hr_st(hr + idx, v);
     }
   }
 }
 // the same pass with four consecutive pixels per thread (w % 4 == 0): 16-byte loads of each plane, one 12-byte store of
 // the four uint8 NHWC pixels (or a 16-byte store per plane); per-element expressions and their order are k_tail_fused's
-template <bool NORM, bool DIFF, bool U8>
-__global__ void k_tail_fused4(float* __restrict__ hr, uint8_t* __restrict__ out, const float* __restrict__ diff, int n, int h, int w,
+template <bool NORM, bool DIFF, bool U8, typename HT = float>
+__global__ void k_tail_fused4(HT* __restrict__ hr, uint8_t* __restrict__ out, const float* __restrict__ diff, int n, int h, int w,
                               int dh, int dw, const float* __restrict__ st_hr, const float* __restrict__ st_lr) {
   constexpr int C = 3;
   const int oy = blockIdx.y, img = blockIdx.z;
@@ -410,8 +433,8 @@ __global__ void k_tail_fused4(float* __restrict__ hr, uint8_t* __restrict__ out,
 #pragma unroll
     for (int k = 0; k < C; ++k) {
       const int pl = img * C + k;
-      float4* p = reinterpret_cast<float4*>(hr + ((size_t)pl * h + oy) * w) + ox4;
-      const float4 in4 = *p;
+      HT* p = hr + ((size_t)pl * h + oy) * w + 4 * (size_t)ox4;
+      const float4 in4 = hr_ld4<HT>(p);
       float v[4] = {in4.x, in4.y, in4.z, in4.w};
       NormCoef nk{};
       if constexpr (NORM) nk = norm_coef(st_hr, st_lr, pl);
@@ -427,7 +450,7 @@ __global__ void k_tail_fused4(float* __restrict__ hr, uint8_t* __restrict__ out,
         v[j] = fminf(fmaxf(v[j], 0.f), 1.f);
         if constexpr (U8) b[k][j] = (uint32_t)(uint8_t)(fminf(fmaxf(v[j], 0.f), 1.f) * 255.f);
       }
-      if constexpr (!U8) *p = make_float4(v[0], v[1], v[2], v[3]);
+      if constexpr (!U8) hr_st4<HT>(p, make_float4(v[0], v[1], v[2], v[3]));
     }
     if constexpr (U8) {
       // bytes 3*j + k of the twelve: pixel j, plane k
@@ -441,14 +464,15 @@ __global__ void k_tail_fused4(float* __restrict__ hr, uint8_t* __restrict__ out,
     }
   }
 }
-void op_tail_fused(float* hr, uint8_t* out_u8, const float* diff, int n, int c, int h, int w, int dh, int dw, const float* st_hr,
+template <typename HT>
+void op_tail_fused(HT* hr, uint8_t* out_u8, const float* diff, int n, int c, int h, int w, int dh, int dw, const float* st_hr,
                    const float* st_lr, hipStream_t st) {
   SS4K_REQUIRE(h <= 65535 && n <= 65535, "fused tail: grid limits");
   const dim3 g = grid_rows(w, h, n);
   const bool norm = st_hr != nullptr, df = diff != nullptr, u8 = out_u8 != nullptr;
   if (c == 3 && (w & 3) == 0 && (reinterpret_cast<uintptr_t>(hr) & 15) == 0 && (reinterpret_cast<uintptr_t>(out_u8) & 3) == 0) {
     const dim3 g4 = grid_rows(w / 4, h, n);
-#define SS4K_TAIL4(N_, D_, U_) hipLaunchKernelGGL((k_tail_fused4<N_, D_, U_>), g4, dim3(256), 0, st, hr, out_u8, diff, n, h, w, dh, dw, st_hr, st_lr)
+#define SS4K_TAIL4(N_, D_, U_) hipLaunchKernelGGL((k_tail_fused4<N_, D_, U_, HT>), g4, dim3(256), 0, st, hr, out_u8, diff, n, h, w, dh, dw, st_hr, st_lr)
     if (norm && df && u8) SS4K_TAIL4(true, true, true); else if (norm && df) SS4K_TAIL4(true, true, false);
     else if (norm && u8) SS4K_TAIL4(true, false, true); else if (norm) SS4K_TAIL4(true, false, false);
     else if (df && u8) SS4K_TAIL4(false, true, true); else if (df) SS4K_TAIL4(false, true, false);
@@ -457,7 +481,7 @@ void op_tail_fused(float* hr, uint8_t* out_u8, const float* diff, int n, int c, 
     SS4K_LAUNCH_OK();
     return;
   }
-#define SS4K_TAIL(N_, D_, U_) hipLaunchKernelGGL((k_tail_fused<N_, D_, U_>), g, dim3(256), 0, st, hr, out_u8, diff, n, c, h, w, dh, dw, st_hr, st_lr)
+#define SS4K_TAIL(N_, D_, U_) hipLaunchKernelGGL((k_tail_fused<N_, D_, U_, HT>), g, dim3(256), 0, st, hr, out_u8, diff, n, c, h, w, dh, dw, st_hr, st_lr)
   if (norm && df && u8) SS4K_TAIL(true, true, true); else if (norm && df) SS4K_TAIL(true, true, false);
   else if (norm && u8) SS4K_TAIL(true, false, true); else if (norm) SS4K_TAIL(true, false, false);
   else if (df && u8) SS4K_TAIL(false, true, true); else if (df) SS4K_TAIL(false, true, false);
@@ -465,10 +489,13 @@ void op_tail_fused(float* hr, uint8_t* out_u8, const float* diff, int n, int c, 
 #undef SS4K_TAIL
   SS4K_LAUNCH_OK();
 }
+template void op_tail_fused<float>(float*, uint8_t*, const float*, int, int, int, int, int, int, const float*, const float*, hipStream_t);
+template void op_tail_fused<__half>(__half*, uint8_t*, const float*, int, int, int, int, int, int, const float*, const float*, hipStream_t);
 
 // bicubic (A = -0.75, align_corners=False: k_bicubic's arithmetic) of an already clamped tensor, then
 // clamp(0,1) * 255 truncated to uint8 NHWC: the resized float tensor is never written
-__global__ void k_bicubic_u8(const float* __restrict__ in, uint8_t* __restrict__ out, int n, int c, int h, int w, int oh, int ow) {
+template <typename HT = float>
+__global__ void k_bicubic_u8(const HT* __restrict__ in, uint8_t* __restrict__ out, int n, int c, int h, int w, int oh, int ow) {
   const int oy = blockIdx.y, img = blockIdx.z;
   const float sy = (float)h / oh, sx = (float)w / ow;
   const float fy = sy * (oy + 0.5f) - 0.5f, fly = floorf(fy);
@@ -486,14 +513,14 @@ __global__ void k_bicubic_u8(const float* __restrict__ in, uint8_t* __restrict__
 #pragma unroll
     for (int b = 0; b < 4; ++b) xi[b] = min(max(ix - 1 + b, 0), w - 1);
     for (int k = 0; k < c; ++k) {
-      const float* src = in + (size_t)(img * c + k) * h * w;
+      const HT* src = in + (size_t)(img * c + k) * h * w;
       float acc = 0.f;
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        const float* rowp = src + (size_t)yi[a] * w;
+        const HT* rowp = src + (size_t)yi[a] * w;
         float row = 0.f;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) row += cx[b] * rowp[xi[b]];
+        for (int b = 0; b < 4; ++b) row += cx[b] * hr_ld(rowp + xi[b]);
         acc += cy[a] * row;
       }
       acc = fminf(fmaxf(acc, 0.f), 1.f);
@@ -505,7 +532,8 @@ __global__ void k_bicubic_u8(const float* __restrict__ in, uint8_t* __restrict__
 // every sample sits at t = 0.5 of input columns 2*ox - 1 .. 2*ox + 2, so four adjacent outputs share ten input columns of
 // each of their four rows - two 16-byte loads and two clamped edge loads instead of sixteen 4-byte ones, and one 12-byte
 // store of the four uint8 NHWC pixels.  Coefficients, products and their order are k_bicubic_u8's.
-__global__ void k_bicubic_u8_half(const float* __restrict__ in, uint8_t* __restrict__ out, int n, int h, int w, int oh, int ow) {
+template <typename HT = float>
+__global__ void k_bicubic_u8_half(const HT* __restrict__ in, uint8_t* __restrict__ out, int n, int h, int w, int oh, int ow) {
   constexpr int C = 3;
   const int oy = blockIdx.y, img = blockIdx.z;
   const float sy = (float)h / oh, sx = (float)w / ow;
@@ -527,13 +555,13 @@ __global__ void k_bicubic_u8_half(const float* __restrict__ in, uint8_t* __restr
     uint32_t b[C][4];
 #pragma unroll
     for (int k = 0; k < C; ++k) {
-      const float* src = in + (size_t)(img * C + k) * h * w;
+      const HT* src = in + (size_t)(img * C + k) * h * w;
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        const float* rowp = src + (size_t)yi[a] * w;
-        const float4 m0 = *reinterpret_cast<const float4*>(rowp + 8 * t), m1 = *reinterpret_cast<const float4*>(rowp + 8 * t + 4);
-        const float col[10] = {rowp[xl], m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, rowp[xr]};   // columns 8t-1 .. 8t+8
+        const HT* rowp = src + (size_t)yi[a] * w;
+        const float4 m0 = hr_ld4<HT>(rowp + 8 * t), m1 = hr_ld4<HT>(rowp + 8 * t + 4);
+        const float col[10] = {hr_ld(rowp + xl), m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, hr_ld(rowp + xr)};   // columns 8t-1 .. 8t+8
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float row = 0.f;
@@ -557,14 +585,17 @@ __global__ void k_bicubic_u8_half(const float* __restrict__ in, uint8_t* __restr
     o[0] = wds[0]; o[1] = wds[1]; o[2] = wds[2];
   }
 }
-void op_bicubic_u8(const float* in, uint8_t* out, int n, int c, int h, int w, int oh, int ow, hipStream_t st) {
+template <typename HT>
+void op_bicubic_u8(const HT* in, uint8_t* out, int n, int c, int h, int w, int oh, int ow, hipStream_t st) {
   SS4K_REQUIRE(oh <= 65535 && n <= 65535, "bicubic: grid limits");
   if (c == 3 && h == 2 * oh && w == 2 * ow && (ow & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0) {
-    hipLaunchKernelGGL(k_bicubic_u8_half, grid_rows(ow / 4, oh, n), dim3(256), 0, st, in, out, n, h, w, oh, ow); SS4K_LAUNCH_OK();
+    hipLaunchKernelGGL(k_bicubic_u8_half<HT>, grid_rows(ow / 4, oh, n), dim3(256), 0, st, in, out, n, h, w, oh, ow); SS4K_LAUNCH_OK();
     return;
   }
-  hipLaunchKernelGGL(k_bicubic_u8, grid_rows(ow, oh, n), dim3(256), 0, st, in, out, n, c, h, w, oh, ow); SS4K_LAUNCH_OK();
+  hipLaunchKernelGGL(k_bicubic_u8<HT>, grid_rows(ow, oh, n), dim3(256), 0, st, in, out, n, c, h, w, oh, ow); SS4K_LAUNCH_OK();
 }
+template void op_bicubic_u8<float>(const float*, uint8_t*, int, int, int, int, int, int, hipStream_t);
+template void op_bicubic_u8<__half>(const __half*, uint8_t*, int, int, int, int, int, int, hipStream_t);
 
 // ------------------------------------------------------------------ elementwise helpers
 __global__ void k_sub(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
@@ -646,8 +677,8 @@ template void op_pack_input<__half>(const float*, __half*, int, int, int, int, i
 // fp32 NCHW planes plus the nearest-upsampled network input.
 // One thread per LR pixel and colour: the r*r channels of that colour are one contiguous run of its
 // record(s), read with 16-byte loads, and leave as r rows of r floats (16-byte stores for r = 4).
-template <typename T, int R, bool STATS>
-__global__ __launch_bounds__(256) void k_ps_nchw_addbase(const T* __restrict__ src, float* __restrict__ out, const float* __restrict__ base,
+template <typename T, int R, bool STATS, typename HT = float>
+__global__ __launch_bounds__(256) void k_ps_nchw_addbase(const T* __restrict__ src, HT* __restrict__ out, const float* __restrict__ base,
                                   int n, int h, int w, int cq, double* __restrict__ acc) {
   constexpr int CW = 16, RR = R * R;
   const int y = blockIdx.y, img = blockIdx.z;
@@ -667,14 +698,14 @@ __global__ __launch_bounds__(256) void k_ps_nchw_addbase(const T* __restrict__ s
         *reinterpret_cast<uint2*>(v) = *reinterpret_cast<const uint2*>(rec);  // 4 fp16 channels
       }
       const float b = base[(((size_t)img * cq + c) * h + y) * w + x];
-      float* o = out + (((size_t)img * cq + c) * OH + (size_t)y * R) * OW + (size_t)x * R;
+      HT* o = out + (((size_t)img * cq + c) * OH + (size_t)y * R) * OW + (size_t)x * R;
       float f[RR];
 #pragma unroll
       for (int k = 0; k < RR; ++k) f[k] = (float)v[k] + b;
 #pragma unroll
       for (int dy = 0; dy < R; ++dy) {
-        if constexpr (R == 4) *reinterpret_cast<float4*>(o + (size_t)dy * OW) = make_float4(f[dy * 4], f[dy * 4 + 1], f[dy * 4 + 2], f[dy * 4 + 3]);
-        else *reinterpret_cast<float2*>(o + (size_t)dy * OW) = make_float2(f[dy * 2], f[dy * 2 + 1]);
+        if constexpr (R == 4) hr_st4<HT>(o + (size_t)dy * OW, make_float4(f[dy * 4], f[dy * 4 + 1], f[dy * 4 + 2], f[dy * 4 + 3]));
+        else { hr_st(o + (size_t)dy * OW, f[dy * 2]); hr_st(o + (size_t)dy * OW + 1, f[dy * 2 + 1]); }
       }
       if constexpr (STATS) {
 #pragma unroll
@@ -703,22 +734,23 @@ __global__ __launch_bounds__(256) void k_ps_nchw_addbase(const T* __restrict__ s
     }
   }
 }
-template <typename T>
-void op_ps_nchw_addbase(const T* src, float* out, const float* base, int n, int h, int w, int r, int cq, double* stats_acc, hipStream_t st) {
+template <typename T, typename HT>
+void op_ps_nchw_addbase(const T* src, HT* out, const float* base, int n, int h, int w, int r, int cq, double* stats_acc, hipStream_t st) {
   SS4K_REQUIRE(h <= 65535 && n <= 65535, "pixel shuffle tail: grid limits");
   SS4K_REQUIRE(!stats_acc || cq <= 4, "pixel shuffle tail: statistics for at most 4 colours");
   if (stats_acc) SS4K_HIP(hipMemsetAsync(stats_acc, 0, sizeof(double) * 2 * n * cq * STATS_SLOTS, st));
   if (r == 4) {
-    if (stats_acc) { hipLaunchKernelGGL((k_ps_nchw_addbase<T, 4, true>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq, stats_acc); }
-    else { hipLaunchKernelGGL((k_ps_nchw_addbase<T, 4, false>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq, stats_acc); }
+    if (stats_acc) { hipLaunchKernelGGL((k_ps_nchw_addbase<T, 4, true, HT>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq, stats_acc); }
+    else { hipLaunchKernelGGL((k_ps_nchw_addbase<T, 4, false, HT>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq, stats_acc); }
   } else if (r == 2) {
-    if (stats_acc) { hipLaunchKernelGGL((k_ps_nchw_addbase<T, 2, true>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq, stats_acc); }
-    else { hipLaunchKernelGGL((k_ps_nchw_addbase<T, 2, false>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq, stats_acc); }
+    if (stats_acc) { hipLaunchKernelGGL((k_ps_nchw_addbase<T, 2, true, HT>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq, stats_acc); }
+    else { hipLaunchKernelGGL((k_ps_nchw_addbase<T, 2, false, HT>), grid_rows(w, h, n), dim3(256), 0, st, src, out, base, n, h, w, cq, stats_acc); }
   } else throw Error(SS4K_EINVAL, "SRVGG: upscale must be 2 or 4");
   SS4K_LAUNCH_OK();
 }
-template void op_ps_nchw_addbase<float>(const float*, float*, const float*, int, int, int, int, int, double*, hipStream_t);
-template void op_ps_nchw_addbase<__half>(const __half*, float*, const float*, int, int, int, int, int, double*, hipStream_t);
+template void op_ps_nchw_addbase<float, float>(const float*, float*, const float*, int, int, int, int, int, double*, hipStream_t);
+template void op_ps_nchw_addbase<__half, float>(const __half*, float*, const float*, int, int, int, int, int, double*, hipStream_t);
+template void op_ps_nchw_addbase<__half, __half>(const __half*, __half*, const float*, int, int, int, int, int, double*, hipStream_t);
 
 // BSVD stream mode: the ShiftConv input of frame t (bsvd/model.py:42-53,95-138) takes channels
 // [0, fold) from frame t+1, [fold, 2*fold) from frame t-1 (zeros past either end of the stream) and

@@ -193,6 +193,7 @@ void Model::build(const float* w, size_t n) {
   if (fl & SS4K_MODEL_NO_CHAIN) chain_mode = 1;
   if (fl & SS4K_MODEL_CHAIN) chain_mode = 2;
   if (fl & SS4K_MODEL_NO_PAIR) use_pair = false;
+  if (fl & SS4K_MODEL_HR_F32) hr_f32 = true;
   if (!(fl & (SS4K_MODEL_ONE_CHAIN | SS4K_MODEL_TWO_CHAINS)))
     if (const char* e = std::getenv("SS4K_LANES")) lanes_mode = std::max(0, std::min(2, std::atoi(e)));
   if (const char* e = std::getenv("SS4K_FS_EXACT")) fs_exact = fs_exact || e[0] == '1';
@@ -608,7 +609,7 @@ void Model::abort_forward(hipStream_t st) noexcept {
   if (section_open) { ctx->prof_pool.push_back(section); section_open = false; }
   tune_timed = nullptr; cur_lanes = 1;
   chain_rec = false;
-  out_stats_acc = nullptr; out_stats_done = false;
+  out_stats_acc = nullptr; out_stats_done = false; out_half = false;
 }
 
 void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_t st) {
@@ -633,6 +634,7 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
     if (sub_batch > 0) max_n = std::min(max_n, sub_batch);
     if (n > max_n) {
       out_stats_acc = nullptr;   // per-plane accumulation is not offered across a split batch: the caller makes its own pass
+      SS4K_REQUIRE(!out_half, "forward: an fp16 output tensor is not offered across a split batch");
       for (int i = 0; i < n; i += max_n) {
         const int nn = std::min(max_n, n - i);
         forward(in + (size_t)i * in_channels() * h * w, out + (size_t)i * oc * oh * ow, nn, h, w, st);
@@ -731,7 +733,10 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
     if (plan_only) return;
     // the service may ask for the output's plane statistics to be accumulated while it is written
     double* sacc = out_stats_acc; out_stats_acc = nullptr; out_stats_done = sacc != nullptr;
-    if (f16) op_ps_nchw_addbase<__half>(reinterpret_cast<const __half*>(Z.p), out, in, n, h, w, desc.scale, 3, sacc, st);
+    const bool half_out = out_half; out_half = false;
+    SS4K_REQUIRE(!half_out || f16, "internal: fp16 output tensor requested from an fp32 network");
+    if (half_out) op_ps_nchw_addbase<__half, __half>(reinterpret_cast<const __half*>(Z.p), reinterpret_cast<__half*>(out), in, n, h, w, desc.scale, 3, sacc, st);
+    else if (f16) op_ps_nchw_addbase<__half>(reinterpret_cast<const __half*>(Z.p), out, in, n, h, w, desc.scale, 3, sacc, st);
     else op_ps_nchw_addbase<float>(reinterpret_cast<const float*>(Z.p), out, in, n, h, w, desc.scale, 3, sacc, st);
     return;
   }

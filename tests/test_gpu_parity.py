@@ -597,3 +597,25 @@ def test_fsrcnn_f16_mode_vs_oracle(ctx, factor, tag, shape):
     record_measured(f"fsrcnn_f16_x{factor}_{tag}_{shape[2]}x{shape[3]}", psnr_db=p, max_abs_err=err, peak=peak)
     print(f"fsrcnn f16 x{factor} {tag} {shape}: PSNR {p:.1f} dB, max |d| {err:.3g} of peak {peak:.3g}")
     assert p > 55.0 and err < 1e-2 * max(1.0, peak)
+
+
+# ------------------------------------------------------------------------------ fp16 HR tensor on the batched service path
+@pytest.mark.parametrize("out_shape,lr_shape,n", [((144, 256), (72, 128), 2), (None, (72, 128), 1), ((180, 250), (90, 125), 3)])
+def test_srvgg_f16_half_hr_tensor_vs_fp32_hr_tensor(ctx, out_shape, lr_shape, n):
+    """An fp16 SRVGG writes its x4 output tensor as fp16 for the service's fused tail (statistics ride along in fp32, area map,
+    normalise + colour match + clamp in place, bicubic): against the same model with SS4K_MODEL_HR_F32 the uint8 frames may
+    differ by 1 LSB where a value sits within fp16's 2^-12 of a truncation boundary.  Covers the 2:1 bicubic fast path, no
+    resize, and a ragged size on the generic kernels."""
+    t = W.dni_blend(W.srvgg_table(3, num_conv=4), W.srvgg_table(4, num_conv=4), 0.5)
+    flat = W.flatten(t, W.srvgg_keys(4))
+    frames = torch.from_numpy(smooth_u8(31, (n, lr_shape[0], lr_shape[1], 3))).cuda()
+    outs = []
+    for fl in (_capi.MODEL_HR_F32, 0):
+        sr = _capi.Model(ctx, _capi.make_desc(_capi.SRVGG, _capi.F16, scale=4, num_feat=64, num_block=4, flags=fl), flat)
+        up = _capi.Upscaler(ctx, sr, lr_shape, out_shape, True, False, None, 1.0)
+        outs.append(up(frames).cpu().to(torch.int16))
+    d = (outs[0] - outs[1]).abs()
+    frac = float((d != 0).float().mean())
+    record_measured(f"srvgg_half_hr_{lr_shape[0]}x{lr_shape[1]}_n{n}", max_lsb=int(d.max()), frac_differing=frac)
+    print(f"fp16 vs fp32 HR tensor {lr_shape} -> {out_shape}: max {int(d.max())} LSB, {100 * frac:.2f} % of bytes differ")
+    assert int(d.max()) <= 1 and frac < 0.08
