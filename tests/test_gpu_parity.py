@@ -568,7 +568,9 @@ def test_fused_tails_full_size_identical(ctx):
     """Same at the shipped default's size (SRVGG x4 on 720p, bicubic to 1440p, colour match on) in fp16, where the
     statistics come out of the PixelShuffle tail's accumulators: mean / std may differ in the last fp64 bits of
     the sum, so frames are compared within 1 LSB and must be almost everywhere identical."""
-    sr = factory.build_model_esrgan(ctx, "realesr-general-x4v3", weights="synthetic", dtype="f16", seed=3)
+    # (SS4K_MODEL_HR_F32: the fused path of an fp16 SRVGG would otherwise keep the HR tensor in fp16 - that difference has its own test,
+    # test_srvgg_f16_half_hr_tensor_vs_fp32_hr_tensor; this one is about the fusion)
+    sr = factory.build_model_esrgan(ctx, "realesr-general-x4v3", weights="synthetic", dtype="f16", seed=3, flags=_capi.MODEL_HR_F32)
     up_f = _capi.Upscaler(ctx, sr, (720, 1280), (1440, 2560), True, False, None, 0.5)
     up_u = _capi.Upscaler(ctx, sr, (720, 1280), (1440, 2560), True, False, None, 0.5)
     up_u.enable_taps(True)
