@@ -43,7 +43,7 @@ CONV_KERNEL_NAME = ("3x3 implicit-GEMM conv, all launches of a step: ss4k::conv3
 WORKLOADS = {
     "rrdbnet": "RealESRGAN RRDBNet x2 (23 blocks) 720p->1440p fp16 [BASELINE configs[2]]",
     "fsrcnn_f16": "FSRCNN x2 720p->1440p in the reference engine's precision: fp16 operands and intermediates, fp32 accumulation; all three stages on fp16 MFMA (dtype f16; PSNR against the fp32 CPU forward reported) [BASELINE configs[1] at TensorRT-fp16 precision]",
-    "fsrcnn": "FSRCNN x2 720p->1440p, fp32 tensors; head exact fp32 (vector ALUs), mapping + transposed conv on fp16 MFMA with hi/lo-split operands and fp32 accumulation (fp32-grade: ~1e-6 of the exact kernels) [BASELINE configs[1]]",
+    "fsrcnn": "FSRCNN x2 720p->1440p, fp32 tensors; all three stages on fp16 MFMA with hi/lo-split operands and fp32 accumulation (fp32-grade: ~1e-6 of the exact kernels) [BASELINE configs[1]]",
     "pipeline": "BSVD denoise + RealESRGAN RRDBNet x2 720p->1440p fp16, per-frame path [BASELINE configs[3]]",
     "srvgg": "SRVGGNetCompact realesr-general-x4v3 x4 + bicubic to 1440p fp16 (the reference's shipped default)",
     "rrdbnet_x4": "RealESRGAN RRDBNet x4 (23 blocks) 1080p->4320x7680->bicubic 2160x3840 fp16 [BASELINE configs[4], per GPU]",
@@ -252,8 +252,8 @@ def conv_roofline(ctx, up, frames, out, psteps=3):
 
 def fsrcnn_stage_rooflines(ctx, up, frames, out, psteps=3, half=False):
     """FSRCNN's three stages timed live (events around each stage on the launch stream), each against the unit that bounds it:
-    the head runs exact fp32 on the vector ALUs (157.3 TFLOP/s); mapping and tail run on the fp16 matrix cores with hi/lo-split
-    operands - three MFMAs per product, so their algorithmic bound is the dense fp16 peak / 3.  half (dtype f16): every stage is
+    all three run on the fp16 matrix cores with hi/lo-split operands - three MFMAs per product, so their algorithmic bound is the
+    dense fp16 peak / 3 (the exact-fp32 vector-ALU head is kept for SS4K_MODEL_FS_EXACT).  half (dtype f16): every stage is
     one fp16 MFMA per product, against the dense fp16 peak."""
     ctx.prof_reset(); ctx.prof_enable(True)
     for _ in range(psteps):
@@ -263,7 +263,7 @@ def fsrcnn_stage_rooflines(ctx, up, frames, out, psteps=3, half=False):
     table = ((1, "head (5x5 conv 1->56 + 1x1 56->12, fp16 MFMA)", MFMA_F16_DENSE_PEAK_TFLOPS, "dense fp16 MFMA peak"),
              (2, "mapping (4 x conv3x3 12->12, fp16 MFMA)", MFMA_F16_DENSE_PEAK_TFLOPS, "dense fp16 MFMA peak"),
              (3, "tail (1x1 12->56 + 9x9 transposed conv, fp16 MFMA)", MFMA_F16_DENSE_PEAK_TFLOPS, "dense fp16 MFMA peak")) if half else (
-                                  (1, "head (5x5 conv 1->56 + 1x1 56->12, exact fp32, vector ALUs)", F32_VECTOR_PEAK_TFLOPS, "fp32 vector peak"),
+                                  (1, "head (5x5 conv 1->56 + 1x1 56->12, fp16 MFMA, hi/lo split)", MFMA_F16_DENSE_PEAK_TFLOPS / 3, "dense fp16 MFMA peak / 3"),
                                    (2, "mapping (4 x conv3x3 12->12, fp16 MFMA, hi/lo split)", MFMA_F16_DENSE_PEAK_TFLOPS / 3, "dense fp16 MFMA peak / 3"),
                                    (3, "tail (1x1 12->56 + 9x9 transposed conv, fp16 MFMA, hi/lo split)", MFMA_F16_DENSE_PEAK_TFLOPS / 3, "dense fp16 MFMA peak / 3"))
     for kind, name, peak, unit in table:

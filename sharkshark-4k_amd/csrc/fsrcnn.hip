@@ -1,9 +1,10 @@
 // FSRCNN forward (reference src/upscale/model/fsrcnn/model.py:14-62) on fp32 planes.
-// Channel depths are 1 / 56 / 12, far too shallow for a dense MFMA contraction, so these are
-// direct convolutions on the vector ALUs: one thread per low-resolution pixel holds every output
-// channel in registers, weights are wave-uniform (scalar loads), activations are stored as groups of
-// four channels, group-major ([C/4][pixel][4] fp32), so a wave's 16-byte loads/stores of one group are
-// one contiguous kilobyte whatever the channel count.  Layers are fused where no halo is needed:
+// Three arithmetic modes (fsrcnn_forward): fp32-grade on the fp16 matrix cores with hi/lo-split operands (default), plain fp16
+// operands (an SS4K_F16 model), and the exact-fp32 kernels this file started with (SS4K_MODEL_FS_EXACT; the A/B reference).
+// The exact kernels: channel depths are 1 / 56 / 12, so these are direct convolutions on the vector ALUs (head, mapping) and
+// fp32 MFMA (tail): one thread per low-resolution pixel holds every output channel in registers, weights are wave-uniform
+// (scalar loads).  Activations between the stages are groups of four channels, group-major ([C/4][pixel][4]; fp32, or fp16 in
+// fp16 mode), so a wave's loads/stores of one group are contiguous whatever the channel count.  Layers are fused where no halo is needed:
 //   head  = conv5x5(1->56)+PReLU -> conv1x1(56->12)+PReLU        (56-wide map never leaves registers)
 //   map   = conv3x3(12->12)+PReLU                                 (x4)
 //   tail  = conv1x1(12->56)+PReLU -> ConvTranspose 9x9 stride s   (fused, exact-fp32 MFMA: k_fs_tail)
@@ -560,23 +561,34 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
 constexpr int FH_COLS = 128, FH_RING = 8, FH_ROWH = 136 + 8;   // ring row: columns X0 - 2 .. X0 + 133 (+ pad), fp16
 
 
-__global__ __launch_bounds__(256, 2) void k_fs_head_h(const float* __restrict__ in, uint2* __restrict__ out,
+// SPLIT: the same structure at fp32 accuracy (the default, fp32-grade mode): every operand hi + 2^-11 lo, three MFMAs per product (as the
+// mapping stage and the tail), two fp16 input rings, fp32 PReLU and re-split of the 56-channel map, fp32 output.
+template <bool SPLIT>
+__global__ __launch_bounds__(256, SPLIT ? 1 : 2) void k_fs_head_m(const float* __restrict__ in, void* __restrict__ outv,
                                                       const float* __restrict__ wf, const float* __restrict__ bf,
                                                       const float* __restrict__ af, const float* __restrict__ ws,
                                                       const float* __restrict__ bs, const float* __restrict__ as,
                                                       int planes, int h, int w, int bands) {
-  __shared__ __attribute__((aligned(16))) _Float16 ring_all[4][FH_RING][FH_ROWH];
+  constexpr int NP = SPLIT ? 2 : 1;   // operand parts: hi (, lo)
+  __shared__ __attribute__((aligned(16))) _Float16 ring_all[4][FH_RING][NP][FH_ROWH];
+  __shared__ float slope_lds[SPLIT ? 2 * 2 * 16 + 2 * 8 : 1];   // SPLIT: fp32 slopes per lane half, re-read per use (registers are short)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, kq = lane >> 5;
   const int strips = (w + FH_COLS - 1) / FH_COLS;
   const int wid = blockIdx.x * 4 + wave;
   const int strip = wid % strips, band = (wid / strips) % bands, plane = wid / (strips * bands);
   const int rpb = (h + bands - 1) / bands, ylo = band * rpb, yhi = min(h, ylo + rpb);
+  if constexpr (SPLIT) {
+    // [kq][block b][i]: slope of channel 32b + (i&3) + 8(i>>2) + 4kq; then [kq][i] for the shrink's rows (i&3) + 8(i>>2) + 4kq
+    if (tid < 64) { const int q = tid >> 5, bb = (tid >> 4) & 1, i = tid & 15, c = 32 * bb + (i & 3) + 8 * (i >> 2) + 4 * q; slope_lds[tid] = c < 56 ? af[c] : 1.f; }
+    else if (tid < 80) { const int q = (tid - 64) >> 3, i = tid & 7, c = (i & 3) + 8 * (i >> 2) + 4 * q; slope_lds[tid] = c < 12 ? as[c] : 1.f; }
+    __syncthreads();
+  }
   if (plane >= planes || ylo >= yhi) return;   // whole waves leave: nothing below synchronises across waves
-  _Float16 (*ring)[FH_ROWH] = ring_all[wave];
+  _Float16 (*ring)[NP][FH_ROWH] = ring_all[wave];
   const int X0 = strip * FH_COLS;
 
-  // first-product weights: [shift g][K-step s][cout block b]; lane (m = n, kq): slot j is tap (dy = 2s + kq, dx = j - g)
-  uint4 A1[2][3][2];
+  // first-product weights: [part][shift g][K-step s][cout block b]; lane (m = n, kq): slot j is tap (dy = 2s + kq, dx = j - g)
+  uint4 A1[NP][2][3][2];
 #pragma unroll
   for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -592,10 +604,14 @@ __global__ __launch_bounds__(256, 2) void k_fs_head_h(const float* __restrict__ 
           if (dy < 5) { if (dx >= 0 && dx < 5 && co < 56) v[j] = wf[(dy * 5 + dx) * 56 + co]; }
           else if (j == 0) v[j] = co < 56 ? bf[co] : co == 56 ? 1.f : 0.f;   // the bias slot (its pixel operand is the constant 1)
         }
-        A1[g][s3][b] = make_uint4(half2_rne(v[0], v[1]), half2_rne(v[2], v[3]), half2_rne(v[4], v[5]), half2_rne(v[6], v[7]));
+        uint32_t ph[4], pl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pack2<SPLIT>(v[2 * j], v[2 * j + 1], ph[j], pl[j]);
+        A1[0][g][s3][b] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        if constexpr (SPLIT) A1[1][g][s3][b] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
       }
   // second-product weights: K-step s4, slot j is the channel accumulator register i = 8*(s4&1) + j of block s4>>1 holds in lane half kq
-  uint4 A2[4];
+  uint4 A2[NP][4];
 #pragma unroll
   for (int s4 = 0; s4 < 4; ++s4) {
     float v[8];
@@ -604,26 +620,31 @@ __global__ __launch_bounds__(256, 2) void k_fs_head_h(const float* __restrict__ 
       const int i = 8 * (s4 & 1) + j, ch = 32 * (s4 >> 1) + (i & 3) + 8 * (i >> 2) + 4 * kq;
       v[j] = n < 12 ? (ch < 56 ? ws[ch * 12 + n] : ch == 56 ? bs[n] : 0.f) : 0.f;
     }
-    A2[s4] = make_uint4(half2_rne(v[0], v[1]), half2_rne(v[2], v[3]), half2_rne(v[4], v[5]), half2_rne(v[6], v[7]));
+    uint32_t ph[4], pl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pack2<SPLIT>(v[2 * j], v[2 * j + 1], ph[j], pl[j]);
+    A2[0][s4] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+    if constexpr (SPLIT) A2[1][s4] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
   }
-  // PReLU slopes of the channels this lane's accumulators hold, packed in pairs
+  // fp16 mode: PReLU slopes of the channels this lane's accumulators hold, packed in pairs (SPLIT: fp32, in LDS)
   uint32_t sl1[2][8], sl2[4];
+  if constexpr (!SPLIT) {
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int i = 0; i < 16; i += 2) {
-      const int c0 = 32 * b + (i & 3) + 8 * (i >> 2) + 4 * kq;
-      sl1[b][i >> 1] = half2_rne(c0 < 56 ? af[c0] : 1.f, c0 + 1 < 56 ? af[c0 + 1] : 1.f);
+      for (int i = 0; i < 16; i += 2) {
+        const int c0 = 32 * b + (i & 3) + 8 * (i >> 2) + 4 * kq;
+        sl1[b][i >> 1] = half2_rne(c0 < 56 ? af[c0] : 1.f, c0 + 1 < 56 ? af[c0 + 1] : 1.f);
+      }
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      const int c0 = (i & 3) + 8 * (i >> 2) + 4 * kq;
+      sl2[i >> 1] = half2_rne(c0 < 12 ? as[c0] : 1.f, c0 + 1 < 12 ? as[c0 + 1] : 1.f);
     }
-#pragma unroll
-  for (int i = 0; i < 8; i += 2) {
-    const int c0 = (i & 3) + 8 * (i >> 2) + 4 * kq;
-    sl2[i >> 1] = half2_rne(c0 < 12 ? as[c0] : 1.f, c0 + 1 < 12 ? as[c0 + 1] : 1.f);
   }
 
   const size_t plane_px = (size_t)h * w, total = (size_t)planes * plane_px;
   const float* src = in + (size_t)plane * plane_px;
-  uint2* dst = out + (size_t)plane * plane_px;
   // loader: ring column c is image column X0 - 2 + c; a lane moves columns lane, lane + 64 and (lane < 8) lane + 128
   auto fetch = [&](int y, float (&v)[3]) {
 #pragma unroll
@@ -633,15 +654,25 @@ __global__ __launch_bounds__(256, 2) void k_fs_head_h(const float* __restrict__ 
     }
   };
   auto put = [&](int y, const float (&v)[3]) {
-    _Float16* row = ring[y & (FH_RING - 1)];
-    row[lane] = (_Float16)v[0]; row[lane + 64] = (_Float16)v[1];
-    if (lane < 8) row[lane + 128] = (_Float16)v[2];
+    _Float16 (*row)[FH_ROWH] = ring[y & (FH_RING - 1)];
+    if constexpr (SPLIT) {
+      uint32_t h01, l01, h2, l2;
+      split2(v[0], v[1], h01, l01); split2(v[2], 0.f, h2, l2);
+      uint16_t* rh = reinterpret_cast<uint16_t*>(row[0]); uint16_t* rl = reinterpret_cast<uint16_t*>(row[1]);
+      rh[lane] = (uint16_t)h01; rh[lane + 64] = (uint16_t)(h01 >> 16);
+      rl[lane] = (uint16_t)l01; rl[lane + 64] = (uint16_t)(l01 >> 16);
+      if (lane < 8) { rh[lane + 128] = (uint16_t)h2; rl[lane + 128] = (uint16_t)l2; }
+    } else {
+      row[0][lane] = (_Float16)v[0]; row[0][lane + 64] = (_Float16)v[1];
+      if (lane < 8) row[0][lane + 128] = (_Float16)v[2];
+    }
   };
   float pre[3];
   for (int y = ylo - 2; y < ylo + 2; ++y) { fetch(y, pre); put(y, pre); }
   fetch(ylo + 2, pre);
   const f32x16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const uint4 one_op = make_uint4(0x00003c00u, 0u, 0u, 0u);   // {1.0, 0, ...}: the bias slot's pixel operand
+  const uint4 one_op = make_uint4(0x00003c00u, 0u, 0u, 0u), zero_op = make_uint4(0u, 0u, 0u, 0u);   // {1.0, 0, ...}: the bias slot's pixel operand
+  constexpr float LO = 1.f / 2048.f;
   for (int y = ylo; y < yhi; ++y) {
     put(y + 2, pre);
     fetch(y + 3, pre);
@@ -650,46 +681,91 @@ __global__ __launch_bounds__(256, 2) void k_fs_head_h(const float* __restrict__ 
       const int P = X0 + 64 * pass;
       if (P >= w) break;   // wave-uniform
       // pixel operands: 8 columns from ring column 64*pass + 2n of rows y - 2 + 2s + kq
-      uint4 B1[3];
+      uint4 B1[NP][3];
 #pragma unroll
-      for (int s3 = 0; s3 < 3; ++s3) {
-        const uint32_t* p32 = reinterpret_cast<const uint32_t*>(&ring[(y - 2 + 2 * s3 + kq) & (FH_RING - 1)][64 * pass + 2 * n]);
-        B1[s3] = make_uint4(p32[0], p32[1], p32[2], p32[3]);
-      }
-      if (kq == 1) B1[2] = one_op;
-      uint32_t o[2][4];   // [pixel parity][regs 0-1: channels of accumulator registers 0-3, 2-3: of registers 4-7]
+      for (int part = 0; part < NP; ++part)
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+          const uint32_t* p32 = reinterpret_cast<const uint32_t*>(&ring[(y - 2 + 2 * s3 + kq) & (FH_RING - 1)][part][64 * pass + 2 * n]);
+          B1[part][s3] = make_uint4(p32[0], p32[1], p32[2], p32[3]);
+        }
+      if (kq == 1) { B1[0][2] = one_op; if constexpr (SPLIT) B1[1][2] = zero_op; }
+      uint32_t o[2][4];   // fp16 mode: [pixel parity][regs 0-1: channels of accumulator registers 0-3, 2-3: of registers 4-7]
+      float of[2][8];     // SPLIT: the same twelve channels in fp32
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        uint32_t E[2][8];
+        uint32_t E[NP][2][8];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          f32x16v acc = zero16;
+          f32x16v acc = zero16, acc2 = zero16;
 #pragma unroll
-          for (int s3 = 0; s3 < 3; ++s3)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A1[g][s3][b]), __builtin_bit_cast(f16x8v, B1[s3]), acc, 0, 0, 0);
+          for (int s3 = 0; s3 < 3; ++s3) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A1[0][g][s3][b]), __builtin_bit_cast(f16x8v, B1[0][s3]), acc, 0, 0, 0);
+            if constexpr (SPLIT) {
+              acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A1[0][g][s3][b]), __builtin_bit_cast(f16x8v, B1[1][s3]), acc2, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A1[1][g][s3][b]), __builtin_bit_cast(f16x8v, B1[0][s3]), acc2, 0, 0, 0);
+            }
+          }
+          if constexpr (SPLIT) {
+            const float4* slp = reinterpret_cast<const float4*>(slope_lds + 32 * kq + 16 * b);
 #pragma unroll
-          for (int i = 0; i < 16; i += 2) E[b][i >> 1] = prelu_h2(half2_rne(acc[i], acc[i + 1]), sl1[b][i >> 1]);
+            for (int q = 0; q < 4; ++q) {
+              const float4 sv = slp[q];
+              const float sl[4] = {sv.x, sv.y, sv.z, sv.w};
+              float ev[4];
+#pragma unroll
+              for (int t = 0; t < 4; ++t) ev[t] = prelu(fmaf(acc2[4 * q + t], LO, acc[4 * q + t]), sl[t]);
+              split2(ev[0], ev[1], E[0][b][2 * q], E[1][b][2 * q]);
+              split2(ev[2], ev[3], E[0][b][2 * q + 1], E[1][b][2 * q + 1]);
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) E[0][b][i >> 1] = prelu_h2(half2_rne(acc[i], acc[i + 1]), sl1[b][i >> 1]);
+          }
         }
-        f32x16v d2 = zero16;
+        f32x16v d2 = zero16, d2l = zero16;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
           const int b = s4 >> 1, o4 = 4 * (s4 & 1);
-          const uint4 e = make_uint4(E[b][o4], E[b][o4 + 1], E[b][o4 + 2], E[b][o4 + 3]);
-          d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A2[s4]), __builtin_bit_cast(f16x8v, e), d2, 0, 0, 0);
+          const uint4 e = make_uint4(E[0][b][o4], E[0][b][o4 + 1], E[0][b][o4 + 2], E[0][b][o4 + 3]);
+          d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A2[0][s4]), __builtin_bit_cast(f16x8v, e), d2, 0, 0, 0);
+          if constexpr (SPLIT) {
+            const uint4 el = make_uint4(E[1][b][o4], E[1][b][o4 + 1], E[1][b][o4 + 2], E[1][b][o4 + 3]);
+            d2l = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A2[0][s4]), __builtin_bit_cast(f16x8v, el), d2l, 0, 0, 0);
+            d2l = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A2[1][s4]), __builtin_bit_cast(f16x8v, e), d2l, 0, 0, 0);
+          }
         }
+        if constexpr (SPLIT) {
+          const float4* slp = reinterpret_cast<const float4*>(slope_lds + 64 + 8 * kq);
+          const float4 s0 = slp[0], s1 = slp[1];
+          const float sl[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
-        for (int i = 0; i < 8; i += 2) o[g][i >> 1] = prelu_h2(half2_rne(d2[i], d2[i + 1]), sl2[i >> 1]);
+          for (int i = 0; i < 8; ++i) of[g][i] = prelu(fmaf(d2l[i], LO, d2[i]), sl[i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; i += 2) o[g][i >> 1] = prelu_h2(half2_rne(d2[i], d2[i + 1]), sl2[i >> 1]);
+        }
       }
       // lane half 0 holds channel groups 0 (registers 0-3) and 2 (registers 4-7), lane half 1 group 1, of pixels P + 2n, P + 2n + 1
       const int x = P + 2 * n;
-      uint2* row = dst + (size_t)y * w + x;
       const size_t ga = (size_t)kq * total;
-      if (x + 1 < w) {
-        *reinterpret_cast<uint4*>(row + ga) = make_uint4(o[0][0], o[0][1], o[1][0], o[1][1]);
-        if (kq == 0) *reinterpret_cast<uint4*>(row + 2 * total) = make_uint4(o[0][2], o[0][3], o[1][2], o[1][3]);
-      } else if (x < w) {
-        row[ga] = make_uint2(o[0][0], o[0][1]);
-        if (kq == 0) row[2 * total] = make_uint2(o[0][2], o[0][3]);
+      if constexpr (SPLIT) {
+        float4* row = reinterpret_cast<float4*>(outv) + (size_t)plane * plane_px + (size_t)y * w + x;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+          if (x + g < w) {
+            row[ga + g] = make_float4(of[g][0], of[g][1], of[g][2], of[g][3]);
+            if (kq == 0) row[2 * total + g] = make_float4(of[g][4], of[g][5], of[g][6], of[g][7]);
+          }
+      } else {
+        uint2* row = reinterpret_cast<uint2*>(outv) + (size_t)plane * plane_px + (size_t)y * w + x;
+        if (x + 1 < w) {
+          *reinterpret_cast<uint4*>(row + ga) = make_uint4(o[0][0], o[0][1], o[1][0], o[1][1]);
+          if (kq == 0) *reinterpret_cast<uint4*>(row + 2 * total) = make_uint4(o[0][2], o[0][3], o[1][2], o[1][3]);
+        } else if (x < w) {
+          row[ga] = make_uint2(o[0][0], o[0][1]);
+          if (kq == 0) row[2 * total] = make_uint2(o[0][2], o[0][3]);
+        }
       }
     }
   }
@@ -1057,14 +1133,19 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
   // per-stage timing for bench.py's stage rooflines (ss4k_prof_read_kind); algorithmic FLOPs per LR pixel and plane:
   // head 2 * (25 * 56 + 56 * 12), mapping 2 * 4 * 9 * 12 * 12, tail 2 * (12 * 56 + 81 * 56)  (12 464 MAC in all)
   ProfEvent pe = ctx->prof_begin(st, PROF_FS_HEAD);
-  if (half) {
+  // fp16 mode and the default fp32-grade mode run the head on the matrix cores (k_fs_head_m: one | three MFMAs per product); the exact
+  // mode keeps the vector-ALU kernel
+  if (!exact) {
     const int hstrips = (w + FH_COLS - 1) / FH_COLS;
-    // two waves per SIMD over the chip, bands of at least 8 rows (every band re-reads 4 halo rows)
-    const int hb0 = std::max(1, std::min((h + 7) / 8, 8 * ctx->num_cu / std::max(1, planes * hstrips)));
+    // two waves (fp32-grade: one) per SIMD over the chip, bands of at least 8 rows (every band re-reads 4 halo rows)
+    const int per_simd = half ? 2 : 1;
+    const int hb0 = std::max(1, std::min((h + 7) / 8, 4 * per_simd * ctx->num_cu / std::max(1, planes * hstrips)));
     const int hbands = (h + (h + hb0 - 1) / hb0 - 1) / ((h + hb0 - 1) / hb0);
     const unsigned hwaves = (unsigned)(planes * hbands * hstrips);
-    hipLaunchKernelGGL(k_fs_head_h, dim3((hwaves + 3) / 4), block, 0, st, in, reinterpret_cast<uint2*>(ws12a), W.w_feat, W.b_feat,
-                       W.a_feat, W.w_shrink, W.b_shrink, W.a_shrink, planes, h, w, hbands);
+    if (half) hipLaunchKernelGGL(k_fs_head_m<false>, dim3((hwaves + 3) / 4), block, 0, st, in, static_cast<void*>(ws12a), W.w_feat, W.b_feat,
+                                 W.a_feat, W.w_shrink, W.b_shrink, W.a_shrink, planes, h, w, hbands);
+    else hipLaunchKernelGGL(k_fs_head_m<true>, dim3((hwaves + 3) / 4), block, 0, st, in, static_cast<void*>(ws12a), W.w_feat, W.b_feat,
+                            W.a_feat, W.w_shrink, W.b_shrink, W.a_shrink, planes, h, w, hbands);
   } else
   hipLaunchKernelGGL(k_fs_head, grid, block, 0, st, in, ws12a, W.w_feat, W.b_feat, W.a_feat, W.w_shrink, W.b_shrink,
                      W.a_shrink, planes, h, w);
