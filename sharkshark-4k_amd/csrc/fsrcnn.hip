@@ -564,7 +564,7 @@ constexpr int FH_COLS = 128, FH_RING = 8, FH_ROWH = 136 + 8;   // ring row: colu
 // SPLIT: the same structure at fp32 accuracy (the default, fp32-grade mode): every operand hi + 2^-11 lo, three MFMAs per product (as the
 // mapping stage and the tail), two fp16 input rings, fp32 PReLU and re-split of the 56-channel map, fp32 output.
 template <bool SPLIT>
-__global__ __launch_bounds__(256, SPLIT ? 1 : 2) void k_fs_head_m(const float* __restrict__ in, void* __restrict__ outv,
+__global__ __launch_bounds__(256, 2) void k_fs_head_m(const float* __restrict__ in, void* __restrict__ outv,
                                                       const float* __restrict__ wf, const float* __restrict__ bf,
                                                       const float* __restrict__ af, const float* __restrict__ ws,
                                                       const float* __restrict__ bs, const float* __restrict__ as,
@@ -587,10 +587,13 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void k_fs_head_m(const float* _
   _Float16 (*ring)[NP][FH_ROWH] = ring_all[wave];
   const int X0 = strip * FH_COLS;
 
-  // first-product weights: [part][shift g][K-step s][cout block b]; lane (m = n, kq): slot j is tap (dy = 2s + kq, dx = j - g)
-  uint4 A1[NP][2][3][2];
+  // first-product weights: [part][shift g][K-step s][cout block b]; lane (m = n, kq): slot j is tap (dy = 2s + kq, dx = j - g).
+  // SPLIT holds shift 0 only (registers: two waves per SIMD need <= 256) and derives shift 1 where it is used: the same eight fp16
+  // slots moved up by one - except the bias slot's lanes (K-step 2, kq = 1), whose operand is the same for both shifts
+  constexpr int NG = SPLIT ? 1 : 2;
+  uint4 A1[NP][NG][3][2];
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+  for (int g = 0; g < NG; ++g)
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3)
 #pragma unroll
@@ -671,6 +674,17 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void k_fs_head_m(const float* _
   for (int y = ylo - 2; y < ylo + 2; ++y) { fetch(y, pre); put(y, pre); }
   fetch(ylo + 2, pre);
   const f32x16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto a1 = [&](int part, int g, int s3, int b) -> uint4 {   // the weight operand of shift g
+    if constexpr (!SPLIT) return A1[part][g][s3][b];
+    else {
+      const uint4 v = A1[part][0][s3][b];
+      if (g == 0) return v;
+      uint4 r;
+      r.x = v.x << 16; r.y = __builtin_amdgcn_alignbit(v.y, v.x, 16); r.z = __builtin_amdgcn_alignbit(v.z, v.y, 16); r.w = __builtin_amdgcn_alignbit(v.w, v.z, 16);
+      if (s3 == 2 && kq == 1) r = v;
+      return r;
+    }
+  };
   const uint4 one_op = make_uint4(0x00003c00u, 0u, 0u, 0u), zero_op = make_uint4(0u, 0u, 0u, 0u);   // {1.0, 0, ...}: the bias slot's pixel operand
   constexpr float LO = 1.f / 2048.f;
   for (int y = ylo; y < yhi; ++y) {
@@ -691,19 +705,23 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void k_fs_head_m(const float* _
         }
       if (kq == 1) { B1[0][2] = one_op; if constexpr (SPLIT) B1[1][2] = zero_op; }
       uint32_t o[2][4];   // fp16 mode: [pixel parity][regs 0-1: channels of accumulator registers 0-3, 2-3: of registers 4-7]
-      float of[2][8];     // SPLIT: the same twelve channels in fp32
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        uint32_t E[NP][2][8];
+        // per cout block: first product, PReLU (+ re-split), and straight away the two K-steps of the second product that consume
+        // this block's activations - only one block's operands are alive at a time
+        f32x16v d2 = zero16, d2l = zero16;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
+          uint32_t E[NP][8];
           f32x16v acc = zero16, acc2 = zero16;
 #pragma unroll
           for (int s3 = 0; s3 < 3; ++s3) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A1[0][g][s3][b]), __builtin_bit_cast(f16x8v, B1[0][s3]), acc, 0, 0, 0);
+            const uint4 wh = a1(0, g, s3, b);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, wh), __builtin_bit_cast(f16x8v, B1[0][s3]), acc, 0, 0, 0);
             if constexpr (SPLIT) {
-              acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A1[0][g][s3][b]), __builtin_bit_cast(f16x8v, B1[1][s3]), acc2, 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A1[1][g][s3][b]), __builtin_bit_cast(f16x8v, B1[0][s3]), acc2, 0, 0, 0);
+              const uint4 wl = a1(1, g, s3, b);
+              acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, wh), __builtin_bit_cast(f16x8v, B1[1][s3]), acc2, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, wl), __builtin_bit_cast(f16x8v, B1[0][s3]), acc2, 0, 0, 0);
             }
           }
           if constexpr (SPLIT) {
@@ -715,32 +733,39 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void k_fs_head_m(const float* _
               float ev[4];
 #pragma unroll
               for (int t = 0; t < 4; ++t) ev[t] = prelu(fmaf(acc2[4 * q + t], LO, acc[4 * q + t]), sl[t]);
-              split2(ev[0], ev[1], E[0][b][2 * q], E[1][b][2 * q]);
-              split2(ev[2], ev[3], E[0][b][2 * q + 1], E[1][b][2 * q + 1]);
+              split2(ev[0], ev[1], E[0][2 * q], E[1][2 * q]);
+              split2(ev[2], ev[3], E[0][2 * q + 1], E[1][2 * q + 1]);
             }
           } else {
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) E[0][b][i >> 1] = prelu_h2(half2_rne(acc[i], acc[i + 1]), sl1[b][i >> 1]);
+            for (int i = 0; i < 16; i += 2) E[0][i >> 1] = prelu_h2(half2_rne(acc[i], acc[i + 1]), sl1[b][i >> 1]);
           }
-        }
-        f32x16v d2 = zero16, d2l = zero16;
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const int b = s4 >> 1, o4 = 4 * (s4 & 1);
-          const uint4 e = make_uint4(E[0][b][o4], E[0][b][o4 + 1], E[0][b][o4 + 2], E[0][b][o4 + 3]);
-          d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A2[0][s4]), __builtin_bit_cast(f16x8v, e), d2, 0, 0, 0);
-          if constexpr (SPLIT) {
-            const uint4 el = make_uint4(E[1][b][o4], E[1][b][o4 + 1], E[1][b][o4 + 2], E[1][b][o4 + 3]);
-            d2l = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A2[0][s4]), __builtin_bit_cast(f16x8v, el), d2l, 0, 0, 0);
-            d2l = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A2[1][s4]), __builtin_bit_cast(f16x8v, e), d2l, 0, 0, 0);
+          for (int hs = 0; hs < 2; ++hs) {
+            const int s4 = 2 * b + hs, o4 = 4 * hs;
+            const uint4 e = make_uint4(E[0][o4], E[0][o4 + 1], E[0][o4 + 2], E[0][o4 + 3]);
+            d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A2[0][s4]), __builtin_bit_cast(f16x8v, e), d2, 0, 0, 0);
+            if constexpr (SPLIT) {
+              const uint4 el = make_uint4(E[1][o4], E[1][o4 + 1], E[1][o4 + 2], E[1][o4 + 3]);
+              d2l = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A2[0][s4]), __builtin_bit_cast(f16x8v, el), d2l, 0, 0, 0);
+              d2l = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A2[1][s4]), __builtin_bit_cast(f16x8v, e), d2l, 0, 0, 0);
+            }
           }
         }
         if constexpr (SPLIT) {
           const float4* slp = reinterpret_cast<const float4*>(slope_lds + 64 + 8 * kq);
           const float4 s0 = slp[0], s1 = slp[1];
           const float sl[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+          float of[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) of[g][i] = prelu(fmaf(d2l[i], LO, d2[i]), sl[i]);
+          for (int i = 0; i < 8; ++i) of[i] = prelu(fmaf(d2l[i], LO, d2[i]), sl[i]);
+          // lane half 0 holds channel groups 0 (registers 0-3) and 2 (registers 4-7), lane half 1 group 1, of pixel P + 2n + g
+          const int xg = P + 2 * n + g;
+          if (xg < w) {
+            float4* row = reinterpret_cast<float4*>(outv) + (size_t)plane * plane_px + (size_t)y * w + xg;
+            row[(size_t)kq * total] = make_float4(of[0], of[1], of[2], of[3]);
+            if (kq == 0) row[2 * total] = make_float4(of[4], of[5], of[6], of[7]);
+          }
         } else {
 #pragma unroll
           for (int i = 0; i < 8; i += 2) o[g][i >> 1] = prelu_h2(half2_rne(d2[i], d2[i + 1]), sl2[i >> 1]);
@@ -750,13 +775,7 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void k_fs_head_m(const float* _
       const int x = P + 2 * n;
       const size_t ga = (size_t)kq * total;
       if constexpr (SPLIT) {
-        float4* row = reinterpret_cast<float4*>(outv) + (size_t)plane * plane_px + (size_t)y * w + x;
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-          if (x + g < w) {
-            row[ga + g] = make_float4(of[g][0], of[g][1], of[g][2], of[g][3]);
-            if (kq == 0) row[2 * total + g] = make_float4(of[g][4], of[g][5], of[g][6], of[g][7]);
-          }
+        // (stored per pixel inside the loop above)
       } else {
         uint2* row = reinterpret_cast<uint2*>(outv) + (size_t)plane * plane_px + (size_t)y * w + x;
         if (x + 1 < w) {
@@ -1138,7 +1157,7 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
   if (!exact) {
     const int hstrips = (w + FH_COLS - 1) / FH_COLS;
     // two waves (fp32-grade: one) per SIMD over the chip, bands of at least 8 rows (every band re-reads 4 halo rows)
-    const int per_simd = half ? 2 : 1;
+    const int per_simd = 2;
     const int hb0 = std::max(1, std::min((h + 7) / 8, 4 * per_simd * ctx->num_cu / std::max(1, planes * hstrips)));
     const int hbands = (h + (h + hb0 - 1) / hb0 - 1) / ((h + hb0 - 1) / hb0);
     const unsigned hwaves = (unsigned)(planes * hbands * hstrips);
