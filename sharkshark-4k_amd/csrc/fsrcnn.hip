@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
       for (int t = 0; t < 2; ++t) {
         const int kin = 8 * kq + j + t;
         v[t] = (ch < 56 && kin < 12) ? we[kin * 56 + ch] : 0.f;
-        if (!SPLIT && ch < 56 && kin == 12) v[t] = be[ch];   // fp16 mode: input slot 12 is the constant 1 (0 outside the image)
+        if (ch < 56 && kin == 12) v[t] = be[ch];   // input slot 12 is the constant 1 (0 outside the image): it carries the expand bias
       }
       pack2<SPLIT>(v[0], v[1], vh[j >> 1], vl[j >> 1]);
     }
@@ -440,6 +440,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
       uint4 xh, xl;
       if constexpr (SPLIT) {
         split2(g0.x, g0.y, xh.x, xl.x); split2(g0.z, g0.w, xh.y, xl.y); split2(g1.x, g1.y, xh.z, xl.z); split2(g1.z, g1.w, xh.w, xl.w);
+        if (hh == 1 && col_ok) xh.z = 0x00003c00u;   // slot 12 = 1 (lo part 0): carries the expand bias; a column outside the image stays all zero
       } else {
         xh = make_uint4(__float_as_uint(g0.x), __float_as_uint(g0.y), __float_as_uint(g1.x), __float_as_uint(g1.y));
         if (hh == 1 && col_ok) xh.z = 0x00003c00u;   // slot 12 = 1: carries the expand bias; a column outside the image stays all zero
@@ -463,14 +464,10 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
       } else
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        f32x16v E1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float4 bv = *reinterpret_cast<const float4*>(&bea[32 * b + 8 * k + 4 * hh]);
-          E1[4 * k] = bv.x; E1[4 * k + 1] = bv.y; E1[4 * k + 2] = bv.z; E1[4 * k + 3] = bv.w;
-        }
+        // (the bias arrives through the constant-1 slot of the input: accumulators start from the inline constant 0, and a column
+        // outside the image - all-zero input - gives PReLU(0) = 0 without a select)
         const f16x8v ah = __builtin_bit_cast(f16x8v, we_hi[b * 64 + lane]), al = __builtin_bit_cast(f16x8v, we_lo[b * 64 + lane]);
-        E1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bxh, E1, 0, 0, 0);
+        f32x16v E1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bxh, zero16, 0, 0, 0);
         f32x16v E2 = zero16;
         if constexpr (SPLIT) {
           E2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bxl, zero16, 0, 0, 0);
@@ -484,7 +481,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const float v = SPLIT ? fmaf(E2[4 * k + t], LO, E1[4 * k + t]) : E1[4 * k + t];
-            ev[4 * k + t] = col_ok ? prelu(v, sv[t]) : 0.f;   // a column outside the image contributes nothing
+            ev[4 * k + t] = prelu(v, sv[t]);
           }
         }
 #pragma unroll
