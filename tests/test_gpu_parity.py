@@ -621,3 +621,21 @@ def test_srvgg_f16_half_hr_tensor_vs_fp32_hr_tensor(ctx, out_shape, lr_shape, n)
     record_measured(f"srvgg_half_hr_{lr_shape[0]}x{lr_shape[1]}_n{n}", max_lsb=int(d.max()), frac_differing=frac)
     print(f"fp16 vs fp32 HR tensor {lr_shape} -> {out_shape}: max {int(d.max())} LSB, {100 * frac:.2f} % of bytes differ")
     assert int(d.max()) <= 1 and frac < 0.08
+
+
+def test_hip_service_fsrcnn_f16_in_process(ctx):
+    """HipUpscalerService(fsrcnn_dtype='f16'): the worker body in-process on the fp16 FSRCNN mode, against the oracle service
+    (uint8 frames: the fp16 mode's own error is ~60 dB down, a 1 LSB flip near truncation boundaries)."""
+    from sharkshark4k_amd.upscale.hip_upscaler import HipUpscalerService
+    table = _t91(2)
+    svc = HipUpscalerService(device=0, denoising=False, upscaler_model="fsrcnn", scale=2, lr_shape=(90, 124), weights={"sr": table},
+                             fsrcnn_dtype="f16")
+    svc.proc_init()
+    frames = torch.from_numpy(smooth_u8(5, (2, 90, 124, 3)))
+    got = svc.upscale(frames.cuda()).cpu()
+    osv = osvc.OracleUpscaler(lambda x: onets.fsrcnn(x, table, 2), upscaler_model="fsrcnn", lr_shape=(90, 124))
+    want = osv.upscale(frames)
+    d = (got.to(torch.int16) - want.to(torch.int16)).abs()
+    frac = float((d != 0).float().mean())
+    record_measured("svc_fsrcnn_f16_90x124", max_lsb=int(d.max()), frac_differing=frac)
+    assert got.shape == want.shape and int(d.max()) <= 1 and frac < 0.08, (int(d.max()), frac)
