@@ -17,6 +17,9 @@ for shape in ((4, 4, 720, 1280), (3, 4, 100, 252), (1, 4, 64, 60)):
 fs = factory.build_model_fsrcnn(ctx, factor=2, weights=W.fsrcnn_table(seed=2), dtype="f16")
 for shape in ((12, 1, 720, 1280), (3, 1, 150, 333)):
     jobs.append((f"fsrcnn f16 {shape}", fs, torch.rand(*shape, generator=g).cuda()))
+fs32 = factory.build_model_fsrcnn(ctx, factor=2, weights=W.fsrcnn_table(seed=2))
+for shape in ((12, 1, 720, 1280), (3, 1, 97, 130)):
+    jobs.append((f"fsrcnn fp32-grade (split MFMA head) {shape}", fs32, torch.rand(*shape, generator=g).cuda()))
 rr = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=4, flags=_capi.MODEL_CHAIN),
                  W.flatten(W.rrdbnet_table(5, scale=2, num_block=4), W.rrdbnet_keys(4)))
 jobs.append(("rrdbnet chain (1, 3, 360, 500)", rr, torch.rand(1, 3, 360, 500, generator=g).cuda()))
