@@ -180,9 +180,13 @@ struct Upscaler {
     const size_t plane = (size_t)lh * lw;
     img.ensure((size_t)P * h * w * 4);
     op_u8nhwc_to_f32nchw(in, img.as<float>(), n, h, w, 3, st);
-    lr.ensure(plane * P * 4);
-    op_area(img.as<float>(), lr.as<float>(), P, h, w, lh, lw, st);  // unconditional in this path (:239-241)
-    const float* lr_before = lr.as<float>();
+    // area resize, unconditional in this path (:239-241); at equal size adaptive average pooling is the identity: no copy
+    const float* lr_before = img.as<float>();
+    if (!(h == lh && w == lw)) {
+      lr.ensure(plane * P * 4);
+      op_area(img.as<float>(), lr.as<float>(), P, h, w, lh, lw, st);
+      lr_before = lr.as<float>();
+    }
     const float* lr_cur = lr_before;
     if (cfg.denoising) {
       lr4.ensure(plane * 4 * n * 4); den.ensure(plane * P * 4 * 2);
