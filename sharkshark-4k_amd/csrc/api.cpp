@@ -209,10 +209,28 @@ struct Upscaler {
     int oc, H, W; sr->out_shape(1, lh, lw, &oc, &H, &W);
     hr.ensure((size_t)P * H * W * 4 * 2);
     float* hrp = hr.as<float>();
+    // fp16 HR tensor where the network can write one and nothing but the fused tail reads it (no HR sharpening pass, no taps)
+    const bool hr16 = !taps_on && !cfg.denoising && sr->can_half_out();
     const double tm0 = now_ms();
+    sr->out_half = hr16;
     if (cfg.sr_is_realesrgan) sr->forward(lr_cur, hrp, n, lh, lw, st);
     else sr->forward(lr_cur, hrp, P, lh, lw, st);  // FSRCNN on the colour planes (:297)
     enq_model_ms = now_ms() - tm0;
+    if (hr16) {
+      __half* hrh = hr.as<__half>();
+      st_hr.ensure(P * 8); st_lr.ensure(P * 8);
+      SS4K_REQUIRE(P <= STATS_MAX_PLANES, "too many frames in one job");
+      st_acc.ensure(sizeof(double) * 2 * P * STATS_SLOTS);
+      op_plane_stats(st_acc.as<double>(), hrh, st_hr.as<float>(), P, H * W, st);
+      op_plane_stats(st_acc.as<double>(), lr_before, st_lr.as<float>(), P, lh * lw, st);
+      const bool rs_ = cfg.out_h > 0 && !(cfg.out_h == H && cfg.out_w == W);
+      if (!rs_) op_tail_fused(hrh, out, static_cast<const float*>(nullptr), n, 3, H, W, 1, 1, st_hr.as<float>(), st_lr.as<float>(), st);
+      else {
+        op_tail_fused(hrh, static_cast<uint8_t*>(nullptr), static_cast<const float*>(nullptr), n, 3, H, W, 1, 1, st_hr.as<float>(), st_lr.as<float>(), st);
+        op_bicubic_u8(hrh, out, n, 3, H, W, cfg.out_h, cfg.out_w, st);
+      }
+      return;
+    }
     if (cfg.denoising) {
       float* hs = hrp + (size_t)P * H * W;
       op_depthwise_reflect(hrp, hs, k_sharp_hr.as<float>(), P, H, W, 3, 1, nullptr, 0, 0, st);  // :298-299

@@ -331,7 +331,7 @@ __device__ __forceinline__ float dpp_shr1(float v) {   // lane i <- lane i - 1
 
 template <int S> struct FsTailGeo { static constexpr int HALO = S == 2 ? 2 : 1, CI = 32 - 2 * HALO; };
 
-template <int S, bool SPLIT>
+template <int S, bool SPLIT, bool OUT_HALF = false>
 __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ in12, float* __restrict__ out,
                                                    const float* __restrict__ we, const float* __restrict__ be,
                                                    const float* __restrict__ ae, const float* __restrict__ wd, float bias,
@@ -534,6 +534,14 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
         fvS o = V[j];
 #pragma unroll
         for (int e = 0; e < S; ++e) o[e] += bias;
+        if constexpr (OUT_HALF) {   // the service's fp16 HR tensor (an fp16 model): S halves per lane and row
+          _Float16* oh = reinterpret_cast<_Float16*>(out) + (size_t)plane * OH * OW + (size_t)Y * OW + (size_t)S * px;
+          typedef _Float16 hvS __attribute__((ext_vector_type(S)));
+          hvS ohv;
+#pragma unroll
+          for (int e = 0; e < S; ++e) ohv[e] = (_Float16)o[e];
+          *reinterpret_cast<hvS*>(oh) = ohv;
+        } else
         *reinterpret_cast<fvS*>(&oplane[(size_t)Y * OW + (size_t)S * px]) = o;
       }
     }
@@ -1137,8 +1145,9 @@ __global__ __launch_bounds__(256, 4) void k_fs_maps4_h(const uint2* __restrict__
 }
 
 void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const float* in, float* out, int planes, int h,
-                    int w, float* ws12a, float* ws12b, int mode, hipStream_t st) {
+                    int w, float* ws12a, float* ws12b, int mode, hipStream_t st, bool out_half) {
   const bool exact = mode == FS_MODE_EXACT, half = mode == FS_MODE_HALF;
+  SS4K_REQUIRE(!out_half || half, "FSRCNN: an fp16 output tensor is offered in fp16 mode only");
   const size_t total = (size_t)planes * h * w;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   // exact (SS4K_FS_EXACT=1 when the model was built): the exact-fp32 kernels - vector-ALU mapping layers, fp32-MFMA tail with
@@ -1240,8 +1249,13 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
     hipLaunchKernelGGL(kern, tgrid, block, lds, st, cur, out, W.w_expand, W.b_expand, W.a_expand, W.w_deconv, W.b_deconv,
                        planes, h, w, bands);
   };
-  if (factor == 2) { if (exact) launch_tail(k_fs_tail<2>, 2); else if (half) launch_tail(k_fs_tail_r<2, false>, 2); else launch_tail(k_fs_tail_r<2, true>, 2); }
-  else { if (exact) launch_tail(k_fs_tail<4>, 4); else if (half) launch_tail(k_fs_tail_r<4, false>, 4); else launch_tail(k_fs_tail_r<4, true>, 4); }
+  if (factor == 2) {
+    if (exact) launch_tail(k_fs_tail<2>, 2); else if (half && out_half) launch_tail(k_fs_tail_r<2, false, true>, 2);
+    else if (half) launch_tail(k_fs_tail_r<2, false>, 2); else launch_tail(k_fs_tail_r<2, true>, 2);
+  } else {
+    if (exact) launch_tail(k_fs_tail<4>, 4); else if (half && out_half) launch_tail(k_fs_tail_r<4, false, true>, 4);
+    else if (half) launch_tail(k_fs_tail_r<4, false>, 4); else launch_tail(k_fs_tail_r<4, true>, 4);
+  }
   ctx->prof_end(pe, st, 10416.0 * (double)total);
   SS4K_HIP(hipGetLastError());
 }

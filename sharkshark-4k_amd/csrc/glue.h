@@ -13,7 +13,8 @@ constexpr int STATS_MAX_PLANES = 4096;
 // doubles): thousands of workgroups adding into ONE address pair per plane serialise in the memory-side atomic units
 // (measured: the statistics pass ran at 1.4 TB/s, the PixelShuffle tail doubled its time when the sums rode along)
 constexpr int STATS_SLOTS = 32;
-void op_plane_stats(double* acc, const float* in, float* stats, int planes, int hw, hipStream_t st);
+template <typename HT>
+void op_plane_stats(double* acc, const HT* in, float* stats, int planes, int hw, hipStream_t st);
 void op_plane_stats_finish(const double* acc, float* stats, int planes, int hw, hipStream_t st);
 // HT: element type of the network's HR output tensor (float, or __half where the network's tail can write it)
 template <typename HT>
@@ -64,6 +65,6 @@ struct FsrcnnWeights {
 // plain fp16 operands with fp32 accumulation (an SS4K_F16 model: the precision the reference's TensorRT engine runs FSRCNN in)
 enum { FS_MODE_SPLIT = 0, FS_MODE_EXACT = 1, FS_MODE_HALF = 2 };
 void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const float* in, float* out, int planes, int h,
-                    int w, float* ws12a, float* ws12b, int mode, hipStream_t st);
+                    int w, float* ws12a, float* ws12b, int mode, hipStream_t st, bool out_half = false);   // out_half: fp16 mode only, HR planes as fp16
 
 }  // namespace ss4k

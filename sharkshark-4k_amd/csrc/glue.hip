@@ -138,16 +138,16 @@ template void op_area_normalized<float>(const float*, float*, int, int, int, int
 template void op_area_normalized<__half>(const __half*, float*, int, int, int, int, int, const float*, const float*, hipStream_t);
 
 // ------------------------------------------------------------------ per-plane mean / unbiased std
-__global__ void k_stats_partial(const float* __restrict__ in, double* __restrict__ acc, int hw) {
+template <typename HT = float>
+__global__ void k_stats_partial(const HT* __restrict__ in, double* __restrict__ acc, int hw) {
   const int pl = blockIdx.y;
-  const float* src = in + (size_t)pl * hw;
+  const HT* src = in + (size_t)pl * hw;
   double s = 0.0, q = 0.0;
   if ((hw & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
     // 16-byte loads, four independent fp64 chains (the sums are order-free: the partials meet in atomics anyway)
     double s4[4] = {0, 0, 0, 0}, q4[4] = {0, 0, 0, 0};
-    const float4* s16 = reinterpret_cast<const float4*>(src);
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)hw / 4; i += (size_t)gridDim.x * blockDim.x) {
-      const float4 v = s16[i];
+      const float4 v = hr_ld4<HT>(src + 4 * i);
       const double d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) { s4[k] += d[k]; q4[k] += d[k] * d[k]; }
@@ -155,7 +155,7 @@ __global__ void k_stats_partial(const float* __restrict__ in, double* __restrict
     s = (s4[0] + s4[1]) + (s4[2] + s4[3]); q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
   } else
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)hw; i += (size_t)gridDim.x * blockDim.x) {
-    const double v = src[i];
+    const double v = hr_ld(src + i);
     s += v; q += v * v;
   }
   for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); q += __shfl_down(q, off, 64); }
@@ -186,14 +186,17 @@ __global__ void k_stats_final(const double* __restrict__ acc, float* __restrict_
 void op_plane_stats_finish(const double* acc, float* stats, int planes, int hw, hipStream_t st) {
   hipLaunchKernelGGL(k_stats_final, dim3((planes + 63) / 64), dim3(64), 0, st, acc, stats, planes, hw); SS4K_LAUNCH_OK();
 }
-void op_plane_stats(double* acc, const float* in, float* stats, int planes, int hw, hipStream_t st) {
+template <typename HT>
+void op_plane_stats(double* acc, const HT* in, float* stats, int planes, int hw, hipStream_t st) {
   SS4K_REQUIRE(planes <= STATS_MAX_PLANES, "plane_stats: too many planes");
   SS4K_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 2 * planes * STATS_SLOTS, st));
   int gx = (hw + 256 * 16 - 1) / (256 * 16);
   gx = std::max(1, std::min(gx, 128));
-  hipLaunchKernelGGL(k_stats_partial, dim3(gx, planes), dim3(256), 0, st, in, acc, hw); SS4K_LAUNCH_OK();
+  hipLaunchKernelGGL(k_stats_partial<HT>, dim3(gx, planes), dim3(256), 0, st, in, acc, hw); SS4K_LAUNCH_OK();
   op_plane_stats_finish(acc, stats, planes, hw, st);
 }
+template void op_plane_stats<float>(double*, const float*, float*, int, int, hipStream_t);
+template void op_plane_stats<__half>(double*, const __half*, float*, int, int, hipStream_t);
 
 // hr = (hr - mean_hr) / (std_hr + 1e-8) * std_lr + mean_lr   (fsrcnn_upscaler.py:198-199, :312-313).
 // One expression, used by the stand-alone pass and by every consumer that applies it on the fly: the fused and

@@ -647,8 +647,9 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
     if (acts.size() < 2) acts.resize(2);
     if (plan_only) { plan_bytes.assign(2, px * 12 * 4); return; }
     acts[0].ensure(px * 12 * 4); acts[1].ensure(px * 12 * 4);
+    const bool half_out = out_half; out_half = false;
     fsrcnn_forward(ctx, fsw, desc.scale, in, out, n, h, w, acts[0].as<float>(), acts[1].as<float>(),
-                   fs_exact ? FS_MODE_EXACT : f16 ? FS_MODE_HALF : FS_MODE_SPLIT, st);
+                   fs_exact ? FS_MODE_EXACT : f16 ? FS_MODE_HALF : FS_MODE_SPLIT, st, half_out);
     return;
   }
   lanes_begin(n, h, w, st);

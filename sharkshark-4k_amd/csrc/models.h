@@ -51,10 +51,12 @@ struct Model {
   double* out_stats_acc = nullptr;
   bool out_stats_done = false;
   // one-shot request of the caller (like out_stats_acc): write the NCHW output tensor as fp16 instead of fp32.  Only honoured where
-  // can_half_out() says so (an fp16 SRVGG: its PixelShuffle tail converts anyway); the caller sized `out` accordingly
+  // can_half_out() says so (an fp16 SRVGG: its PixelShuffle tail converts anyway; an fp16-mode FSRCNN: its tail stores from registers); the caller sized `out` accordingly
   bool out_half = false;
   bool hr_f32 = false;         // SS4K_MODEL_HR_F32
-  bool can_half_out() const { return desc.kind == SS4K_SRVGG && desc.dtype == SS4K_F16 && !plan_only && !hr_f32; }
+  bool can_half_out() const {
+    return (desc.kind == SS4K_SRVGG || (desc.kind == SS4K_FSRCNN && !fs_exact)) && desc.dtype == SS4K_F16 && !plan_only && !hr_f32;
+  }
   // frame lanes: the frames of a job are independent, so an even batch can go through the conv layers as TWO concurrent
   // launch chains - lane 0 on the caller's stream, lane 1 on the context's lane stream, each working on its own half of
   // the frames of the same tensors, every launch still sized for the whole chip.  The hardware dispatcher then fills any
