@@ -90,7 +90,7 @@ enum {
   SS4K_MODEL_CHAIN = 128,       /* ... chain kernel for every fp16 job size that fits it */
   SS4K_MODEL_NO_PAIR = 256,     /* BSVD: the full-resolution layer pairs (inc, outc) as two launches each instead of the fused
                                    row-marching kernel (conv_pair.hip); bit-identical results */
-  SS4K_MODEL_HR_F32 = 512,      /* fp16 SRVGG on the batched service path: keep the network's output tensor (x4 on 720p: 2880 x 5120 x 3
+  SS4K_MODEL_HR_F32 = 512,      /* fp16 SRVGG / fp16-mode FSRCNN on the service paths: keep the network's output tensor (x4 on 720p: 2880 x 5120 x 3
                                    per frame) in fp32; default: fp16 (half the bytes of the service's four passes over it; the uint8 frames
                                    differ by at most 1 LSB in a few per cent of the bytes - an fp16 model's own error is 30 dB above that) */
   SS4K_MODEL_FLAGS_ALL = 1023
