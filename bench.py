@@ -35,6 +35,9 @@ from sharkshark4k_amd.upscale import model as factory  # noqa: E402
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16
 F32_VECTOR_PEAK_TFLOPS = 157.3
 PMC_TRAFFIC_FILE = "conv3x3_pmc_traffic_current.json"  # written by tools/collect_profiles.sh next to its per-round copy (tools/pmc_traffic.py)
+# algorithmic bytes = uint8 frame in (2 764 800) + uint8 frame out (11 059 200) per frame, + the fp16 weights
+# (33.4 MB) once per step: 88.7 MB for a 4-frame step
+ALGORITHMIC_BYTES_PER_FRAME, ALGORITHMIC_WEIGHT_BYTES = 2_764_800 + 11_059_200, 33.4e6
 HBM_SPEC_GBS, HBM_ACHIEVABLE_GBS = 8000.0, 6290.0  # MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured (float4 copy)
 CONV_KERNEL_NAME = ("3x3 implicit-GEMM conv, all launches of a step: ss4k::conv3x3_kernel<__half,NB> (LDS weights, "
                     "v_mfma_f32_32x32x16_f16) + ss4k::rs::conv3x3_rs_kernel<6,16,1,4> (register-stationary weights, "
@@ -301,11 +304,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the short secondary-workload measurements")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks as child processes even for --gpus 1 (exercises the parent / child relay; with "
+                         "SS4K_FORCE_GROUP=1 the single rank also creates its RCCL group and broadcasts the weights through it)")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.spawn) and "WORLD_SIZE" not in os.environ:
         # no launcher: this process becomes the parent of N fresh ranks and never touches a GPU itself
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(spawn_ranks(args.gpus, [a for a in sys.argv[1:] if a != "--spawn"]))
 
     rank, world_env, local = sharding.init_distributed()
     assert world_env == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch one rank per GPU"
@@ -335,7 +341,8 @@ def main():
         "dtype": "f32" if args.workload == "fsrcnn" else "f16", "data": "synthetic",
         "config": {"workload": WORKLOADS[args.workload], "frames_per_step_per_gpu": args.batch,
                    "in": [in_shape[0], in_shape[1], 3], "out": [oh, ow, 3], "io": "uint8 NHWC resident in HBM",
-                   "parallelism": f"frame-sharded x{world}, weights broadcast once (RCCL)",
+                   "parallelism": (f"frame-sharded x{world}, weights broadcast once from rank 0 (RCCL)" if torch.distributed.is_initialized()
+                                   else "one GPU, no process group (frames shard one-per-GPU at N > 1; the only collective is the weight broadcast)"),
                    "fps_per_gpu": fps / world, "net_tflops_per_gpu": flops_per_frame * fps / world / 1e12},
     }
 
@@ -360,18 +367,26 @@ def main():
                 # hits, MI355X_MICROARCH.md HBM section): bytes per step / conv time of a step
                 bytes_step = traffic * rl["launches_per_step"]
                 gbs = bytes_step / (rl["conv_ms_per_step"] * 1e-3) / 1e9
-                hbm = {"achieved": gbs, "peak": HBM_SPEC_GBS, "unit": "GB/s", "frac": gbs / HBM_SPEC_GBS,
+                hbm = {"what": "diagnostic: measured L2 <-> fabric bytes over conv time (NOT an achievement figure)",
+                       "achieved": gbs, "peak": HBM_SPEC_GBS, "unit": "GB/s", "frac": gbs / HBM_SPEC_GBS,
                        "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": gbs / HBM_ACHIEVABLE_GBS,
                        "bytes_per_step": bytes_step,
                        "flop_per_byte": rl["algorithmic_gflop_per_launch"] * 1e9 / traffic,
                        "ridge_flop_per_byte": MFMA_F16_DENSE_PEAK_TFLOPS * 1e12 / (HBM_ACHIEVABLE_GBS * 1e9),
                        "note": "measured fabric bytes (layer-by-layer dense blocks re-read x 5x, x1 4x, ... per RDB), not SURVEY 8(d)'s "
                                "algorithmic bytes; FETCH_SIZE counts Infinity-Cache hits, so the HBM share of these bytes is unknown"}
-            binding = "hbm" if hbm is not None and hbm["frac"] > mfma["frac"] else "mfma"
-            top = hbm if binding == "hbm" else mfma
-            result["roofline"] = {"bound": binding, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
-                                  "frac": top["frac"], "mfma": mfma, "hbm": hbm, "traffic": traffic,
-                                  "traffic_unit": "bytes per launch (L2<->fabric, PMC)", "traffic_source": traffic_src,
+            # this path is MFMA-bound by arithmetic intensity (8.263 TFLOP against 22 MB of algorithmic bytes per
+            # frame), so the figure of merit is the MFMA fraction at ALGORITHMIC FLOPs.  The fabric figures (measured L2 <-> fabric
+            # bytes, FLOP per measured byte against the ridge) are the diagnosis of what holds it back - they go UP when a kernel
+            # wastes more bytes - and live in the "fabric" sub-record, never in frac.
+            alg_bytes_step = ALGORITHMIC_BYTES_PER_FRAME * args.batch + ALGORITHMIC_WEIGHT_BYTES
+            if hbm is not None:
+                hbm["algorithmic_bytes_per_step"] = alg_bytes_step
+                hbm["measured_over_algorithmic"] = hbm["bytes_per_step"] / alg_bytes_step
+            result["roofline"] = {"bound": "mfma", "achieved": mfma["achieved"], "peak": mfma["peak"], "unit": mfma["unit"],
+                                  "frac": mfma["frac"], "mfma": mfma, "fabric": hbm, "traffic": traffic,
+                                  "algorithmic_bytes_per_step": alg_bytes_step,
+                                  "traffic_unit": "bytes per launch, L2 <-> fabric (Infinity Cache / HBM), PMC", "traffic_source": traffic_src,
                                   "kernel": CONV_KERNEL_NAME,
                                   "launches_per_step": rl["launches_per_step"],
                                   "avg_launch_us": rl["avg_launch_us"],
@@ -471,7 +486,7 @@ def main():
         torch.distributed.barrier()
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

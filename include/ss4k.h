@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define SS4K_ABI_VERSION 1
+#define SS4K_ABI_VERSION 2   /* 2: ss4k_model_desc.reserved[0] became the validated `flags` word (must be 0 or SS4K_MODEL_* bits);
+                                 ss4k_prof_read_kind and ss4k_model_check were added */
 
 enum { SS4K_OK = 0, SS4K_EINVAL = -22, SS4K_ENOMEM = -12, SS4K_EHIP = -5, SS4K_ENODEV = -19 };
 
@@ -77,7 +78,7 @@ typedef struct ss4k_model_desc {
 enum {
   SS4K_MODEL_FS_EXACT = 1,      /* FSRCNN: exact-fp32 kernels for every stage instead of the fp16 hi/lo-split matrix-core
                                    stages (fp32-grade, ~1e-6 of the exact ones); also chosen automatically when the
-                                   checkpoint's range does not fit the split (see csrc/models.cpp fsrcnn_split_is_safe) */
+                                   checkpoint's range does not fit the split (a weight >= 6e4: Model::build, csrc/models.cpp) */
   SS4K_MODEL_ONE_CHAIN = 2,     /* an even job never runs as two concurrent launch chains (frame lanes) */
   SS4K_MODEL_TWO_CHAINS = 4,    /* ... always does (default: measured per shape over the first calls) */
   SS4K_MODEL_NO_RS = 8,         /* every conv layer on the LDS-weights kernel (conv_mfma.hip); default: conv5 of an RDB on the
@@ -85,9 +86,10 @@ enum {
                                    layer (one fp16 rounding per layer either way) */
   SS4K_MODEL_TILE_ROWS_16 = 16, /* 32-cout body layers on 16-row tiles ... */
   SS4K_MODEL_TILE_ROWS_20 = 32, /* ... or on 20-row tiles (default: by image height); bit-identical results */
-  SS4K_MODEL_NO_CHAIN = 64,     /* RRDBNet body of 1- and 2-frame jobs as one launch per layer instead of the cross-layer
-                                   chain kernel (csrc/conv_chain.hip); bit-identical results */
-  SS4K_MODEL_CHAIN = 128,       /* ... chain kernel for every fp16 job size that fits it */
+  SS4K_MODEL_NO_CHAIN = 64,     /* RRDBNet body as one launch per layer: this IS the default, the bit only states it */
+  SS4K_MODEL_CHAIN = 128,       /* opt-in: the RRDB body of every fp16 job as ONE persistent launch with per-tile hand-offs
+                                   (csrc/conv_chain.hip); bit-identical results.  The latency mode of a service that is the
+                                   GPU's only caller; its asynchronous failure mode is reported by ss4k_model_check */
   SS4K_MODEL_NO_PAIR = 256,     /* BSVD: the full-resolution layer pairs (inc, outc) as two launches each instead of the fused
                                    row-marching kernel (conv_pair.hip); bit-identical results */
   SS4K_MODEL_HR_F32 = 512,      /* fp16 SRVGG / fp16-mode FSRCNN on the service paths: keep the network's output tensor (x4 on 720p: 2880 x 5120 x 3
@@ -130,6 +132,14 @@ int ss4k_model_workspace_bytes(ss4k_model* m, int n, int h, int w, size_t* bytes
  * BSVD: in (n,4,h,w) = the reference's (n,1,4,h,w); out (n,3,h,w).  FSRCNN: (planes,1,h,w). */
 int ss4k_model_forward(ss4k_model* m, const float* in_nchw_dev, float* out_nchw_dev, int n, int h,
                        int w, void* hip_stream);
+
+/* Asynchronous status of the model's earlier forwards.  Only the cross-layer chain kernel (SS4K_MODEL_CHAIN) has one: a work
+ * unit that waited for its neighbours past a bound gives up (the launch always drains) and marks a sticky word that no later
+ * launch resets.  Returns SS4K_OK, or SS4K_EHIP once per failure (the outputs since the last successful check are void).
+ * wait != 0: first block until the model's last chain launch has finished, so the answer covers the forward just enqueued -
+ * call it where the result is consumed.  wait == 0 never blocks; the next ss4k_model_forward performs the same check.
+ * Models without a chain launch return SS4K_OK at once. */
+int ss4k_model_check(ss4k_model* m, int wait);
 
 /* ---- the service's frame-in/frame-out hot path ------------------------------------------- */
 typedef struct ss4k_upscale_cfg {

@@ -23,7 +23,7 @@ F32, F16 = 0, 1
 SYMBOLS = [
     "ss4k_abi_version", "ss4k_last_error", "ss4k_ctx_create", "ss4k_ctx_destroy", "ss4k_ctx_device",
     "ss4k_model_param_count", "ss4k_model_create", "ss4k_model_destroy", "ss4k_model_out_shape",
-    "ss4k_model_in_channels", "ss4k_model_forward", "ss4k_upscaler_create", "ss4k_upscaler_destroy",
+    "ss4k_model_in_channels", "ss4k_model_forward", "ss4k_model_check", "ss4k_upscaler_create", "ss4k_upscaler_destroy",
     "ss4k_upscaler_reset", "ss4k_upscaler_out_shape", "ss4k_upscaler_last_enqueue_ms", "ss4k_model_workspace_bytes", "ss4k_upscale_frames", "ss4k_upscaler_enable_taps",
     "ss4k_upscaler_read_tap", "ss4k_op_u8nhwc_to_f32nchw", "ss4k_op_area_resize", "ss4k_op_bicubic_resize",
     "ss4k_op_bilinear_resize", "ss4k_op_depthwise_reflect", "ss4k_op_plane_stats", "ss4k_op_f32nchw_to_u8nhwc",
@@ -82,6 +82,7 @@ def load(path: str) -> C.CDLL:
     L.ss4k_model_out_shape.argtypes = [vp, i, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.ss4k_model_in_channels.argtypes = [vp]
     L.ss4k_model_forward.argtypes = [vp, vp, vp, i, i, i, vp]
+    L.ss4k_model_check.argtypes = [vp, i]
     L.ss4k_upscaler_create.argtypes = [vp, C.POINTER(UpscaleCfg), vp, vp, C.POINTER(vp)]
     L.ss4k_upscaler_destroy.argtypes = [vp]; L.ss4k_upscaler_destroy.restype = None
     L.ss4k_upscaler_reset.argtypes = [vp]
@@ -264,6 +265,10 @@ class Model:
             self.close()
         except Exception:
             pass
+
+    def check(self, wait: bool = True) -> None:
+        """Raise if an earlier forward of this model failed asynchronously (ss4k_model_check; only the chain kernel can)."""
+        _check(lib().ss4k_model_check(self._h, 1 if wait else 0))
 
     def workspace_bytes(self, n, h, w) -> int:
         b = C.c_size_t()

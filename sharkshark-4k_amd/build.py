@@ -14,7 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libss4k_hip.so")
 LIB_DEV = os.path.join(HERE, "libss4k_hip_dev.so")
-SOURCES = ["conv_mfma.hip", "conv_rs.hip", "conv_chain.hip", "conv_s3.hip", "conv_pair.hip", "glue.hip", "fsrcnn.hip", "pack.cpp", "models.cpp", "api.cpp"]
+SOURCES = ["conv_mfma.hip", "conv_rs.hip", "conv_chain.hip", "conv_pair.hip", "glue.hip", "fsrcnn.hip", "pack.cpp", "models.cpp", "api.cpp"]
+DEV_SOURCES = ["conv_s3.hip"]   # measurement-only experiments: libss4k_hip_dev.so alone
 # conv_rs.hip: the per-tile body is thousands of fully unrolled MFMAs (weights live in named registers); hipcc's
 # default cap on '#pragma unroll' size would leave the chunk loop rolled and the weights in scratch
 EXTRA_FLAGS = {"conv_rs.hip": ["-mllvm", "-pragma-unroll-threshold=4000000"]}
@@ -45,7 +46,8 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
     flags = FLAGS + (["-DSS4K_DEV"] if dev else [])
     os.makedirs(objdir, exist_ok=True)
     jobs = []
-    for s in SOURCES:
+    sources = SOURCES + (DEV_SOURCES if dev else [])
+    for s in sources:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
         if force or _needs_build(obj, src):
@@ -64,7 +66,7 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    objs = [os.path.join(objdir, os.path.splitext(s)[0] + ".o") for s in SOURCES]
+    objs = [os.path.join(objdir, os.path.splitext(s)[0] + ".o") for s in sources]
     if jobs or not os.path.exists(lib):
         cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", lib]
         if verbose:

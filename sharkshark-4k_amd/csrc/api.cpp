@@ -343,6 +343,13 @@ int ss4k_model_forward(ss4k_model* m, const float* in, float* out, int n, int h,
   });
 }
 
+int ss4k_model_check(ss4k_model* m, int wait) {
+  return guard([&] {
+    SS4K_REQUIRE(m, "ss4k_model_check: NULL argument");
+    m->m.check_async_error(wait != 0);
+  });
+}
+
 int ss4k_upscaler_create(ss4k_ctx* ctx, const ss4k_upscale_cfg* cfg, ss4k_model* sr, ss4k_model* dn, ss4k_upscaler** out) {
   return guard([&] {
     SS4K_REQUIRE(ctx && cfg && sr && out, "ss4k_upscaler_create: NULL argument");

@@ -184,10 +184,13 @@ struct ChainItem {
 struct ChainArgs {
   const ChainItem* items; int nitems;
   unsigned* ctl;                        // [0] queue head, [1] error word, [4 ...] per-tile counters of finished units; zeroed per launch
+  unsigned* err_sticky;                 // device pointer of the model's sticky error word (pinned, host-mapped): OR-ed into when a unit
+                                        // times out, never reset by a launch
   const char* zero_page;
   int N, n0, H, W, tiles_x, tiles_y;
   int grid;                             // > 0: workgroups to launch (default: one per workgroup slot)
   int abl;                              // dev library: timing-only ablation build (conv_chain.hip)
+  unsigned spin_limit;                  // dev library: polls before a unit gives up (0 = SPIN_LIMIT); fault injection for the error path
 };
 // every unit of the chain: fp16, plain epilogue, cout group of 32.  rows_per_wave 4 or 5 (16- / 20-row tiles).
 void launch_conv_chain(ss4k_ctx* ctx, const ChainArgs& a, int rows_per_wave, hipStream_t st);

@@ -124,7 +124,18 @@ __global__ __launch_bounds__(64 * NW, chain_wgs_per_cu<MB>()) void conv3x3_chain
   const unsigned nwork = (unsigned)ca.nitems * (unsigned)ntiles;
   gu32* head = (gu32*)ca.ctl;
   gu32* errw = head + 1;
+  // a unit that gives up marks the launch (errw: per launch, makes every other wait end so the grid drains) AND the model's sticky
+  // word in pinned host memory, which no launch ever resets - only the host code that reports the error clears it
+  auto raise_err = [&]() {
+    __hip_atomic_fetch_or(errw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ca.err_sticky) __hip_atomic_fetch_or((gu32*)ca.err_sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  };
   gu32* flags = head + 4;
+#ifdef SS4K_DEV
+  const unsigned spin_limit = ca.spin_limit ? ca.spin_limit : SPIN_LIMIT;
+#else
+  constexpr unsigned spin_limit = SPIN_LIMIT;
+#endif
 
   auto swz = [](int x) { return (x >> 3) & 1; };
   int rd_base[3];
@@ -176,8 +187,8 @@ __global__ __launch_bounds__(64 * NW, chain_wgs_per_cu<MB>()) void conv3x3_chain
       // give up after SPIN_LIMIT polls - or as soon as any unit has (the error word is sticky: once a unit timed out the results
       // of this forward are void and every wait ends, so the launch drains in milliseconds); the host sees the error word
       const bool dead = (spins & 1023u) == 0 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-      if (spins > SPIN_LIMIT || dead) {
-        if (lane == 0) __hip_atomic_fetch_or(errw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (spins > spin_limit || dead) {
+        if (lane == 0) raise_err();
         break;
       }
     }
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(64 * NW, chain_wgs_per_cu<MB>()) void conv3x3_chain
         unsigned spins = 0;
         while ((int)(__hip_atomic_load(flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - pub_need) < 0) {
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > SPIN_LIMIT) { __hip_atomic_fetch_or(errw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          if (++spins > spin_limit) { raise_err(); break; }
         }
       }
       __hip_atomic_fetch_add(flags + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

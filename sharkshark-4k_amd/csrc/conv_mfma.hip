@@ -718,8 +718,12 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
   ConvArgs a = a0;
   a.tiles_x = (a.W + TW - 1) / TW;
   a.zero_page = ctx->zero_page();
+#ifdef SS4K_DEV
   const bool split64 = a.cout_pad == -64;   // dev experiment (models.cpp SS4K_SPLIT64): 64 couts as two 32-cout groups
   if (split64) a.cout_pad = 64;
+#else
+  constexpr bool split64 = false;
+#endif
   const int nb = (a.cout_pad <= 32 || split64) ? 1 : 2;
   const int groups = (a.cout_pad + nb * 32 - 1) / (nb * 32);
   SS4K_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0, "conv3x3: empty grid");

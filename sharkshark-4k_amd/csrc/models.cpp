@@ -438,12 +438,15 @@ void Model::chain_run(int N, int H, int W, hipStream_t st) {
   chain_rec = false;
   if (chain_items.empty()) return;
   if (!chain_err_host) {
-    SS4K_HIP(hipHostMalloc(reinterpret_cast<void**>(&chain_err_host), 64, hipHostMallocDefault));
-    *chain_err_host = 0;
+    // the sticky error word: pinned host memory mapped into the device's address space.  A unit that times out ORs into it
+    // (system scope); no launch resets it and no copy is involved, so an error can neither be lost nor raced - only
+    // check_async_error(), which reports it, clears it
+    SS4K_HIP(hipHostMalloc(reinterpret_cast<void**>(&chain_err_host), 64, hipHostMallocMapped | hipHostMallocCoherent));
+    __atomic_store_n(chain_err_host, 0u, __ATOMIC_RELAXED);
+    SS4K_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&chain_err_dev), chain_err_host, 0));
+    SS4K_HIP(hipEventCreateWithFlags(&chain_done, hipEventDisableTiming));
   }
-  // a unit of an earlier chain launch gave up waiting (a co-running kernel starved it for seconds, or a defect): its results
-  // were void.  The copy of the error word is asynchronous, so this reports the failure on the next call.
-  if (*chain_err_host) { *chain_err_host = 0; throw Error(SS4K_EHIP, "conv chain: a work unit timed out waiting for its neighbours (previous forward's output is invalid)"); }
+  check_async_error(false);   // an EARLIER forward's chain gave up: reported here at the latest (ss4k_model_check reports it at once)
   const size_t bytes = chain_items.size() * sizeof(ChainItem);
   if (chain_uploaded.size() != chain_items.size() || std::memcmp(chain_uploaded.data(), chain_items.data(), bytes) != 0) {
     // a new job shape (or re-allocated activations): rare, so the upload is allowed to wait - for the previous chain launch, which
@@ -465,7 +468,9 @@ void Model::chain_run(int N, int H, int W, hipStream_t st) {
   chain_ctl.ensure(conv_chain_ctl_bytes(ntiles));
   ca.ctl = chain_ctl.as<unsigned>();
   ca.zero_page = ctx->zero_page();
+  ca.err_sticky = chain_err_dev;
 #ifdef SS4K_DEV
+  if (const char* e = std::getenv("SS4K_CHAIN_SPIN_LIMIT")) ca.spin_limit = (unsigned)std::atoi(e);   // fault injection: units give up early
   if (const char* e = std::getenv("SS4K_CHAIN_GRID")) ca.grid = std::atoi(e);
   if (const char* e = std::getenv("SS4K_CHAIN_ABL")) ca.abl = std::atoi(e);
 #endif
@@ -474,7 +479,8 @@ void Model::chain_run(int N, int H, int W, hipStream_t st) {
   const ProfEvent pe = ctx->prof_begin(st, PROF_CONV);
   launch_conv_chain(ctx, ca, mb, st);
   ctx->prof_end(pe, st, flops);
-  SS4K_HIP(hipMemcpyAsync(chain_err_host, ca.ctl + 1, 4, hipMemcpyDeviceToHost, st));
+  SS4K_HIP(hipEventRecord(chain_done, st));   // ss4k_model_check(wait) waits for THIS launch before it reads the sticky word
+  chain_pending = true;
 #ifdef SS4K_DEV
   if (ca.abl == 8) {   // statistics build: how often units started blocked, how long they polled
     SS4K_HIP(hipStreamSynchronize(st));
@@ -484,6 +490,16 @@ void Model::chain_run(int N, int H, int W, hipStream_t st) {
             ca.grid, ca.nitems, ntiles, (unsigned)ca.nitems * ntiles, h[2], h[3] / 100.0, h[4 + ntiles] / 100.0);
   }
 #endif
+}
+
+// Asynchronous failures of the chain kernel (a unit gave up waiting: a co-running kernel starved it for seconds, or a defect).
+// wait: block until the last chain launch has finished, so that THIS forward's status is known before its output is used.
+void Model::check_async_error(bool wait) {
+  if (!chain_err_host) return;
+  if (wait && chain_pending) { SS4K_HIP(hipEventSynchronize(chain_done)); chain_pending = false; }
+  if (__atomic_exchange_n(chain_err_host, 0u, __ATOMIC_ACQ_REL) != 0)
+    throw Error(SS4K_EHIP, "conv chain: a work unit timed out waiting for its neighbours; the output of the forward(s) since the "
+                           "last successful ss4k_model_check is invalid");
 }
 
 // Called at the top of a conv network's forward: one launch chain or two?  Both give bit-identical tensors.
@@ -653,7 +669,9 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
     return;
   }
   lanes_begin(n, h, w, st);
-  conv_calls = (forward_calls++ & 1) ? -(1 << 30) : 0;   // fault injection (dev library): every other forward fails
+#ifdef SS4K_DEV
+  conv_calls = (forward_calls++ & 1) ? -(1 << 30) : 0;   // fault injection (SS4K_FAIL_AT_CONV): every other forward fails
+#endif
   // plane index of channel c inside a tensor
   auto plane_of = [&](const Tens& t, int channel) { return Tens{t.p, t.plane_bytes, t.plane0 + channel / cw()}; };
   auto nchw_out = [&]() { return Tens{reinterpret_cast<char*>(out), 0, 0}; };
@@ -769,6 +787,9 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
       const Tens rest{t.p, t.plane_bytes, t.plane0 + lead};
       conv(li++, S, planes_for(c) > lead ? &rest : nullptr, N, H, W, relu6(outT), st);
     };
+    // (workspace planning counts the tensors inside the inc / outc pairs whichever route runs: a pair that falls back to two
+    // launches at run time - a measurement selector set after the query - must never find the workspace under-reported)
+    if (plan_only) { (void)act(2, px, desc.bsvd_interm_ch); (void)act(13, px, c0); }
     if (conv_pair(li, IN, n, h, w, relu6(X0), st)) li += 2;                            // inc.convblock.0 + .3 fused (conv_pair.hip)
     else {
       Tens I0 = act(2, px, desc.bsvd_interm_ch);

@@ -90,7 +90,10 @@ struct Model {
   std::vector<ChainLayerRec> chain_layers;
   std::vector<ChainItem> chain_uploaded;
   DevBuf chain_tab, chain_ctl;
-  unsigned* chain_err_host = nullptr;   // pinned copy of the chain's error word, refreshed after every chain launch
+  unsigned* chain_err_host = nullptr;   // sticky error word of the chain kernel: pinned host memory the device ORs into (never reset by a launch)
+  unsigned* chain_err_dev = nullptr;    // ... its device address
+  hipEvent_t chain_done = nullptr; bool chain_pending = false;   // end of the last chain launch (ss4k_model_check(wait))
+  void check_async_error(bool wait);    // throws if a chain launch reported a timed-out unit since the last check; clears the word
   void chain_record(const ConvArgs& a, const ConvLayer& L);
   void chain_run(int N, int H, int W, hipStream_t st);
   int fail_at_conv = 0, conv_calls = 0, forward_calls = 0;   // dev library only: fault injection (SS4K_FAIL_AT_CONV)
@@ -113,6 +116,7 @@ struct Model {
     for (auto& l : layers) { l.w.release(); l.bias.release(); l.prelu.release(); l.wrs.release(); l.wch.release(); }
     chain_tab.release(); chain_ctl.release();
     if (chain_err_host) (void)hipHostFree(chain_err_host);
+    if (chain_done) (void)hipEventDestroy(chain_done);
     for (auto& a : acts) a.release();
     fs_blob.release();
     for (auto* tab : {&lane_tune}) for (auto& t : *tab) for (auto& pr : t.second.ev) for (auto e : pr) if (e) (void)hipEventDestroy(e);

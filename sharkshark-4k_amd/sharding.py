@@ -16,12 +16,16 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """(rank, world, local_rank) from the torchrun environment; initialises the process group."""
+def init_distributed(backend: Optional[str] = None, force_group: bool = False) -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from the torchrun environment; initialises the process group.
+
+    A world of one needs no group (nothing is exchanged); ``force_group`` (or ``SS4K_FORCE_GROUP=1``) creates it anyway, so
+    that library load, communicator init and the broadcast kernel of RCCL can be exercised on a one-GPU box."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    force_group = force_group or os.environ.get("SS4K_FORCE_GROUP", "0") == "1"
+    if (world > 1 or force_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend is None:
@@ -40,9 +44,16 @@ def my_steps(steps: Iterable[int], rank: int, world: int) -> List[int]:
     return [s for s in steps if owner_of(s, world) == rank]
 
 
-def broadcast_weights(flat: Optional[np.ndarray], n_floats: int, device: torch.device, src: int = 0) -> np.ndarray:
-    """Rank ``src`` passes the flat fp32 state_dict blob, the others ``None``; all get a copy."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+def broadcast_weights(flat: Optional[np.ndarray], n_floats: int, device: torch.device, src: int = 0,
+                      force_collective: bool = False) -> np.ndarray:
+    """Rank ``src`` passes the flat fp32 state_dict blob, the others ``None``; all get a copy.
+
+    With one rank the blob is returned as it is - unless ``force_collective`` (or ``SS4K_FORCE_GROUP=1``) asks for the
+    broadcast to run anyway (needs an initialised group): the blob then takes the same device round trip through
+    ``dist.broadcast`` that it takes at N > 1."""
+    force_collective = force_collective or os.environ.get("SS4K_FORCE_GROUP", "0") == "1"
+    have_group = dist.is_available() and dist.is_initialized()
+    if not have_group or (dist.get_world_size() == 1 and not force_collective):
         assert flat is not None
         return np.ascontiguousarray(flat, dtype=np.float32)
     t = torch.empty(n_floats, dtype=torch.float32, device=device)

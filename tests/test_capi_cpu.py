@@ -34,7 +34,7 @@ def test_header_symbols_exported(lib):
     assert sorted(_capi.SYMBOLS) == syms, "python binding list and header disagree"
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/ss4k.h but not exported"
-    assert lib.ss4k_abi_version() == 1
+    assert lib.ss4k_abi_version() == 2
 
 
 def test_dev_library_is_a_superset_and_product_has_no_bench_hooks(lib):

@@ -112,3 +112,38 @@ def test_service_model_flags_route_to_the_chain(ctx):
         outs.append(svc.upscale(frames).cpu().to(torch.int16))
     assert outs[0].shape == (1, 144, 208, 3)
     assert int((outs[0] - outs[1]).abs().max()) <= 1
+
+
+def test_chain_timeout_is_reported_once_and_never_lost(ctx, monkeypatch):
+    """The chain's asynchronous failure mode (a unit gives up waiting) through the C ABI: injected in the dev library by letting
+    units give up after ONE poll (SS4K_CHAIN_SPIN_LIMIT=1).  The sticky word lives in pinned host memory, no launch resets it:
+    ss4k_model_check(wait=1) reports the failed forward before its output is used, a second check is clean, a failure that
+    nobody checked for is reported by the next forward, and a healthy forward afterwards is bit-identical to a healthy model."""
+    import ctypes as C
+    from sharkshark4k_amd import build as B
+    L = _capi.load(B.LIB_DEV)
+    t = W.rrdbnet_table(5, scale=2, num_block=2)
+    flat = np.ascontiguousarray(W.flatten(t, W.rrdbnet_keys(2)), dtype=np.float32)
+    desc = _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=2, flags=CHAIN)
+    x = torch.rand(1, 3, 288, 416, generator=torch.Generator().manual_seed(3)).cuda()
+    want = _capi.Model(ctx, desc, flat)(x).clone()
+    hctx, hm = C.c_void_p(), C.c_void_p()
+    assert L.ss4k_ctx_create(0, C.byref(hctx)) == 0
+    assert L.ss4k_model_create(hctx, C.byref(desc), flat.ctypes.data_as(C.c_void_p), flat.size, C.byref(hm)) == 0, L.ss4k_last_error()
+    out = torch.empty_like(want)
+    st = int(torch.cuda.current_stream().cuda_stream)
+    fwd = lambda: L.ss4k_model_forward(hm, x.data_ptr(), out.data_ptr(), 1, 288, 416, st)
+    assert L.ss4k_model_check(hm, 1) == 0                      # nothing launched yet
+    assert fwd() == 0 and L.ss4k_model_check(hm, 1) == 0       # healthy
+    torch.cuda.synchronize(); assert torch.equal(out, want)
+    monkeypatch.setenv("SS4K_CHAIN_SPIN_LIMIT", "1")           # read per chain launch (dev library)
+    assert fwd() == 0                                          # the failure is asynchronous: enqueueing succeeds
+    assert L.ss4k_model_check(hm, 1) != 0 and b"timed out" in L.ss4k_last_error()
+    assert L.ss4k_model_check(hm, 1) == 0                      # reported once, then cleared by the code that reported it
+    assert fwd() == 0                                          # a second failed forward that nobody checks ...
+    torch.cuda.synchronize()
+    monkeypatch.delenv("SS4K_CHAIN_SPIN_LIMIT")
+    assert fwd() != 0 and b"timed out" in L.ss4k_last_error()  # ... is reported by the next forward, not lost
+    assert fwd() == 0 and L.ss4k_model_check(hm, 1) == 0
+    torch.cuda.synchronize(); assert torch.equal(out, want)
+    L.ss4k_model_destroy(hm)

@@ -114,9 +114,10 @@ def test_config2_rrdbnet_x2_720p_fp16_service_vs_oracle(ctx):
     p = psnr(got.float(), want.float(), peak=255.0)
     print(f"configs[2] fp16 vs oracle: PSNR {p:.2f} dB, max |delta| {int(d.max())} LSB, {float((d > 0).float().mean()):.4%} bytes differ")
     record_measured("config2_rrdbnet_x2_720p_fp16_service", psnr_db=p, max_lsb=int(d.max()), bytes_differ=float((d > 0).float().mean()),
-                    asserted="PSNR >= 50 dB, max <= 4 LSB")
-    assert p >= 50.0, f"PSNR {p:.2f} dB"
-    assert int(d.max()) <= 4, f"max |delta| {int(d.max())} LSB"
+                    asserted="PSNR >= 55.5 dB, max <= 2 LSB")
+    # measured 57.5 dB / 1 LSB (profiles/r0N_parity_measured.json): asserted at measured - 2 dB / + 1 LSB like configs[3] / [4]
+    assert p >= 55.5, f"PSNR {p:.2f} dB"
+    assert int(d.max()) <= 2, f"max |delta| {int(d.max())} LSB"
     # a 4-frame job gives every frame the same result as a 1-frame job (frames are independent)
     four = torch.cat([frames, torch.from_numpy(smooth_u8(124, (3, 720, 1280, 3)))]).cuda()
     assert torch.equal(up(four)[0].cpu(), got[0])

@@ -598,7 +598,8 @@ def test_fsrcnn_f16_mode_vs_oracle(ctx, factor, tag, shape):
     err = float((got - want).abs().max())
     record_measured(f"fsrcnn_f16_x{factor}_{tag}_{shape[2]}x{shape[3]}", psnr_db=p, max_abs_err=err, peak=peak)
     print(f"fsrcnn f16 x{factor} {tag} {shape}: PSNR {p:.1f} dB, max |d| {err:.3g} of peak {peak:.3g}")
-    assert p > 55.0 and err < 1e-2 * max(1.0, peak)
+    # measured 69.1-85.8 dB over the six cases (profiles/r0N_parity_measured.json): asserted at the worst case - 2 dB
+    assert p > 67.0 and err < 1e-2 * max(1.0, peak)
 
 
 # ------------------------------------------------------------------------------ fp16 HR tensor on the batched service path
@@ -620,7 +621,7 @@ def test_srvgg_f16_half_hr_tensor_vs_fp32_hr_tensor(ctx, out_shape, lr_shape, n)
     frac = float((d != 0).float().mean())
     record_measured(f"srvgg_half_hr_{lr_shape[0]}x{lr_shape[1]}_n{n}", max_lsb=int(d.max()), frac_differing=frac)
     print(f"fp16 vs fp32 HR tensor {lr_shape} -> {out_shape}: max {int(d.max())} LSB, {100 * frac:.2f} % of bytes differ")
-    assert int(d.max()) <= 1 and frac < 0.08
+    assert int(d.max()) <= 1 and frac < 0.04   # measured 2.2-2.6 % of the bytes
 
 
 def test_hip_service_fsrcnn_f16_in_process(ctx):
@@ -638,4 +639,4 @@ def test_hip_service_fsrcnn_f16_in_process(ctx):
     d = (got.to(torch.int16) - want.to(torch.int16)).abs()
     frac = float((d != 0).float().mean())
     record_measured("svc_fsrcnn_f16_90x124", max_lsb=int(d.max()), frac_differing=frac)
-    assert got.shape == want.shape and int(d.max()) <= 1 and frac < 0.08, (int(d.max()), frac)
+    assert got.shape == want.shape and int(d.max()) <= 1 and frac < 0.06, (int(d.max()), frac)   # measured 3.8-4.4 %

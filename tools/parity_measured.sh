@@ -1,11 +1,17 @@
 #!/bin/bash
-# Run ON THE GPU BOX: the headline-path tests that compare the fp16 production path with the oracle record what they measured
-# (PSNR, max LSB) in gpurun_out/parity_measured.json (tests/helpers.py record_measured); copy it to profiles/<tag>_parity_measured.json.
-# usage: bash tools/parity_measured.sh r03
+# Run ON THE GPU BOX: every GPU parity test that compares a production path with the oracle (or one mode with another) records
+# what it measured (PSNR, max LSB, share of differing bytes) in gpurun_out/parity_measured.json (tests/helpers.py
+# record_measured).  This script runs the WHOLE gpu marker set from an empty accumulator, so the tracked copy always holds
+# every entry (a later single-test run appends to / refreshes gpurun_out/parity_measured.json but never the tagged copy).
+# usage: bash tools/parity_measured.sh r04   ->  gpurun_out/r04_parity_measured.json  (copy it to profiles/)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd "$GRAFT_REPO_ROOT"
 rm -f gpurun_out/parity_measured.json
-python3 -m pytest tests/test_gpu_headline.py -q -m gpu -k "vs_oracle or literal_tolerance" 2>&1 | tail -5
+python3 -m pytest tests -q -m gpu -x 2>&1 | tail -5
 cp gpurun_out/parity_measured.json gpurun_out/${TAG}_parity_measured.json
-cat gpurun_out/${TAG}_parity_measured.json
+python3 - <<PY
+import json
+d = json.load(open("gpurun_out/${TAG}_parity_measured.json"))
+print(len(d), "entries:", ", ".join(sorted(d)))
+PY
