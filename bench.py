@@ -322,7 +322,8 @@ def main():
     device = torch.device("cuda", local)
     ctx = _capi.Context(local)
     in_shape = (1080, 1920) if args.workload == "rrdbnet_x4" else (720, 1280)
-    up, keep, flops_per_frame = build_upscaler(ctx, args.workload, device, lr_shape=in_shape)
+    # SS4K_BENCH_MODEL_FLAGS: SS4K_MODEL_* bits for the headline network (A/B of bit-identical routes under the profiler)
+    up, keep, flops_per_frame = build_upscaler(ctx, args.workload, device, lr_shape=in_shape, flags=int(os.environ.get("SS4K_BENCH_MODEL_FLAGS", "0")))
 
     # every rank gets its own shard of the synthetic stream: frames rank, rank+world, ...
     frames = synthetic_frames(args.batch, in_shape, seed=1000 + rank).to(device)

@@ -95,7 +95,11 @@ enum {
   SS4K_MODEL_HR_F32 = 512,      /* fp16 SRVGG / fp16-mode FSRCNN on the service paths: keep the network's output tensor (x4 on 720p: 2880 x 5120 x 3
                                    per frame) in fp32; default: fp16 (half the bytes of the service's four passes over it; the uint8 frames
                                    differ by at most 1 LSB in a few per cent of the bytes - an fp16 model's own error is 30 dB above that) */
-  SS4K_MODEL_FLAGS_ALL = 1023
+  SS4K_MODEL_NO_DENSE = 1024,   /* RRDBNet: conv1..conv4 of every dense block always as four launches, never as two fused layer pairs
+                                   (csrc/conv_dense.hip: (conv1, conv2) and (conv3, conv4) stream their shared input planes once and
+                                   hand x1 / x3 over in LDS); bit-identical results.  Default: fused where it is measured faster */
+  SS4K_MODEL_DENSE = 2048,      /* ... fused pairs for every job size */
+  SS4K_MODEL_FLAGS_ALL = 4095
 };
 
 int ss4k_abi_version(void);

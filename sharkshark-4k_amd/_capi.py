@@ -41,7 +41,7 @@ class ModelDesc(C.Structure):
 
 # ss4k_model_desc.flags (include/ss4k.h)
 MODEL_FS_EXACT, MODEL_ONE_CHAIN, MODEL_TWO_CHAINS, MODEL_NO_RS, MODEL_TILE_ROWS_16, MODEL_TILE_ROWS_20 = 1, 2, 4, 8, 16, 32
-MODEL_NO_CHAIN, MODEL_CHAIN, MODEL_NO_PAIR, MODEL_HR_F32 = 64, 128, 256, 512
+MODEL_NO_CHAIN, MODEL_CHAIN, MODEL_NO_PAIR, MODEL_HR_F32, MODEL_NO_DENSE, MODEL_DENSE = 64, 128, 256, 512, 1024, 2048
 
 
 class UpscaleCfg(C.Structure):
@@ -82,7 +82,8 @@ def load(path: str) -> C.CDLL:
     L.ss4k_model_out_shape.argtypes = [vp, i, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.ss4k_model_in_channels.argtypes = [vp]
     L.ss4k_model_forward.argtypes = [vp, vp, vp, i, i, i, vp]
-    L.ss4k_model_check.argtypes = [vp, i]
+    if hasattr(L, "ss4k_model_check"):   # (absent from ABI-1 builds, which tools/lib_ab.py loads for A/B timing)
+        L.ss4k_model_check.argtypes = [vp, i]
     L.ss4k_upscaler_create.argtypes = [vp, C.POINTER(UpscaleCfg), vp, vp, C.POINTER(vp)]
     L.ss4k_upscaler_destroy.argtypes = [vp]; L.ss4k_upscaler_destroy.restype = None
     L.ss4k_upscaler_reset.argtypes = [vp]
@@ -103,7 +104,8 @@ def load(path: str) -> C.CDLL:
     L.ss4k_prof_enable.argtypes = [vp, i]
     L.ss4k_prof_reset.argtypes = [vp]
     L.ss4k_prof_read.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
-    L.ss4k_prof_read_kind.argtypes = [vp, i, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    if hasattr(L, "ss4k_prof_read_kind"):
+        L.ss4k_prof_read_kind.argtypes = [vp, i, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ss4k_prof_read_section_ms.argtypes = [vp, C.POINTER(C.c_double)]
     return L
 

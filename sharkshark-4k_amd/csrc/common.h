@@ -217,6 +217,26 @@ struct PairArgs {
 bool conv3x3_pair_eligible(int planes_a, int cout_pad_a, int nchunks_b, int cout_pad_b);
 void launch_conv3x3_pair(ss4k_ctx* ctx, const PairArgs& a, hipStream_t st);
 
+// conv_dense.hip: conv_k and conv_{k+1} of a dense block (32 couts each, LeakyReLU, fp16) as one launch; conv_{k+1} reads conv_k's
+// input planes (segments 0 / 1, nchunks0 + nchunks1 K-chunks) plus conv_k's output, which it takes from LDS
+struct DenseArgs {
+  const char* in0; size_t in0_plane_bytes; int in0_plane0, nchunks0;
+  const char* in1; size_t in1_plane_bytes; int in1_plane0, nchunks1;
+  const char* w1; const float* bias1;                   // conv_k: packed fragments (pack.cpp, nb = 1), 32 biases
+  const char* w2; const float* bias2;                   // conv_{k+1}: nchunks0 + nchunks1 + 2 K-chunks
+  float slope;                                          // LeakyReLU of both layers
+  char* out1; size_t out1_plane_bytes; int out1_plane0; // x_k (two planes)
+  char* out2; size_t out2_plane_bytes; int out2_plane0; // x_{k+1}
+  const char* zero_page;
+  int n0, N, H, W, tiles_x, tiles_y;
+  float grid_share;
+  int reverse;
+  double flops;
+  unsigned long long* dbg_buf;                          // dev library, SS4K_DENSE_STAMP=1: per-wave phase cycle counters
+};
+bool conv3x3_dense2_eligible(int nchunks_a, int cout_pad_a, int nchunks_b, int cout_pad_b);
+void launch_conv3x3_dense2(ss4k_ctx* ctx, const DenseArgs& a, hipStream_t st);
+
 int conv_cw(int dtype);  // channels per plane / K-chunk: 16
 // three-stage-ring build of the 32-cout tile body (conv_s3.hip)
 bool conv3x3_s3_eligible(const ConvArgs& a, int dtype);

@@ -193,6 +193,9 @@ void Model::build(const float* w, size_t n) {
   if (fl & SS4K_MODEL_NO_CHAIN) chain_mode = 1;
   if (fl & SS4K_MODEL_CHAIN) chain_mode = 2;
   if (fl & SS4K_MODEL_NO_PAIR) use_pair = false;
+  SS4K_REQUIRE(!((fl & SS4K_MODEL_NO_DENSE) && (fl & SS4K_MODEL_DENSE)), "desc.flags: NO_DENSE and DENSE exclude each other");
+  if (fl & SS4K_MODEL_NO_DENSE) dense_mode = 1;
+  if (fl & SS4K_MODEL_DENSE) dense_mode = 2;
   if (fl & SS4K_MODEL_HR_F32) hr_f32 = true;
   if (!(fl & (SS4K_MODEL_ONE_CHAIN | SS4K_MODEL_TWO_CHAINS)))
     if (const char* e = std::getenv("SS4K_LANES")) lanes_mode = std::max(0, std::min(2, std::atoi(e)));
@@ -205,6 +208,7 @@ void Model::build(const float* w, size_t n) {
   if (const char* e = std::getenv("SS4K_RS_W8")) rs_wide = e[0] == '1';          // A/B switch: eight-wave variants of the 32-cout shapes
   if (const char* e = std::getenv("SS4K_MB")) mb_override = std::atoi(e);
   if (const char* e = std::getenv("SS4K_S3")) use_s3 = e[0] == '1';
+  if (const char* e = std::getenv("SS4K_DENSE_MASK")) dense_mask = std::atoi(e);   // A/B switch: which layer pairs of an RDB run fused
   if (const char* e = std::getenv("SS4K_LANE_GRID")) lane_grid_share = (float)std::atof(e);   // A/B switch: grid of a lane's launch as a share of the chip's slots
   if (const char* e = std::getenv("SS4K_FAIL_AT_CONV")) fail_at_conv = std::atoi(e);   // fault injection: the k-th conv call of every
                                                                                         // other forward throws (tests the unwind of a forked forward)
@@ -390,6 +394,57 @@ bool Model::conv_pair(int li, const Tens& in0, int N, int H, int W, const ConvOp
     a.grid_share = lane_grid_share;
     a.flops = flops * a.N;
     launch_conv3x3_pair(ctx, a, l == 0 ? st : ctx->lane_stream());
+  }
+  return true;
+}
+
+// ---- fused dense-block layer pair (conv_dense.hip) --------------------------------------------------------------------
+bool Model::conv_dense(int li, const Tens& in0, const Tens* in1, int N, int H, int W, float slope, const Tens& out1, const Tens& out2, hipStream_t st) {
+  const ConvLayer& A = layers[li]; const ConvLayer& B = layers[li + 1];
+  const int pair_bit = (A.nchunks0 + A.nchunks1) <= 4 ? 1 : 2;   // dense_mask: 1 = (conv1, conv2), 2 = (conv3, conv4)
+  // default: fused for a job that runs as ONE chain of one-frame launches (nothing else covers its launch boundaries and partly filled
+  // rounds: + 8-11 % measured); bigger jobs measured - 3 ... + 0.6 % box by box (the fused tile spends 18 % more MFMAs), so they keep
+  // one launch per layer unless SS4K_MODEL_DENSE asks for the fused pairs everywhere
+  const bool want = dense_mode == 2 || (dense_mode == 0 && N == 1 && cur_lanes <= 1);
+  if (!want || !(dense_mask & pair_bit) || desc.dtype != SS4K_F16 || dbg || chain_rec || A.has_prelu || B.has_prelu || A.nchunks0 != B.nchunks0 ||
+      !conv3x3_dense2_eligible(A.nchunks0 + A.nchunks1, A.cout_pad, B.nchunks0 + B.nchunks1, B.cout_pad))
+    return false;
+  if (plan_only) return true;
+#ifdef SS4K_DEV
+  if (fail_at_conv > 0 && ++conv_calls == fail_at_conv) throw Error(SS4K_EINVAL, "injected failure (SS4K_FAIL_AT_CONV)");
+#endif
+  SS4K_REQUIRE((in1 != nullptr) == (A.nchunks1 > 0), "internal: conv segment mismatch");
+  DenseArgs a{};
+  a.in0 = in0.p; a.in0_plane_bytes = in0.plane_bytes; a.in0_plane0 = in0.plane0; a.nchunks0 = A.nchunks0;
+  if (in1) { a.in1 = in1->p; a.in1_plane_bytes = in1->plane_bytes; a.in1_plane0 = in1->plane0; a.nchunks1 = A.nchunks1; }
+  a.w1 = A.w.as<char>(); a.bias1 = A.bias.as<float>();
+  a.w2 = B.w.as<char>(); a.bias2 = B.bias.as<float>();
+  a.slope = slope;
+  a.out1 = out1.p; a.out1_plane_bytes = out1.plane_bytes; a.out1_plane0 = out1.plane0;
+  a.out2 = out2.p; a.out2_plane_bytes = out2.plane_bytes; a.out2_plane0 = out2.plane0;
+  a.H = H; a.W = W;
+  a.reverse = (flip_walk && (launch_parity ^= 1)) ? 1 : 0;
+  const double flops = 2.0 * 9.0 * ((double)A.cin_real * A.cout_real + (double)B.cin_real * B.cout_real) * (double)H * W;
+  if (ctx->prof && !section_open) {
+    section = ctx->prof_get_events();
+    SS4K_HIP(hipEventRecord(section.a, st));
+    section_open = true;
+  }
+  if (cur_lanes <= 1 || N != cur_n) {
+    a.n0 = 0; a.N = N; a.flops = flops * N;
+    launch_conv3x3_dense2(ctx, a, st);
+    return true;
+  }
+  if (!forked) {
+    SS4K_HIP(hipEventRecord(ctx->lane_fork(), st));
+    SS4K_HIP(hipStreamWaitEvent(ctx->lane_stream(), ctx->lane_fork(), 0));
+    forked = true;
+  }
+  for (int l = 0; l < 2; ++l) {
+    a.n0 = N * l / 2; a.N = N * (l + 1) / 2 - a.n0;
+    a.grid_share = lane_grid_share;
+    a.flops = flops * a.N;
+    launch_conv3x3_dense2(ctx, a, l == 0 ? st : ctx->lane_stream());
   }
   return true;
 }
@@ -707,6 +762,11 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
       const Tens rout[3] = {t1, t2, dst};
       for (int rr = 0; rr < 3; ++rr) {
         for (int c = 0; c < 4; ++c) {
+          // (conv1, conv2) and (conv3, conv4) read the same planes: one fused launch each where the shape fits (conv_dense.hip)
+          if (!(c & 1) && conv_dense(li, rin[rr], c == 0 ? nullptr : &G, n, H, W, 0.2f, plane_of(G, c * g), plane_of(G, (c + 1) * g), st)) {
+            li += 2; ++c;
+            continue;
+          }
           ConvOpts o; o.act = ACT_LRELU; o.slope = 0.2f; o.out = plane_of(G, c * g);
           conv(li++, rin[rr], c == 0 ? nullptr : &G, n, H, W, o, st);
         }

@@ -82,6 +82,9 @@ struct Model {
   void lanes_join(hipStream_t st, bool end_of_forward);
   // cross-layer chain (conv_chain.hip): the RRDB body of small fp16 jobs as ONE persistent launch.  While chain_rec is set,
   // conv() records work items instead of launching; chain_run() resolves the dependencies and launches the chain.
+  int dense_mode = 0;          // RRDBNet: (conv1, conv2) and (conv3, conv4) of every RDB as one fused launch each (conv_dense.hip): 0 = where measured
+                               // faster (one-frame jobs on one launch chain), 1 = never (SS4K_MODEL_NO_DENSE), 2 = every job (SS4K_MODEL_DENSE)
+  int dense_mask = 3;          // ... which pairs: bit 0 = (conv1, conv2), bit 1 = (conv3, conv4)
   bool use_pair = true;        // BSVD: inc / outc layer pairs as one fused launch each (conv_pair.hip); SS4K_MODEL_NO_PAIR: two launches
   int chain_mode = 1;          // 1: never (default, SS4K_MODEL_NO_CHAIN); 2: the RRDB body of every fp16 job (SS4K_MODEL_CHAIN)
   bool chain_rec = false;
@@ -135,6 +138,8 @@ struct Model {
   void conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, const ConvOpts& o, hipStream_t st);
   // layers li (ReLU6) and li + 1 (options o) as one fused launch; false (nothing done) if the pair does not fit the fused kernel
   bool conv_pair(int li, const Tens& in0, int N, int H, int W, const ConvOpts& o, hipStream_t st);
+  // dense-block layers li and li + 1 (both LeakyReLU `slope`, outputs out1 / out2) as one fused launch; false if the pair does not fit
+  bool conv_dense(int li, const Tens& in0, const Tens* in1, int N, int H, int W, float slope, const Tens& out1, const Tens& out2, hipStream_t st);
   Tens act(int idx, size_t pixels, int channels);
   void pack_in(const float* in, const Tens& dst, int nplanes, int n, int c, int h, int w, int r, hipStream_t st);
 };
