@@ -97,8 +97,9 @@ enum {
                                    differ by at most 1 LSB in a few per cent of the bytes - an fp16 model's own error is 30 dB above that) */
   SS4K_MODEL_NO_DENSE = 1024,   /* RRDBNet: conv1..conv4 of every dense block always as four launches, never as two fused layer pairs
                                    (csrc/conv_dense.hip: (conv1, conv2) and (conv3, conv4) stream their shared input planes once and
-                                   hand x1 / x3 over in LDS); bit-identical results.  Default: fused where it is measured faster */
-  SS4K_MODEL_DENSE = 2048,      /* ... fused pairs for every job size */
+                                   hand x1 / x3 over in LDS); bit-identical results.  Default: fused */
+  SS4K_MODEL_DENSE = 2048,      /* ... fused pairs pinned (today's default; a test or caller that must not follow a later change of
+                                   the default policy sets it) */
   SS4K_MODEL_FLAGS_ALL = 4095
 };
 

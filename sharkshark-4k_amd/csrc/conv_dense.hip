@@ -3,28 +3,30 @@
 //
 // Why.  conv_{k+1} reads exactly conv_k's input planes plus conv_k's output: launched one after the other the two layers stream the
 // same planes twice and the 32-channel x_k makes a round trip through memory in between.  Here a workgroup
-//   * streams the shared input planes ONCE: per K-chunk one halo tile feeds two accumulator sets - conv_k on the output tile grown by
-//     one pixel (18 rows x 32 columns) and conv_{k+1}'s partial sum on the tile itself - and every activation fragment read from LDS
-//     feeds up to six MFMAs (three of each layer) instead of three: the x-phase IS the 64-cout tile body of conv_mfma.hip with
-//     [W_k ; W_{k+1}] as its two cout blocks;
+//   * streams the shared input planes ONCE: per K-chunk one halo tile feeds two accumulator sets - conv_k and conv_{k+1}'s partial sum
+//     on the same 16 x 32 pixels - and every activation fragment read from LDS feeds up to six MFMAs (three of each layer) instead of
+//     three: this part IS the 64-cout tile body of conv_mfma.hip with [W_k ; W_{k+1}] as its two cout blocks;
+//   * computes the one-pixel RING of x_k around the tile (34 + 34 + 16 + 16 = 100 pixels) as ONE more 32-pixel MFMA group per wave: a
+//     lane of that group is any pixel of the ring (per-lane LDS addresses make the gather free), so the halo costs 4 pixel groups on top
+//     of 16 rows x 32 columns, every wave carries the same load, and all 32 lanes of the tile's MFMAs are output pixels;
 //   * activates x_k, rounds it to fp16 exactly as the store does, keeps it in LDS (positions outside the image are ZEROS: they are
-//     conv_{k+1}'s padding, not conv_k evaluated on padded input), writes its interior to memory (conv5 and the later layers read it)
-//     and finishes conv_{k+1} with two K-chunks from LDS.
+//     conv_{k+1}'s padding, not conv_k evaluated on padded input), writes the tile's own 16 x 32 pixels to memory (conv5 and the later
+//     layers read them) and finishes conv_{k+1} with two K-chunks from LDS.
 // Per pixel and RDB the planes read drop from 4+6+8+10 = 28 to 4+8 = 12 (conv5's 12 stay), the launches from 5 to 3.
+// MFMA work against four launches: conv_k x 20/16 (the ring), conv_{k+1} x 1: + 10 % on (conv1, conv2), + 11 % on (conv3, conv4).
 //
-// Geometry (fp16, 4 waves, TWO workgroups per CU like the kernel it replaces):
-//   output tile of conv_{k+1}: 16 rows x 30 columns (lane l of an MFMA's 32 pixels <-> image column x0 - 1 + l; lanes 1..30 are stored)
-//   x_k tile:                  18 rows x 32 columns (rows y0 - 1 .. y0 + 16, lanes 0..31), LDS image 18 x 34 pixels (column = lane + 1)
-//   input halo tile:           20 rows x 34 columns per K-chunk (rows y0 - 2 .., columns x0 - 2 ..)
-//   wave w: conv_{k+1} rows 4w .. 4w+3 and conv_k rows y0 + 4w .. y0 + 4w + 3 - the SAME six input rows, so the two layers share every
-//   fragment; x_k's two extra rows (y0 - 1: wave 0, y0 + 16: wave 3) cost those waves one more row of conv_k MFMAs.
-//   MFMA work: x 32/30 on every layer (two of 32 lanes are halo), x 5/4 on conv_k for waves 0 and 3.
-// LDS (80.6 KB, two workgroups per CU): two 21.3 KB halo-tile buffers, two 18 KB weight stages (a chunk's W_k and W_{k+1} fragments, each
-// 9 KB, DMA'd from the two layers' own packed blobs - pack.cpp, nothing is repacked), 256 B of biases.  After the last input chunk the two
-// tile buffers are free: x_k's plane 0 lives in buffer 0, plane 1 in buffer 1 (19.1 KB each), and the next tile's first chunk is
-// prefetched into buffer 0 while conv_{k+1}'s last chunk reads buffer 1.
+// Geometry (fp16, 4 waves, TWO workgroups per CU like the kernel it replaces).  All LDS images of a tile share ONE coordinate system:
+// buffer (row r, column c) <-> image (y0 - 2 + r, x0 - 2 + c), rows of 36 pixels:
+//   input halo tile: rows 0..19, columns 0..35, one per K-chunk (22.5 KB, double buffered);
+//   x_k:             rows 1..18, columns 1..34, plane 0 in tile buffer 0 and plane 1 in buffer 1 once the input chunks are done;
+//   wave w owns output rows y0 + 4w .. 4w+3 of BOTH layers (they read the same six buffer rows 4w+1 .. 4w+6 at columns lane+1+dx)
+//   plus ring group w; conv_{k+1}'s reads of x_k use the very same addresses as its reads of the input tile.
+// Weights: a five-slot ring of 6 KB units in LDS.  A unit is one tap column (dx) of one K-chunk of both layers ([W_k: 3 KB][W_{k+1}:
+// 3 KB], DMA'd from the two layers' own packed blobs - pack.cpp, nothing is repacked); conv_{k+1}'s two x_k chunks are three more units.
+// Two 22.5 KB tile buffers + two 18 KB weight stages would be 81.3 KB - one workgroup per CU; the ring (30 KB) needs one more
+// (LDS-only) barrier per K-chunk: after tap column 0 every wave is past the oldest unit and its slot takes the next chunk's last unit.
 //
-// Results are BIT-IDENTICAL to the two launches on the LDS-weights kernel (tests/test_gpu_dense_pair.py): same packed fragments, fp32
+// Results are BIT-IDENTICAL to the four launches on the LDS-weights kernel (tests/test_gpu_dense_pair.py): same packed fragments, fp32
 // accumulators start from the bias, MFMAs per output in (K-chunk, dx, dy) order, LeakyReLU as max(t, slope t), round-to-nearest fp16.
 #include "common.h"
 #include "conv_tile.h"
@@ -32,21 +34,20 @@
 namespace ss4k {
 namespace dense {
 
-constexpr int NW = 4, MB = 4, TH = NW * MB, TWO = TW - 2;
-constexpr int XH = TH + 4;                          // rows of an input halo tile
+constexpr int NW = 4, MB = 4, TH = NW * MB;
+constexpr int XH = TH + 4, XW = TW + 4;             // rows / columns of a tile buffer image
 constexpr int REC = 32, SPR = 2;
-constexpr int ROWB = IN_W * REC;                    // bytes of one 34-pixel row of an LDS image
-constexpr int XT_SLOTS = XH * IN_W * SPR;           // 1360 16-byte slots
-constexpr int XT_BYTES = XT_SLOTS * 16;             // 21760
-constexpr int XT_DMA = (XT_SLOTS + 63) / 64;        // 22 wave-level DMA instructions
+constexpr int ROWX = XW * REC;                      // 1152 bytes per image row
+constexpr int XT_SLOTS = XH * XW * SPR;             // 1440 16-byte slots
+constexpr int XT_BYTES = XT_SLOTS * 16;             // 23040
+constexpr int XT_DMA = (XT_SLOTS + 63) / 64;        // 23 wave-level DMA instructions (the last one half full)
 constexpr int DMA_PER_WAVE = (XT_DMA + NW - 1) / NW;  // 6
-constexpr int WC = 9 * 64 * 16;                     // one layer's fragments for one K-chunk: 9216 bytes
-constexpr int W_BYTES = 2 * WC;                     // a weight stage
-constexpr int NDMA_W = (18 + NW - 1) / NW;          // 5
-constexpr int NDMA = DMA_PER_WAVE + NDMA_W;         // 11 DMA slots per wave and chunk
-constexpr size_t LDS_BYTES = 2 * XT_BYTES + 2 * W_BYTES + 64 * 4;
+constexpr int WU = 6 * 1024, NSLOT = 5;             // weight unit, ring slots
+constexpr int NDMA = 11;                            // DMA slots per wave and chunk: 6 tile pieces, 3 for weight units 0 and 1, 2 for unit 2
+constexpr int W_OFF = 2 * XT_BYTES, B_OFF = W_OFF + NSLOT * WU;
+constexpr size_t LDS_BYTES = B_OFF + 64 * 4;
 static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
-static_assert((TH + 2) * ROWB <= XT_BYTES, "x_k's plane image fits a tile buffer");
+static_assert((TH + 3) * ROWX <= XT_BYTES, "x_k's plane image fits a tile buffer");
 
 // LeakyReLU with a slope in [0, 1] as max(t, slope t) - the value conv_mfma.hip's epilogue computes with fmaxf - in ONE instruction:
 // v_med3_f32(t, slope t, +inf).  (fmaxf costs two: in IEEE mode the compiler first quiets a possible signalling NaN with v_max(t, t).)
@@ -62,7 +63,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_dense2_kernel(const DenseA
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   const int K1 = K1T ? K1T : a.nchunks0 + a.nchunks1;   // K-chunks of conv_k = the planes both layers read (even, host-checked)
-  // STAMP: [0] tile setup + accumulator init, [1] x-phase reads + MFMAs + DMA issue, [2] x-phase vmcnt wait, [3] x-phase barrier, [4] x_k
+  const int ntiles = a.N * a.tiles_y * a.tiles_x;
+  // STAMP: [0] tile setup + accumulator init, [1] x-phase reads + MFMAs + DMA issue, [2] x-phase vmcnt wait, [3] x-phase barriers, [4] x_k
   // epilogue, [5] barrier after it, [6] x_k-phase reads + MFMAs, [7] barrier between its chunks, [8] hand-over wait, [9] hand-over barrier,
   // [10] conv_{k+1} epilogue
   unsigned long long ph[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, rt0 = 0, ct0 = 0;
@@ -77,7 +79,6 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_dense2_kernel(const DenseA
       tlast = t;
     }
   };
-  const int ntiles = a.N * a.tiles_y * a.tiles_x;
 
   // XCD-banded persistent tile walk (conv_mfma.hip): placement only, never results
   const bool banded = (gridDim.x % 8 == 0) && ntiles >= (int)gridDim.x;
@@ -93,55 +94,86 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_dense2_kernel(const DenseA
   };
 
   auto swz = [](int x) { return (x >> 3) & 1; };
-  // operand read base: LDS image row 4w + 1, column lr + dx.  Input tile: the wave's six rows are 4w+1 .. 4w+6 (+ ir * ROWB);
-  // x_k image: rows 4w .. 4w+5 ((ir - 1) * ROWB).
+  // byte offset of pixel (r, c)'s 16-byte half `lh` inside a tile buffer image
+  auto img_off = [&](int r, int c) { return ((r * XW + c) * SPR + (lh ^ swz(c))) * 16; };
+  // operand read base of both layers' 16 x 32 pixels: buffer row 4w + 1 (+ ir), column lane + 1 + dx
   int rd_base[3];
 #pragma unroll
-  for (int dx = 0; dx < 3; ++dx) {
-    const int x = lr + dx;
-    rd_base[dx] = (((wave * MB + 1) * IN_W + x) * SPR + (lh ^ swz(x))) * 16;
-  }
+  for (int dx = 0; dx < 3; ++dx) rd_base[dx] = img_off(wave * MB + 1, lr + 1 + dx);
+  // The ring of x_k around the tile, in x_k coordinates (j, i) = buffer (j + 1, i + 1): top row j = 0 and bottom row j = 17 (i = 0..33),
+  // left column i = 0 and right column i = 33 (j = 1..16).  Ring group w: every 16-lane half u = 2w + (lane >> 4) & 1 takes two pixels of
+  // each column (consecutive rows: different banks) and nine consecutive pixels of the two rows; 3 of 16 lanes idle.
+  auto ring_pixel = [&]() -> int {   // j | i << 8 | valid << 16 (recomputed where needed: cheaper than a register through the MFMA loops)
+    int lre = lr;
+    asm volatile("" : "+v"(lre));
+    const int u = 2 * wave + (lre >> 4), t = lre & 15;
+    int j = 0, i = 0; bool ok = true;
+    if (t < 4) { j = 1 + 2 * u + (t & 1); i = (t & 2) ? TW + 1 : 0; }
+    else {
+      const int p = 9 * u + (t - 4);
+      ok = t < 13 && p < 2 * (TW + 2);
+      j = p < TW + 2 ? 0 : TH + 1; i = p < TW + 2 ? p : p - (TW + 2);
+    }
+    if (!ok) { j = 0; i = 0; }
+    return j | (i << 8) | ((ok ? 1 : 0) << 16);
+  };
+  int rd_h[3];   // x_k (j, i) reads buffer (j + dy, i + dx)
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) { const int hp = ring_pixel(); rd_h[dx] = img_off(hp & 0xff, ((hp >> 8) & 0xff) + dx); }
+
   // per-lane source of every halo-tile DMA instruction of this wave: byte offset inside a plane (32 bits: the host sends bigger
-  // planes down the two-launch route), OOB = the zero page.  LDS slot s = 64k + lane holds pixel (row, x) = (s / 2) divmod 34, source
+  // planes down the four-launch route), OOB = the zero page.  LDS slot s = 64k + lane holds pixel (row, x) = (s / 2) divmod 36, source
   // channel group (s & 1) ^ swz(x).  Recomputed per tile (six divisions by a constant) instead of kept in registers.
   uint32_t src_off[DMA_PER_WAVE];
   auto setup_tile = [&](int tile, int& n, int& y0, int& x0) {
     const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
     const int ty = tyn % a.tiles_y;
-    n = a.n0 + tyn / a.tiles_y; y0 = ty * TH; x0 = tx * TWO;
+    n = a.n0 + tyn / a.tiles_y; y0 = ty * TH; x0 = tx * TW;
 #pragma unroll
     for (int j = 0; j < DMA_PER_WAVE; ++j) {
       const int s = (wave + NW * j) * 64 + lane;
       const int p = s >> 1, gq = s & 1;
-      const int row = p / IN_W, x = p - row * IN_W;
+      const int row = p / XW, x = p - row * XW;
       const int iy = y0 - 2 + row, ix = x0 - 2 + x;
       const bool ok = s < XT_SLOTS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
       src_off[j] = ok ? ((uint32_t)(n * a.H + iy) * (uint32_t)a.W + (uint32_t)ix) * REC + (uint32_t)((gq ^ swz(x)) * 16) : OOB;
     }
   };
-
-  // a prefetch = an optional halo tile (DMA_PER_WAVE instructions per wave) + an optional weight stage (18 KB = two 9 KB pieces)
-  const char* pf_plane = nullptr; const char* pf_wa = nullptr; const char* pf_wb = nullptr;
-  uint32_t pf_tdst = 0, pf_wdst = 0; bool pf_tile = false, pf_w = false;
   auto plane_of = [&](int c) {
     return (c < a.nchunks0) ? a.in0 + (size_t)(a.in0_plane0 + c) * a.in0_plane_bytes
                             : a.in1 + (size_t)(a.in1_plane0 + c - a.nchunks0) * a.in1_plane_bytes;
   };
-  auto dma_op = [&](int idx) {
-    if (idx < DMA_PER_WAVE) {
-      const int k = wave + NW * idx;
-      if (pf_tile && k < XT_DMA) {
-        const char* src = src_off[idx] != OOB ? pf_plane + src_off[idx] : a.zero_page + (lane & 3) * 16;
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(pf_tdst + k * 1024);
-        if (k * 64 + lane < XT_SLOTS) dma16(src, dst);   // lanes past the tile's last slot are masked off (EXEC)
-      }
-    } else if (idx < NDMA) {
-      const int k = wave + NW * (idx - DMA_PER_WAVE);
-      if (pf_w && k < 18) dma16((k < 9 ? pf_wa + k * 1024 : pf_wb + (k - 9) * 1024) + lane * 16, __builtin_amdgcn_readfirstlane(pf_wdst + k * 1024));
+
+  // ---- prefetch state.  A prefetch is an optional halo tile (23 instructions) and up to three weight units (6 each) of chunk `pf_cn` of
+  // conv_k / conv_{k+1} (pf_cn < K1: unit g = tap column g of both layers) or of conv_{k+1}'s x_k chunks (pf_cn == K1: unit g = the g-th
+  // 6 KB of its last two chunks); units go to ring slots pf_slot, pf_slot + 1, pf_slot + 2 (mod 5).
+  const char* pf_plane = nullptr; uint32_t pf_tdst = 0; int pf_cn = 0, pf_slot = 0; bool pf_tile = false, pf_w01 = false, pf_w2 = false;
+  auto slot_add = [](int s, int k) { const int t = s + k; return t >= NSLOT ? t - NSLOT : t; };
+  auto unit_piece = [&](int u, int piece) {   // DMA of 1 KB piece `piece` (0..5) of unit u of the prefetched chunk
+    const char* src = pf_cn < K1 ? (piece < 3 ? a.w1 : a.w2) + (size_t)((pf_cn * 9 + u * 3 + (piece < 3 ? piece : piece - 3)) * 1024)
+                                 : a.w2 + (size_t)((K1 * 9 + u * 6 + piece) * 1024);
+    dma16(src + lane * 16, __builtin_amdgcn_readfirstlane(lds0 + W_OFF + slot_add(pf_slot, u) * WU + piece * 1024));
+  };
+  auto tile_piece = [&](int j) {
+    const int k = wave + NW * j;
+    if (k < XT_DMA) {
+      const char* src = src_off[j] != OOB ? pf_plane + src_off[j] : a.zero_page + (lane & 3) * 16;
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(pf_tdst + k * 1024);
+      if (k * 64 + lane < XT_SLOTS) dma16(src, dst);   // lanes past the tile's last slot are masked off (EXEC)
     }
   };
+  // DMA slots of a chunk's MFMA stream, idx 0..10.  The halo tile first (its pieces come from beyond L2 and take longest to land): idx
+  // 0..5, all in tap column 0; then the weights (L2-resident): units 0, 1 on idx 6..8 and unit 2 on idx 9, 10 - its slot is free only after
+  // the barrier that follows tap column 0, and these slots lie in column 1.  Column 2 issues nothing: its MFMAs cover the flight time.
+  auto dma_op = [&](int idx) {
+    if (idx < DMA_PER_WAVE) { if (pf_tile) tile_piece(idx); }
+    else if (idx < DMA_PER_WAVE + 3) { const int k = wave + NW * (idx - DMA_PER_WAVE); if (pf_w01) unit_piece(k / 6, k % 6); }
+    else if (idx < NDMA) { const int k = wave + NW * (idx - DMA_PER_WAVE - 3); if (pf_w2 && k < 6) unit_piece(2, k); }
+  };
+  // slot after MFMA pair m of tap column g: column 0 after every second pair (6 slots), column 1 after pairs 1, 3, 5, 7, 9 (5 slots)
+  auto slot_of = [](int g, int m) { return (m & 1) ? (g == 0 ? m / 2 : g == 1 && m / 2 < 5 ? 6 + m / 2 : -1) : -1; };
 
-  float* bias_lds = reinterpret_cast<float*>(smem + 2 * XT_BYTES + 2 * W_BYTES);  // [conv_k 32][conv_{k+1} 32]
+  float* bias_lds = reinterpret_cast<float*>(smem + B_OFF);  // [conv_k 32][conv_{k+1} 32]
   if (tid < 64) bias_lds[tid] = tid < 32 ? a.bias1[tid] : a.bias2[tid - 32];
 
   int kt = 0;
@@ -149,16 +181,17 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_dense2_kernel(const DenseA
   if (tile < 0) return;
   int n, y0, x0;
   setup_tile(tile, n, y0, x0);
-  int wbuf = 0;                                      // weight stage of the tile's first chunk (the tile buffer is always 0)
-  pf_tile = true; pf_w = true; pf_plane = plane_of(0); pf_tdst = lds0; pf_wa = a.w1; pf_wb = a.w2; pf_wdst = lds0 + 2 * XT_BYTES;
+  int slot0 = 0;                                     // ring slot of the tile's first weight unit (the tile buffer is always 0)
+  pf_tile = true; pf_w01 = true; pf_w2 = true; pf_plane = plane_of(0); pf_tdst = lds0; pf_cn = 0; pf_slot = 0;
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) dma_op(i);
   dma_wait();
   __syncthreads();
 
   const float slope = a.slope;
+  const int lane16 = lane * 16;
   while (true) {
-    f32x16 acc1[MB], acc1x, acc2[MB];
+    f32x16 acc1[MB], acch, acc2[MB];
     {
       float b1[16], b2[16];
 #pragma unroll
@@ -170,160 +203,152 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_dense2_kernel(const DenseA
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        acc1x[i] = b1[i];
+        acch[i] = b1[i];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) { acc1[mb][i] = b1[i]; acc2[mb][i] = b2[i]; }
       }
     }
     const int cur_n = n, cur_y0 = y0, cur_x0 = x0;
     const int next_tile = tile_of(kt + 1);
-    int tb = 0;
+    int tb = 0, slot = slot0;
     stamp(0);
 
     // ------------------------------------------------ x-phase: the planes both layers read, one halo tile per K-chunk
+#pragma unroll 1
     for (int c = 0; c < K1; ++c) {
-      if (c + 1 < K1) {
-        pf_tile = true; pf_w = true; pf_plane = plane_of(c + 1); pf_tdst = lds0 + (tb ^ 1) * XT_BYTES;
-        pf_wa = a.w1 + (size_t)(c + 1) * WC; pf_wb = a.w2 + (size_t)(c + 1) * WC;
-      } else {   // conv_{k+1}'s two x_k chunks: weights only (chunks K1, K1 + 1 of its blob are contiguous)
-        pf_tile = false; pf_w = true; pf_wa = a.w2 + (size_t)K1 * WC; pf_wb = pf_wa + WC;
-      }
-      pf_wdst = lds0 + 2 * XT_BYTES + (wbuf ^ 1) * W_BYTES;
+      // next chunk's tile + its three weight units (the last x chunk: conv_{k+1}'s x_k-chunk weights, no tile)
+      pf_tile = c + 1 < K1; pf_w01 = true; pf_w2 = true; pf_cn = c + 1; pf_slot = slot_add(slot, 3);
+      pf_plane = plane_of(c + 1 < K1 ? c + 1 : 0); pf_tdst = lds0 + (tb ^ 1) * XT_BYTES;
       const char* tbp = smem + tb * XT_BYTES;
-      const char* wbp = smem + 2 * XT_BYTES + wbuf * W_BYTES + lane * 16;
       // Fragments.  An input row's fragment is used by ONE step of the (dx, row) walk only (by the <= 3 MFMAs per layer that read row ir
       // at tap column dx), so three rotating registers hold the rows of steps t, t + 1, t + 2 and step t + 3 is loaded as soon as
-      // step t's MFMAs have issued (two steps of latency cover at a quarter of the registers six live rows would take).  The weight
-      // fragments of a tap column stay for its six steps and are refilled in place for the next column after their last MFMA.
-      uint4 wf1[3], wf2[3], af[3], afx;
-      auto af_load = [&](int t) { return *reinterpret_cast<const uint4*>(tbp + rd_base[t / (MB + 2)] + (t % (MB + 2)) * ROWB); };
+      // step t's MFMAs have issued.  The ring group's nine fragments (one per tap, one every second row) share one register.  The
+      // weight fragments of a tap column stay for its six steps and are refilled in place for the next column after their last MFMA.
+      uint4 wf1[3], wf2[3], af[3], hf;
+      auto af_load = [&](int t) { return *reinterpret_cast<const uint4*>(tbp + rd_base[t / (MB + 2)] + (t % (MB + 2)) * ROWX); };
+      auto hf_load = [&](int q) { return *reinterpret_cast<const uint4*>(tbp + rd_h[q / 3] + (q % 3) * ROWX); };
+      const char* wbp = smem + W_OFF + slot * WU + lane16;
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
-        wf1[dy] = *reinterpret_cast<const uint4*>(wbp + (dy * 64) * 16);
-        wf2[dy] = *reinterpret_cast<const uint4*>(wbp + WC + (dy * 64) * 16);
+        wf1[dy] = *reinterpret_cast<const uint4*>(wbp + dy * 1024);
+        wf2[dy] = *reinterpret_cast<const uint4*>(wbp + 3072 + dy * 1024);
       }
 #pragma unroll
       for (int t = 0; t < 3; ++t) af[t] = af_load(t);
-      // the extra conv_k row: wave 0 -> x_k row 0 reads input rows 0 (this fragment), 1, 2; wave 3 -> x_k row 17 reads input rows 17, 18
-      // and 19 (this fragment)
-      if (wave == 0) afx = *reinterpret_cast<const uint4*>(tbp + rd_base[0] - ROWB);
-      if (wave == NW - 1) afx = *reinterpret_cast<const uint4*>(tbp + rd_base[0] + (MB + 2) * ROWB);
+      hf = hf_load(0);
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         const bool more = g + 1 < 3;
+        const char* wbn = smem + W_OFF + slot_add(slot, g + 1) * WU + lane16;   // next tap column's unit
         int m = 0;
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ir = 0; ir < MB + 2; ++ir) {
           const int t = g * (MB + 2) + ir;
-          const uint4& cur = af[t % 3];
-          if (ir == 0 && wave == 0) {
-            acc1x = mma<__half>(wf1[0], afx, acc1x);
-            if (more) afx = *reinterpret_cast<const uint4*>(tbp + rd_base[g + 1] - ROWB);
-          }
 #pragma unroll
           for (int dy = 0; dy < 3; ++dy) {
             const int mb = ir - dy;
             if (mb >= 0 && mb < MB) {
-              acc1[mb] = mma<__half>(wf1[dy], cur, acc1[mb]);
-              acc2[mb] = mma<__half>(wf2[dy], cur, acc2[mb]);
-              if (m % 3 == 1 && g * 4 + m / 3 < NDMA) {
+              acc1[mb] = mma<__half>(wf1[dy], af[t % 3], acc1[mb]);
+              acc2[mb] = mma<__half>(wf2[dy], af[t % 3], acc2[mb]);
+              if (slot_of(g, m) >= 0) {
                 __builtin_amdgcn_sched_barrier(0);
-                dma_op(g * 4 + m / 3);
+                dma_op(slot_of(g, m));
                 __builtin_amdgcn_sched_barrier(0);
               }
               ++m;
             }
           }
-          if (ir == 0 && wave == 0) acc1x = mma<__half>(wf1[1], cur, acc1x);
-          if (ir == 1 && wave == 0) acc1x = mma<__half>(wf1[2], cur, acc1x);
-          if (ir == MB && wave == NW - 1) acc1x = mma<__half>(wf1[0], cur, acc1x);
-          if (ir == MB + 1 && wave == NW - 1) {
-            acc1x = mma<__half>(wf1[1], cur, acc1x);
-            acc1x = mma<__half>(wf1[2], afx, acc1x);
-            if (more) afx = *reinterpret_cast<const uint4*>(tbp + rd_base[g + 1] + (MB + 2) * ROWB);
+          if (ir & 1) {   // ring group: tap (dx = g, dy = ir / 2) after rows 1, 3, 5
+            const int q = g * 3 + (ir >> 1);
+            acch = mma<__half>(wf1[ir >> 1], hf, acch);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < 9) hf = hf_load(q + 1);   // (needed two rows of MFMAs from here)
           }
           __builtin_amdgcn_sched_barrier(0);
           if (t + 3 < 3 * (MB + 2)) af[t % 3] = af_load(t + 3);
           if (more) {   // weights of the next tap column, in place, as soon as a register's last MFMA of this column has issued
-            if (ir >= MB - 1) wf2[ir - (MB - 1)] = *reinterpret_cast<const uint4*>(wbp + WC + (((g + 1) * 3 + ir - (MB - 1)) * 64) * 16);
-            if (ir == MB) wf1[0] = *reinterpret_cast<const uint4*>(wbp + (((g + 1) * 3 + 0) * 64) * 16);
-            if (ir == MB + 1) {
-              wf1[1] = *reinterpret_cast<const uint4*>(wbp + (((g + 1) * 3 + 1) * 64) * 16);
-              wf1[2] = *reinterpret_cast<const uint4*>(wbp + (((g + 1) * 3 + 2) * 64) * 16);
-            }
+            if (ir >= MB - 1) wf2[ir - (MB - 1)] = *reinterpret_cast<const uint4*>(wbn + 3072 + (ir - (MB - 1)) * 1024);
+            if (ir == MB - 1) wf1[0] = *reinterpret_cast<const uint4*>(wbn);            // (the ring group used dy = 0 after row 1,
+            if (ir == MB) wf1[1] = *reinterpret_cast<const uint4*>(wbn + 1024);         //  dy = 1 after row 3,
+            if (ir == MB + 1) wf1[2] = *reinterpret_cast<const uint4*>(wbn + 2048);     //  dy = 2 after row 5)
           }
           __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
+        if (g == 0) { stamp(1); lds_barrier(); stamp(3); }   // every wave is past this chunk's first unit: its slot takes the next chunk's last
       }
       stamp(1);
       dma_wait();        // the next chunk's tile / weights have landed
       stamp(2);
       __syncthreads();   // and every wave is done with this chunk's buffers
       stamp(3);
-      tb ^= 1; wbuf ^= 1;
+      tb ^= 1; slot = slot_add(slot, 3);
     }
-    // here: tb == 0 (K1 is even), weight stage wbuf holds conv_{k+1}'s chunks K1 (first half) and K1 + 1 (second half); both tile
-    // buffers are free
+    // here: tb == 0 (K1 is even); ring slots slot, slot + 1, slot + 2 hold conv_{k+1}'s chunks K1 and K1 + 1 (6 x 3 KB in order); both
+    // tile buffers are free
 
-    // ------------------------------------------------ x_k: activation, fp16, -> LDS (zeros outside the image) and -> memory (interior)
+    // ------------------------------------------------ x_k: activation, fp16, -> LDS (zeros outside the image) and -> memory (own pixels)
     {
-      const int xcol = cur_x0 - 1 + lr;
-      const bool col_in = xcol >= 0 && xcol < a.W;
-      const bool col_st = col_in && lr >= 1 && lr <= TWO;
       int lhe = lh;
-      asm volatile("" : "+v"(lhe));   // re-derive the store pointers per tile (hoisted they cost registers through the MFMA loops)
+      asm volatile("" : "+v"(lhe));   // re-derive the pointers per tile (hoisted they cost registers through the MFMA loops)
       char* o1 = a.out1 + (size_t)a.out1_plane0 * a.out1_plane_bytes + (size_t)lhe * 16;
-      const uint32_t lrow = (uint32_t)(((lr + 1) * SPR + (lhe ^ swz(lr + 1))) * 16);
-      auto put = [&](const f32x16& acc, int j, bool to_mem) {
-        const int y = cur_y0 - 1 + j;
+      // x_k pixel at buffer (r, c) = image (cur_y0 - 2 + r, cur_x0 - 2 + c)
+      auto put = [&](const f32x16& acc, int r, int c, bool own, bool live) {
+        const int y = cur_y0 - 2 + r, x = cur_x0 - 2 + c;
         float v[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { const float t = acc[i]; v[i] = lrelu(t, slope); }
+        for (int i = 0; i < 16; ++i) v[i] = lrelu(acc[i], slope);
         uint4 h0, h1;
         __half* p0 = reinterpret_cast<__half*>(&h0);
         __half* p1 = reinterpret_cast<__half*>(&h1);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { p0[i] = __float2half(v[i]); p1[i] = __float2half(v[8 + i]); }
-        const uint32_t msk = (col_in && y >= 0 && y < a.H) ? 0xFFFFFFFFu : 0u;   // outside the image: zeros (conv_{k+1}'s padding)
-        char* l = smem + j * ROWB + lrow;
-        *reinterpret_cast<uint4*>(l) = make_uint4(h0.x & msk, h0.y & msk, h0.z & msk, h0.w & msk);
-        *reinterpret_cast<uint4*>(l + XT_BYTES) = make_uint4(h1.x & msk, h1.y & msk, h1.z & msk, h1.w & msk);
-        if (to_mem && col_st && y < a.H) {
-          char* o = o1 + ((size_t)(cur_n * a.H + y) * a.W + xcol) * REC;
+        const bool in = y >= 0 && y < a.H && x >= 0 && x < a.W;
+        const uint32_t msk = in ? 0xFFFFFFFFu : 0u;   // outside the image: zeros (conv_{k+1}'s padding)
+        char* l = smem + ((r * XW + c) * SPR + (lhe ^ swz(c))) * 16;
+        if (live) {
+          *reinterpret_cast<uint4*>(l) = make_uint4(h0.x & msk, h0.y & msk, h0.z & msk, h0.w & msk);
+          *reinterpret_cast<uint4*>(l + XT_BYTES) = make_uint4(h1.x & msk, h1.y & msk, h1.z & msk, h1.w & msk);
+        }
+        if (own && in) {
+          char* o = o1 + ((size_t)(cur_n * a.H + y) * a.W + x) * REC;
           __builtin_nontemporal_store(*reinterpret_cast<u32x4*>(&h0), reinterpret_cast<u32x4*>(o));
           __builtin_nontemporal_store(*reinterpret_cast<u32x4*>(&h1), reinterpret_cast<u32x4*>(o + a.out1_plane_bytes));
         }
       };
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) put(acc1[mb], wave * MB + 1 + mb, true);
-      if (wave == 0) put(acc1x, 0, false);
-      if (wave == NW - 1) put(acc1x, TH + 1, false);
+      for (int mb = 0; mb < MB; ++mb) put(acc1[mb], wave * MB + 2 + mb, lr + 2, true, true);
+      const int hpix = ring_pixel();
+      put(acch, (hpix & 0xff) + 1, ((hpix >> 8) & 0xff) + 1, false, (hpix >> 16) != 0);
     }
     stamp(4);
     lds_barrier();   // x_k is visible; (its stores to memory stay in flight)
     stamp(5);
 
-    // ------------------------------------------------ conv_{k+1}'s last two K-chunks: x_k from LDS
+    // ------------------------------------------------ conv_{k+1}'s last two K-chunks: x_k from LDS, at the input tile's addresses
     if (next_tile >= 0) setup_tile(next_tile, n, y0, x0);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      // chunk K1: the next tile's first weight stage goes into the free one; chunk K1 + 1: its first halo tile into buffer 0
-      pf_tile = h == 1 && next_tile >= 0; pf_w = h == 0 && next_tile >= 0;
-      pf_plane = plane_of(0); pf_tdst = lds0; pf_wa = a.w1; pf_wb = a.w2; pf_wdst = lds0 + 2 * XT_BYTES + (wbuf ^ 1) * W_BYTES;
-      const char* tbp = smem + h * XT_BYTES - ROWB;       // image row 4w + ir = read base row (4w + 1) + (ir - 1)
-      const char* wbp = smem + 2 * XT_BYTES + wbuf * W_BYTES + h * WC + lane * 16;
+      // chunk K1: the next tile's first two weight units go into the two free slots; chunk K1 + 1 (every wave is past the ring's oldest
+      // unit and past plane 0's image): its third unit and its first halo tile (buffer 0)
+      pf_tile = h == 1 && next_tile >= 0; pf_w01 = h == 0 && next_tile >= 0; pf_w2 = pf_tile;
+      pf_plane = plane_of(0); pf_tdst = lds0; pf_cn = 0; pf_slot = slot_add(slot, 3);
+      const char* tbp = smem + h * XT_BYTES;
       uint4 wf[3], af[3];
-      auto af_load = [&](int t) { return *reinterpret_cast<const uint4*>(tbp + rd_base[t / (MB + 2)] + (t % (MB + 2)) * ROWB); };
+      auto af_load = [&](int t) { return *reinterpret_cast<const uint4*>(tbp + rd_base[t / (MB + 2)] + (t % (MB + 2)) * ROWX); };
+      // tap column g of chunk K1 + h: the (3h + g)-th 3 KB of the three units
+      auto wptr = [&](int g) { const int e = 3 * h + g; return smem + W_OFF + slot_add(slot, e >> 1) * WU + (e & 1) * 3072 + lane16; };
+      const char* wbp = wptr(0);
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) wf[dy] = *reinterpret_cast<const uint4*>(wbp + (dy * 64) * 16);
+      for (int dy = 0; dy < 3; ++dy) wf[dy] = *reinterpret_cast<const uint4*>(wbp + dy * 1024);
 #pragma unroll
       for (int t = 0; t < 3; ++t) af[t] = af_load(t);
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         const bool more = g + 1 < 3;
+        const char* wbn = wptr(more ? g + 1 : g);
         int m = 0;
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
@@ -335,9 +360,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_dense2_kernel(const DenseA
             const int mb = ir - dy;
             if (mb >= 0 && mb < MB) {
               acc2[mb] = mma<__half>(wf[dy], af[t % 3], acc2[mb]);
-              if (m % 3 == 1 && g * 4 + m / 3 < NDMA) {
+              if (slot_of(g, m) >= 0) {
                 __builtin_amdgcn_sched_barrier(0);
-                dma_op(g * 4 + m / 3);
+                dma_op(slot_of(g, m));
                 __builtin_amdgcn_sched_barrier(0);
               }
               ++m;
@@ -345,13 +370,13 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_dense2_kernel(const DenseA
           }
           __builtin_amdgcn_sched_barrier(0);
           if (t + 3 < 3 * (MB + 2)) af[t % 3] = af_load(t + 3);
-          if (more && ir >= MB - 1) wf[ir - (MB - 1)] = *reinterpret_cast<const uint4*>(wbp + (((g + 1) * 3 + ir - (MB - 1)) * 64) * 16);
+          if (more && ir >= MB - 1) wf[ir - (MB - 1)] = *reinterpret_cast<const uint4*>(wbn + (ir - (MB - 1)) * 1024);
           __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
       }
       stamp(6);
-      if (h == 0) { lds_barrier(); stamp(7); }   // every wave is done with plane 0's image: the next tile's halo tile may land there
+      if (h == 0) { lds_barrier(); stamp(7); }
     }
     // hand the buffers to the next tile BEFORE the epilogue (conv_mfma.hip): the stores drain under its first chunk's MFMAs
     if (next_tile >= 0) {
@@ -359,13 +384,12 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_dense2_kernel(const DenseA
       stamp(8);
       __syncthreads();
       stamp(9);
-      wbuf ^= 1;
+      slot0 = slot_add(slot, 3);
     }
 
-    // ------------------------------------------------ conv_{k+1}'s epilogue: activation, fp16, interior lanes -> memory
+    // ------------------------------------------------ conv_{k+1}'s epilogue: activation, fp16, -> memory
     {
-      const int xcol = cur_x0 - 1 + lr;
-      const bool col_st = xcol < a.W && lr >= 1 && lr <= TWO;
+      const int x = cur_x0 + lr;
       int lhe = lh;
       asm volatile("" : "+v"(lhe));
       char* o2 = a.out2 + (size_t)a.out2_plane0 * a.out2_plane_bytes + (size_t)lhe * 16;
@@ -375,8 +399,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_dense2_kernel(const DenseA
         float v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = lrelu(acc2[mb][i], slope);
-        if (col_st && y < a.H) {
-          char* o = o2 + ((size_t)(cur_n * a.H + y) * a.W + xcol) * REC;
+        if (x < a.W && y < a.H) {
+          char* o = o2 + ((size_t)(cur_n * a.H + y) * a.W + x) * REC;
           store8<__half>(o, v);
           store8<__half>(o + a.out2_plane_bytes, v + 8);
         }
@@ -408,8 +432,8 @@ void launch_conv3x3_dense2(ss4k_ctx* ctx, const DenseArgs& a0, hipStream_t st) {
   SS4K_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0, "dense pair: empty grid");
   SS4K_REQUIRE((a.nchunks0 + a.nchunks1) % 2 == 0 && a.nchunks0 + a.nchunks1 >= 2, "dense pair: conv_k needs an even number of K-chunks");
   SS4K_REQUIRE(a.slope >= 0.f && a.slope <= 1.f, "dense pair: LeakyReLU slope must be in [0,1]");
-  SS4K_REQUIRE((double)a.N * a.H * a.W < 2147483648.0, "dense pair: a plane holds at most 2^31 pixels");
-  a.tiles_x = (a.W + TWO - 1) / TWO; a.tiles_y = (a.H + TH - 1) / TH;
+  SS4K_REQUIRE((double)a.N * a.H * a.W * 32.0 < 4294967296.0, "dense pair: a plane holds at most 4 GB");
+  a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = (a.H + TH - 1) / TH;
   a.zero_page = ctx->zero_page();
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
   int gx = std::min(ntiles, std::max(1, (int)(ctx->num_cu * 2 * (a.grid_share > 0.f ? a.grid_share : 1.f))));

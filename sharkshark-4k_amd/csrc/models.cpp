@@ -209,6 +209,7 @@ void Model::build(const float* w, size_t n) {
   if (const char* e = std::getenv("SS4K_MB")) mb_override = std::atoi(e);
   if (const char* e = std::getenv("SS4K_S3")) use_s3 = e[0] == '1';
   if (const char* e = std::getenv("SS4K_DENSE_MASK")) dense_mask = std::atoi(e);   // A/B switch: which layer pairs of an RDB run fused
+  if (const char* e = std::getenv("SS4K_DENSE_MODE")) dense_mode = std::atoi(e);   // A/B switch: 0 default policy, 1 never, 2 every job
   if (const char* e = std::getenv("SS4K_LANE_GRID")) lane_grid_share = (float)std::atof(e);   // A/B switch: grid of a lane's launch as a share of the chip's slots
   if (const char* e = std::getenv("SS4K_FAIL_AT_CONV")) fail_at_conv = std::atoi(e);   // fault injection: the k-th conv call of every
                                                                                         // other forward throws (tests the unwind of a forked forward)
@@ -402,10 +403,9 @@ bool Model::conv_pair(int li, const Tens& in0, int N, int H, int W, const ConvOp
 bool Model::conv_dense(int li, const Tens& in0, const Tens* in1, int N, int H, int W, float slope, const Tens& out1, const Tens& out2, hipStream_t st) {
   const ConvLayer& A = layers[li]; const ConvLayer& B = layers[li + 1];
   const int pair_bit = (A.nchunks0 + A.nchunks1) <= 4 ? 1 : 2;   // dense_mask: 1 = (conv1, conv2), 2 = (conv3, conv4)
-  // default: fused for a job that runs as ONE chain of one-frame launches (nothing else covers its launch boundaries and partly filled
-  // rounds: + 8-11 % measured); bigger jobs measured - 3 ... + 0.6 % box by box (the fused tile spends 18 % more MFMAs), so they keep
-  // one launch per layer unless SS4K_MODEL_DENSE asks for the fused pairs everywhere
-  const bool want = dense_mode == 2 || (dense_mode == 0 && N == 1 && cur_lanes <= 1);
+  // default: fused.  Measured on the headline network (tools/env_ab.py SS4K_DENSE_MODE, one box, interleaved): 4-frame jobs + 2.4 %,
+  // 2-frame jobs + 3.0 %, one-frame jobs + 11.5 % (nothing else covers their launch boundaries and partly filled rounds of tiles)
+  const bool want = dense_mode != 1;
   if (!want || !(dense_mask & pair_bit) || desc.dtype != SS4K_F16 || dbg || chain_rec || A.has_prelu || B.has_prelu || A.nchunks0 != B.nchunks0 ||
       !conv3x3_dense2_eligible(A.nchunks0 + A.nchunks1, A.cout_pad, B.nchunks0 + B.nchunks1, B.cout_pad))
     return false;

@@ -82,8 +82,8 @@ struct Model {
   void lanes_join(hipStream_t st, bool end_of_forward);
   // cross-layer chain (conv_chain.hip): the RRDB body of small fp16 jobs as ONE persistent launch.  While chain_rec is set,
   // conv() records work items instead of launching; chain_run() resolves the dependencies and launches the chain.
-  int dense_mode = 0;          // RRDBNet: (conv1, conv2) and (conv3, conv4) of every RDB as one fused launch each (conv_dense.hip): 0 = where measured
-                               // faster (one-frame jobs on one launch chain), 1 = never (SS4K_MODEL_NO_DENSE), 2 = every job (SS4K_MODEL_DENSE)
+  int dense_mode = 0;          // RRDBNet: (conv1, conv2) and (conv3, conv4) of every RDB as one fused launch each (conv_dense.hip): 0 = default (fused),
+                               // 1 = never (SS4K_MODEL_NO_DENSE), 2 = forced (SS4K_MODEL_DENSE; the same as the default today)
   int dense_mask = 3;          // ... which pairs: bit 0 = (conv1, conv2), bit 1 = (conv3, conv4)
   bool use_pair = true;        // BSVD: inc / outc layer pairs as one fused launch each (conv_pair.hip); SS4K_MODEL_NO_PAIR: two launches
   int chain_mode = 1;          // 1: never (default, SS4K_MODEL_NO_CHAIN); 2: the RRDB body of every fp16 job (SS4K_MODEL_CHAIN)
