@@ -413,8 +413,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : wgs_per_cu<T, NB, MB, NW>()
             } else {
 #pragma unroll
               for (int i = 0; i < 16; ++i) {
+                // max(t, slope t) in ONE instruction, v_med3_f32(t, slope t, +inf) (fmaxf is two in IEEE mode: the compiler first quiets
+                // a possible signalling NaN with v_max(t, t)); the same value for every non-NaN t
                 const float t = acc[nb][mb][i];
-                v[i] = fmaxf(t, t * slope_v[i]) * alpha;
+                v[i] = __builtin_amdgcn_fmed3f(t, t * slope_v[i], __builtin_inff()) * alpha;
               }
             }
             if (ok) {
