@@ -39,9 +39,11 @@ PMC_TRAFFIC_FILE = "conv3x3_pmc_traffic_current.json"  # written by tools/collec
 # (33.4 MB) once per step: 88.7 MB for a 4-frame step
 ALGORITHMIC_BYTES_PER_FRAME, ALGORITHMIC_WEIGHT_BYTES = 2_764_800 + 11_059_200, 33.4e6
 HBM_SPEC_GBS, HBM_ACHIEVABLE_GBS = 8000.0, 6290.0  # MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured (float4 copy)
-CONV_KERNEL_NAME = ("3x3 implicit-GEMM conv, all launches of a step: ss4k::conv3x3_kernel<__half,NB> (LDS weights, "
-                    "v_mfma_f32_32x32x16_f16) + ss4k::rs::conv3x3_rs_kernel<6,16,1,4> (register-stationary weights, "
-                    "v_mfma_f32_16x16x32_f16; conv5 of every RDB)")
+CONV_KERNEL_NAME = ("3x3 implicit-GEMM conv, all launches of a step: ss4k::dense::conv3x3_dense2_kernel<4|8> (fused layer pairs "
+                    "(conv1, conv2) / (conv3, conv4) of every RDB, v_mfma_f32_32x32x16_f16) + ss4k::rs::conv3x3_rs_kernel<6,16,1,4> "
+                    "(register-stationary weights, v_mfma_f32_16x16x32_f16; conv5 of every RDB) + ss4k::conv3x3_kernel<__half,NB> "
+                    "(LDS weights; first / trunk / tail layers)")
+LAUNCHES_PER_FRAME = 213  # 23 blocks x 3 RDBs x (2 fused pairs + conv5) + conv_first, conv_body, conv_up1, conv_up2, conv_hr, conv_last
 
 WORKLOADS = {
     "rrdbnet": "RealESRGAN RRDBNet x2 (23 blocks) 720p->1440p fp16 [BASELINE configs[2]]",
@@ -352,14 +354,15 @@ def main():
         if rl is not None:
             traffic, traffic_src = None, None
             pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
-            if args.workload == "rrdbnet" and args.batch == 4 and os.path.exists(pmc):
+            if args.workload == "rrdbnet" and os.path.exists(pmc) and "traffic_bytes_per_step" in json.load(open(pmc)):
                 # HBM-side bytes per launch cannot be read from inside the process: they come from the
                 # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
                 with open(pmc) as f:
                     pj = json.load(f)
-                # the committed passes ran with two launch chains forced (2 frames per launch): scale to this run's launches
-                fpl = args.batch * 351.0 / rl["launches_per_step"]
-                traffic = pj["traffic_bytes_per_launch"] * fpl / pj["frames_per_launch"]
+                # bytes per step of all conv launches together (the counter passes ran the same job at pj["frames_per_step"] frames
+                # per step); per launch = that / this run's launches per step
+                bytes_step_pmc = pj["traffic_bytes_per_step"] * args.batch / pj["frames_per_step"]
+                traffic = bytes_step_pmc / rl["launches_per_step"]
                 traffic_src = f"profiles/{PMC_TRAFFIC_FILE} (" + pj["correction"] + f"; {pj['frames_per_launch']} frames per launch in the counter passes)"
             mfma = {"achieved": rl["achieved"], "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rl["frac"]}
             hbm = None
@@ -393,7 +396,7 @@ def main():
                                   "avg_launch_us": rl["avg_launch_us"],
                                   "algorithmic_gflop_per_launch": rl["algorithmic_gflop_per_launch"],
                                   "concurrent_launches": rl["concurrent_launches"],
-                                  "frames_per_launch": args.batch * 351.0 / rl["launches_per_step"],
+                                  "launches_per_frame_chain": LAUNCHES_PER_FRAME,
                                   "kernel_time_share_of_step": rl["conv_ms_per_step"] / (1000.0 * elapsed / args.steps)}
         elif args.workload in ("fsrcnn", "fsrcnn_f16"):
             # FSRCNN: three stages, each against the unit that bounds it (fsrcnn_stage_rooflines); the line's roofline is the

@@ -49,9 +49,21 @@ constexpr size_t LDS_BYTES = B_OFF + 64 * 4;
 static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 static_assert((TH + 3) * ROWX <= XT_BYTES, "x_k's plane image fits a tile buffer");
 
-// LeakyReLU with a slope in [0, 1] as max(t, slope t) - the value conv_mfma.hip's epilogue computes with fmaxf - in ONE instruction:
-// v_med3_f32(t, slope t, +inf).  (fmaxf costs two: in IEEE mode the compiler first quiets a possible signalling NaN with v_max(t, t).)
-__device__ __forceinline__ float lrelu(float t, float slope) { return __builtin_amdgcn_fmed3f(t, t * slope, __builtin_inff()); }
+// LeakyReLU with a slope in [0, 1] as max(t, slope t) - the value conv_mfma.hip's epilogue computes with fmaxf - of the 16 values of an
+// accumulator: the products two at a time (v_pk_mul_f32), the maximum as ONE v_max_f32 each (asm: fmaxf, and v_med3(t, slope t, +inf)
+// which the compiler folds back to it, cost two - in IEEE mode a possible signalling NaN is first quieted with v_max(t, t); the
+// hardware instruction returns the same value for every non-NaN input).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lrelu16(const f32x16& acc, float slope, float* v) {
+  const f32x2 s2 = {slope, slope};
+#pragma unroll
+  for (int i = 0; i < 16; i += 2) {
+    const f32x2 t = {acc[i], acc[i + 1]};
+    const f32x2 n = t * s2;
+    asm("v_max_f32 %0, %1, %2" : "=v"(v[i]) : "v"(t.x), "v"(n.x));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v[i + 1]) : "v"(t.y), "v"(n.y));
+  }
+}
 
 // K1T: K-chunks of conv_k when known at compile time (RRDBNet: 4 and 8), 0 = read from the arguments
 //   STAMP (dev library): per-wave cycle totals of the tile's phases (s_memtime), see launch_conv3x3_dense2
@@ -193,20 +205,23 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_dense2_kernel(const DenseA
   while (true) {
     f32x16 acc1[MB], acch, acc2[MB];
     {
-      float b1[16], b2[16];
+      // accumulators start from the bias: 16-byte LDS reads (every lane of a half-wave reads the same four floats: a broadcast)
+      // straight into the accumulator registers - 36 reads instead of 8 reads + 144 register moves
+      // (as asm: left to the compiler the identical addresses are read once and copied 144 times)
+      typedef float f32x4v __attribute__((ext_vector_type(4)));
+      const uint32_t bl = lds0 + B_OFF + lh * 32;
+      auto init = [&](f32x16& acc, int layer) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 u = *reinterpret_cast<const float4*>(bias_lds + 16 * (q >> 1) + 8 * lh + 4 * (q & 1));
-        const float4 v = *reinterpret_cast<const float4*>(bias_lds + 32 + 16 * (q >> 1) + 8 * lh + 4 * (q & 1));
-        b1[4 * q] = u.x; b1[4 * q + 1] = u.y; b1[4 * q + 2] = u.z; b1[4 * q + 3] = u.w;
-        b2[4 * q] = v.x; b2[4 * q + 1] = v.y; b2[4 * q + 2] = v.z; b2[4 * q + 3] = v.w;
-      }
+        for (int q = 0; q < 4; ++q) {
+          f32x4v b;
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b) : "v"(bl), "i"(layer * 128 + 64 * (q >> 1) + 16 * (q & 1)));
+          acc[4 * q] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+        }
+      };
+      init(acch, 0);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        acch[i] = b1[i];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) { acc1[mb][i] = b1[i]; acc2[mb][i] = b2[i]; }
-      }
+      for (int mb = 0; mb < MB; ++mb) { init(acc1[mb], 0); init(acc2[mb], 1); }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     const int cur_n = n, cur_y0 = y0, cur_x0 = x0;
     const int next_tile = tile_of(kt + 1);
@@ -298,8 +313,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_dense2_kernel(const DenseA
       auto put = [&](const f32x16& acc, int r, int c, bool own, bool live) {
         const int y = cur_y0 - 2 + r, x = cur_x0 - 2 + c;
         float v[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = lrelu(acc[i], slope);
+        lrelu16(acc, slope, v);
         uint4 h0, h1;
         __half* p0 = reinterpret_cast<__half*>(&h0);
         __half* p1 = reinterpret_cast<__half*>(&h1);
@@ -329,54 +343,60 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_dense2_kernel(const DenseA
 
     // ------------------------------------------------ conv_{k+1}'s last two K-chunks: x_k from LDS, at the input tile's addresses
     if (next_tile >= 0) setup_tile(next_tile, n, y0, x0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      // chunk K1: the next tile's first two weight units go into the two free slots; chunk K1 + 1 (every wave is past the ring's oldest
-      // unit and past plane 0's image): its third unit and its first halo tile (buffer 0)
-      pf_tile = h == 1 && next_tile >= 0; pf_w01 = h == 0 && next_tile >= 0; pf_w2 = pf_tile;
-      pf_plane = plane_of(0); pf_tdst = lds0; pf_cn = 0; pf_slot = slot_add(slot, 3);
-      const char* tbp = smem + h * XT_BYTES;
+    {
       uint4 wf[3], af[3];
-      auto af_load = [&](int t) { return *reinterpret_cast<const uint4*>(tbp + rd_base[t / (MB + 2)] + (t % (MB + 2)) * ROWX); };
       // tap column g of chunk K1 + h: the (3h + g)-th 3 KB of the three units
-      auto wptr = [&](int g) { const int e = 3 * h + g; return smem + W_OFF + slot_add(slot, e >> 1) * WU + (e & 1) * 3072 + lane16; };
-      const char* wbp = wptr(0);
+      auto wptr = [&](int h, int g) { const int e = 3 * h + g; return smem + W_OFF + slot_add(slot, e >> 1) * WU + (e & 1) * 3072 + lane16; };
+      auto af_load = [&](int h, int t) { return *reinterpret_cast<const uint4*>(smem + h * XT_BYTES + rd_base[t / (MB + 2)] + (t % (MB + 2)) * ROWX); };
+      auto first_frags = [&](int h) {
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) wf[dy] = *reinterpret_cast<const uint4*>(wbp + dy * 1024);
+        for (int dy = 0; dy < 3; ++dy) wf[dy] = *reinterpret_cast<const uint4*>(wptr(h, 0) + dy * 1024);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) af[t] = af_load(t);
+        for (int t = 0; t < 3; ++t) af[t] = af_load(h, t);
+      };
+      first_frags(0);
 #pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        const bool more = g + 1 < 3;
-        const char* wbn = wptr(more ? g + 1 : g);
-        int m = 0;
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+      for (int h = 0; h < 2; ++h) {
+        // chunk K1: the next tile's first two weight units go into the two free slots; chunk K1 + 1 (every wave is past the ring's
+        // oldest unit and past plane 0's image): its third unit and its first halo tile (buffer 0)
+        pf_tile = h == 1 && next_tile >= 0; pf_w01 = h == 0 && next_tile >= 0; pf_w2 = pf_tile;
+        pf_plane = plane_of(0); pf_tdst = lds0; pf_cn = 0; pf_slot = slot_add(slot, 3);
 #pragma unroll
-        for (int ir = 0; ir < MB + 2; ++ir) {
-          const int t = g * (MB + 2) + ir;
+        for (int g = 0; g < 3; ++g) {
+          const bool more = g + 1 < 3;
+          const char* wbn = wptr(h, more ? g + 1 : g);
+          int m = 0;
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-          for (int dy = 0; dy < 3; ++dy) {
-            const int mb = ir - dy;
-            if (mb >= 0 && mb < MB) {
-              acc2[mb] = mma<__half>(wf[dy], af[t % 3], acc2[mb]);
-              if (slot_of(g, m) >= 0) {
-                __builtin_amdgcn_sched_barrier(0);
-                dma_op(slot_of(g, m));
-                __builtin_amdgcn_sched_barrier(0);
+          for (int ir = 0; ir < MB + 2; ++ir) {
+            const int t = g * (MB + 2) + ir;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+              const int mb = ir - dy;
+              if (mb >= 0 && mb < MB) {
+                acc2[mb] = mma<__half>(wf[dy], af[t % 3], acc2[mb]);
+                if (slot_of(g, m) >= 0) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  dma_op(slot_of(g, m));
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+                ++m;
               }
-              ++m;
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 3 < 3 * (MB + 2)) af[t % 3] = af_load(h, t + 3);
+            if (more && ir >= MB - 1) wf[ir - (MB - 1)] = *reinterpret_cast<const uint4*>(wbn + (ir - (MB - 1)) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);
-          if (t + 3 < 3 * (MB + 2)) af[t % 3] = af_load(t + 3);
-          if (more && ir >= MB - 1) wf[ir - (MB - 1)] = *reinterpret_cast<const uint4*>(wbn + (ir - (MB - 1)) * 1024);
-          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_setprio(0);
         }
-        __builtin_amdgcn_s_setprio(0);
+        stamp(6);
+        if (h == 0) {
+          first_frags(1);   // plane 1's image and its weights are visible since the barrier before chunk K1: read ahead of the barrier
+          lds_barrier(); stamp(7);
+        }
       }
-      stamp(6);
-      if (h == 0) { lds_barrier(); stamp(7); }
     }
     // hand the buffers to the next tile BEFORE the epilogue (conv_mfma.hip): the stores drain under its first chunk's MFMAs
     if (next_tile >= 0) {
@@ -397,8 +417,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_dense2_kernel(const DenseA
       for (int mb = 0; mb < MB; ++mb) {
         const int y = cur_y0 + wave * MB + mb;
         float v[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = lrelu(acc2[mb][i], slope);
+        lrelu16(acc2[mb], slope, v);
         if (x < a.W && y < a.H) {
           char* o = o2 + ((size_t)(cur_n * a.H + y) * a.W + x) * REC;
           store8<__half>(o, v);

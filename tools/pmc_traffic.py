@@ -1,43 +1,46 @@
 """Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/<round>_conv3x3_pmc_traffic.json.
-usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> [frames_per_launch]
-Counts the dispatches of both 3x3 conv kernels (conv3x3_kernel = LDS weights, conv3x3_rs_kernel = register-stationary
-weights) - the same launches bench.py's roofline leg times; FETCH_SIZE is doubled per MI355X_MICROARCH.md (HBM section)."""
+usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> <frames_per_launch> <steps_run> <frames_per_step>
+Counts the dispatches of the 3x3 conv kernels (conv3x3_kernel = LDS weights, conv3x3_rs_kernel = register-stationary weights,
+conv3x3_dense2_kernel = fused dense-block layer pairs) - the same launches bench.py's roofline leg times; FETCH_SIZE is doubled per
+MI355X_MICROARCH.md (HBM section).  The figure bench.py uses is bytes per STEP (all conv launches of a step together): the
+kernels differ too much for a per-launch average to mean anything."""
 import csv, glob, json, sys
 from collections import defaultdict
+
+FAMILIES = ("conv3x3_rs_kernel", "conv3x3_dense2_kernel", "conv3x3_kernel")
 
 
 def per_dispatch(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
-    acc = defaultdict(float)
+    acc, fam = defaultdict(float), {}
     for r in csv.DictReader(open(f)):
         if "conv3x3" in r["Kernel_Name"] and r["Counter_Name"] == counter:
             acc[r["Dispatch_Id"]] += float(r["Counter_Value"])
-            FAMILY[r["Dispatch_Id"]] = "conv3x3_rs_kernel" if "conv3x3_rs_kernel" in r["Kernel_Name"] else "conv3x3_kernel"
-    return acc
+            fam[r["Dispatch_Id"]] = next(k for k in FAMILIES if k in r["Kernel_Name"])
+    return acc, fam
 
 
-FAMILY = {}
-
-
-fetch_d = per_dispatch(sys.argv[1], "FETCH_SIZE")
-fam_f = dict(FAMILY); FAMILY.clear()
-write_d = per_dispatch(sys.argv[2], "WRITE_SIZE")
-fam_w = dict(FAMILY)
-fetch, write = list(fetch_d.values()), list(write_d.values())
-n = int(sys.argv[4]) if len(sys.argv) > 4 else 4
-fa, wa = sum(fetch) / len(fetch), sum(write) / len(write)
+fetch_d, fam_f = per_dispatch(sys.argv[1], "FETCH_SIZE")
+write_d, fam_w = per_dispatch(sys.argv[2], "WRITE_SIZE")
+n = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+steps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+fps = int(sys.argv[6]) if len(sys.argv) > 6 else 4
+fetch_kb, write_kb = sum(fetch_d.values()), sum(write_d.values())
+total = (2 * fetch_kb + write_kb) * 1024
 by_family = {}
-for fam in sorted(set(fam_f.values())):
+for fam in FAMILIES:
     ff = [v for k, v in fetch_d.items() if fam_f[k] == fam]; ww = [v for k, v in write_d.items() if fam_w.get(k) == fam]
     if ff and ww:
-        by_family[fam] = {"launches": len(ff), "traffic_bytes_per_launch": (2 * sum(ff) / len(ff) + sum(ww) / len(ww)) * 1024}
+        by_family[fam] = {"launches_per_step": len(ff) / steps, "traffic_bytes_per_launch": (2 * sum(ff) / len(ff) + sum(ww) / len(ww)) * 1024,
+                          "traffic_bytes_per_step": (2 * sum(ff) + sum(ww)) * 1024 / steps}
 out = {
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 "
-              "--no-cpu-baseline --no-roofline --no-also (RRDBNet x2 720p fp16, %d frames per launch), launches of the two 3x3 conv kernels" % n,
-    "launches_counted": len(fetch), "frames_per_launch": n,
-    "fetch_size_kb_avg_raw": fa, "write_size_kb_avg": wa,
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps %d --warmup 1 "
+              "--no-cpu-baseline --no-roofline --no-also (RRDBNet x2 720p fp16, %d frames per step, %d per launch: SS4K_LANES=2), "
+              "every launch of the three 3x3 conv kernels" % (steps - 1, fps, n),
+    "launches_counted": len(fetch_d), "steps": steps, "frames_per_step": fps, "frames_per_launch": n,
     "correction": "FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as is; KB x1024",
-    "traffic_bytes_per_launch": (2 * fa + wa) * 1024,
+    "traffic_bytes_per_step": total / steps,
+    "traffic_bytes_per_launch": total / len(fetch_d),
     "by_kernel": by_family,
 }
 json.dump(out, open(sys.argv[3], "w"), indent=1)
