@@ -460,7 +460,7 @@ def main():
                 del up2, keep2
             torch.cuda.empty_cache()
         # 1-frame jobs from TWO callers (two upscalers, two streams, jobs alternating): what an image server with two requests
-        # queued gets from this GPU - the overlap the frame lanes give a multi-frame job, done by the caller (DESIGN.md 4.1c)
+        # queued gets from this GPU - the overlap the frame lanes give a multi-frame job, done by the caller (DESIGN.md 4.4)
         try:
             up_b, keep_b, _ = build_upscaler(_capi.Context(local), "rrdbnet", device, lr_shape=in_shape)
             fr1 = frames[:1]

@@ -1,5 +1,5 @@
 // Cross-layer execution of the RRDB body: a CHAIN of 3x3 convs (fp16, plain epilogue, 32-cout groups) as ONE persistent
-// launch, with per-tile ready counters in place of the kernel boundary between dependent layers.
+// launch, with per-tile ready counters in place of the kernel boundary between dependent layers (profiles/NOTES_r01_r03.md 4.1d).
 //
 // Why: a 1-frame 720p job is 345 dependent launches of 360-460 tiles on 512 workgroup slots - every launch pays its boundary,
 // the prologue of its workgroups (first K-chunk in flight, nothing to compute) and a partly filled round of tiles, and frame
@@ -533,7 +533,7 @@ static void launch_t(ss4k_ctx* ctx, const ChainArgs& a, hipStream_t st) {
   // Units are queued, so any grid is CORRECT.  The fastest grid keeps fewer units in flight than lie between a unit and the
   // nearest unit it waits for, (L, t) -> (L - 1, t + tiles_x + 1), i.e. ntiles - tiles_x - 1 tickets: with more workgroups every
   // unit starts before its predecessor layer has reached it and the chain of waits becomes the critical path (measured on one
-  // 720p frame, 460 tiles, 512 slots: 438-460 workgroups 94-97 fps, 480: 88-91, 512: 80-90)
+  // 720p frame, 460 tiles, 512 slots: 438-460 workgroups 94-97 fps, 480: 88-91, 512: 80-90; DESIGN.md 4.5, profiles/NOTES_r01_r03.md 4.1d)
   int gx = std::max(1, std::min(per_cu * ctx->num_cu, ntiles - a.tiles_x - 1));
   if (a.grid > 0) gx = a.grid;
   SS4K_HIP(hipMemsetAsync(a.ctl, 0, conv_chain_ctl_bytes(ntiles), st));

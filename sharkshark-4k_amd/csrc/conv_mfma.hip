@@ -700,7 +700,7 @@ template <int NB, int MB, int NW>
 static void launch_dbg(ss4k_ctx* ctx, const ConvArgs& a, int groups, hipStream_t st) {
   switch (a.dbg & 0xff) {
     case DBG_STAMP: launch_t<__half, NB, MB, NW, DBG_STAMP, EK_PLAIN>(ctx, a, groups, st); break;
-    // timing-only ablations of the memory traffic (results are garbage), see DESIGN.md 4.1:
+    // timing-only ablations of the memory traffic (results are garbage), see profiles/NOTES_r01_r03.md 4.1:
     //   33: halo tiles from a 2 MB L2-resident window, no output stores   (no fabric traffic)
     //   49: real halo tiles, no output stores                             (no fabric writes)
     //   48: halo tiles from the 2 MB window, real stores                  (no fabric reads)
@@ -733,7 +733,7 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
   SS4K_REQUIRE(!a.ups2 || ((a.H % 2 == 0) && (a.W % 2 == 0)), "conv3x3: ups2 needs even grid");
   SS4K_REQUIRE((double)a.N * a.H * a.W < 2147483648.0, "conv3x3: a plane holds at most 2^31 pixels");
   const ProfEvent pe = ctx->prof_begin(st, PROF_CONV);
-  // fp16 tile shapes <couts/32, rows per wave, waves>; see DESIGN.md 4.1 for how they were chosen
+  // fp16 tile shapes <couts/32, rows per wave, waves>; see DESIGN.md 4.3 and profiles/NOTES_r01_r03.md 4.1 for how they were chosen
   // fp16 layers of a supported shape with a plain epilogue: register-stationary weights on the 16x16x32 MFMA
   if (a.wrs && dtype == SS4K_F16 && !a.dbg && a.epi == EPI_NHWC && !a.bsvd_resid && a.act != ACT_RELU6) {
     launch_conv3x3_rs(ctx, a, st);

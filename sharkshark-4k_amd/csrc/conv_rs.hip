@@ -1,7 +1,7 @@
 // 3x3 convolution (pad 1, stride 1), fp16 storage / fp32 accumulate, with REGISTER-STATIONARY WEIGHTS
 // on v_mfma_f32_16x16x32_f16 - the production kernel of the RRDBNet / SRVGG body layers (round 2).
 //
-// Why this shape (measurements: tools/micro/mfma_shapes.hip, tools/micro/rs_skeleton.hip):
+// Why this shape (measurements: tools/micro/mfma_shapes.hip, tools/micro/rs_skeleton.hip, profiles/NOTES_r01_r03.md 4.1b):
 //   * on random data the chip holds a ~13 % higher clock on the 16x16x32 MFMA than on 32x32x16 at
 //     equal cycles per FLOP (the conv kernel is power-bound, not issue-bound);
 //   * K = 32 of that MFMA is one tap x 32 input channels = TWO 16-channel planes, so an LDS pipeline
@@ -24,7 +24,7 @@
 //     64 couts, cin  64 (trunk / tail / SRVGG): <2, 8, 2>      2 row groups x 2 cout halves
 //     64 couts, cin 192         (RDB conv5)   : <6, 16, 1>     every wave the whole tile, 16 couts each
 // (Eight-wave variants <NCH, 4, 1, CG = 2> of the 32-cout shapes - two waves per SIMD, 256 registers each - were
-// built and measured: 0.95-0.98x the LDS-weights kernel for conv1/conv2, register spills for conv3)
+// built and measured: 0.95-0.98x the LDS-weights kernel for conv1/conv2, register spills for conv3; profiles/NOTES_r01_r03.md 4.1b.)
 // Data layout in HBM is conv_mfma.hip's ("planes" of 16 channels, 32-byte records), so the two kernels
 // are interchangeable per layer; the fp32 parity path, the first / last layers and the BSVD epilogues stay
 // on conv_mfma.hip.

@@ -744,12 +744,12 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
     int li = 0;
     { ConvOpts o; o.out = F; conv(li++, P, nullptr, n, H, W, o, st); }
     Tens cur = F;
-    // the body of small fp16 jobs as ONE persistent launch with per-tile hand-offs between the layers (conv_chain.hip):
-    // 1-frame jobs by default (nothing else can overlap their 345 launch boundaries); SS4K_MODEL_CHAIN / _NO_CHAIN force it
-    // Opt-in (SS4K_MODEL_CHAIN).  Measured on one 720p frame (460 tiles per layer, 512 workgroup slots): the chain runs a single
+    // the body of an fp16 job as ONE persistent launch with per-tile hand-offs between the layers (conv_chain.hip): opt-in
+    // (SS4K_MODEL_CHAIN), never the default.  Measured in round 3 on one 720p frame (460 tiles per layer, 512 workgroup slots): the chain runs a single
     // caller's 1-frame jobs 1-6 % faster than 345 launches (box by box), but two callers alternating on two streams are better
     // off with launches (105-112 against 98 frames/s: their chains of launches fill each other's gaps, two chain kernels only
-    // compete for the slots) - and a model cannot know how many callers the GPU has.  DESIGN.md 4.1d.
+    // compete for the slots) - and a model cannot know how many callers the GPU has; since round 4 the fused dense-block launches
+    // (conv_dense.hip) give the single caller more than the chain does.  DESIGN.md 4.5, profiles/NOTES_r01_r03.md 4.1d.
     const bool use_chain = !plan_only && f16 && !dbg && nf == 64 && g == 32 && chain_mode == 2;
     if (use_chain) {
       chain_rec = true; chain_items.clear(); chain_layers.clear();

@@ -61,7 +61,7 @@ struct Model {
   // launch chains - lane 0 on the caller's stream, lane 1 on the context's lane stream, each working on its own half of
   // the frames of the same tensors, every launch still sized for the whole chip.  The hardware dispatcher then fills any
   // CU one chain leaves free (launch boundary, prologue, the partly filled last round of tiles) with waiting workgroups
-  // of the other chain (DESIGN.md 4.1c).  Frames are bit-identical to the single-chain path.
+  // of the other chain (DESIGN.md 4.4).  Frames are bit-identical to the single-chain path.
   bool use_s3 = false;         // 32-cout layers on the three-stage-ring kernel (conv_s3.hip)
   int mb_override = 0;         // SS4K_MB: rows per wave of the 32-cout layers' tiles forced to 4 or 5 (A/B switch)
   bool fs_exact = false;       // SS4K_FS_EXACT=1: FSRCNN's exact-fp32 kernels instead of the fp16-split matrix-core ones (A/B switch)
