@@ -67,7 +67,15 @@ def _load_checkpoint(spec, what: str, default_name: str, checkpoint_dir: Optiona
         # .pth found in a directory is not trusted code.  SS4K_UNSAFE_TORCH_LOAD=1 is the explicit opt-in for a legacy file
         # that pickles other objects (the reference itself loads with torch's old default, fsrcnn/factory.py:12).
         unsafe = os.environ.get("SS4K_UNSAFE_TORCH_LOAD") == "1"
-        return "ckpt", torch.load(os.fspath(spec), map_location="cpu", weights_only=not unsafe)
+        try:
+            return "ckpt", torch.load(os.fspath(spec), map_location="cpu", weights_only=not unsafe)
+        except Exception as e:  # pickle.UnpicklingError (torch re-raises it with its own advice to pass weights_only=False)
+            if unsafe or "weights_only" not in str(e).lower() and "unpickl" not in type(e).__name__.lower():
+                raise
+            raise RuntimeError(
+                f"{what}: {os.fspath(spec)!r} pickles objects other than tensors and plain containers, and checkpoints are "
+                f"loaded tensors-only. If you trust the file (it can run code when unpickled), set SS4K_UNSAFE_TORCH_LOAD=1 "
+                f"- the reference loads with that permissive default (fsrcnn/factory.py:8-13, bsvd/model.py:488). ({e})") from e
     if isinstance(spec, Mapping):
         if any(k in spec for k in ("state_dict", "params_ema", "params")) or any("nets_list." in str(k) for k in spec):
             return "ckpt", spec

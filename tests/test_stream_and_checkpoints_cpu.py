@@ -230,3 +230,30 @@ def test_service_weight_argument_is_validated():
     assert HipUpscalerService(denoising=False, weights="synthetic").weights == "synthetic"
     with pytest.raises(TypeError):
         HipUpscalerService(denoising=False, weights="random")
+
+
+class _NotATensor:   # module-level so that pickle can name it
+    def __init__(self):
+        self.x = 1
+
+
+def test_checkpoint_files_load_tensors_only_with_a_named_opt_in(tmp_path, monkeypatch):
+    """Checkpoint FILES are unpickled tensors-only (a .pth found in a directory is not trusted code).  A file with the usual
+    training wrappers ({'state_dict': ..., 'epoch': ...}) loads; one that pickles an arbitrary object is refused with a message
+    that names the explicit opt-in, SS4K_UNSAFE_TORCH_LOAD=1 - with which it loads as the reference's torch.load would."""
+    import torch
+    from sharkshark4k_amd.upscale import model as factory
+    table = W.fsrcnn_table(3)
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in table.items()}   # the table is in the reference's key names
+    good = tmp_path / "wrapped.pth"
+    torch.save({"state_dict": sd, "epoch": 12, "meta": {"lr": 1e-3, "name": "T91"}}, good)
+    monkeypatch.delenv("SS4K_UNSAFE_TORCH_LOAD", raising=False)
+    kind, obj = factory._load_checkpoint(str(good), "FSRCNN", "x.pth", None)
+    assert kind == "ckpt" and set(obj["state_dict"]) == set(sd) and obj["epoch"] == 12
+    bad = tmp_path / "objects.pth"
+    torch.save({"state_dict": sd, "hook": _NotATensor()}, bad)
+    with pytest.raises(RuntimeError, match="SS4K_UNSAFE_TORCH_LOAD=1"):
+        factory._load_checkpoint(str(bad), "FSRCNN", "x.pth", None)
+    monkeypatch.setenv("SS4K_UNSAFE_TORCH_LOAD", "1")
+    kind, obj = factory._load_checkpoint(str(bad), "FSRCNN", "x.pth", None)
+    assert kind == "ckpt" and isinstance(obj["hook"], _NotATensor)
