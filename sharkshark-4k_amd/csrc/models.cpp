@@ -407,7 +407,8 @@ bool Model::conv_dense(int li, const Tens& in0, const Tens* in1, int N, int H, i
   // 2-frame jobs + 3.0 %, one-frame jobs + 11.5 % (nothing else covers their launch boundaries and partly filled rounds of tiles)
   const bool want = dense_mode != 1;
   if (!want || !(dense_mask & pair_bit) || desc.dtype != SS4K_F16 || dbg || chain_rec || A.has_prelu || B.has_prelu || A.nchunks0 != B.nchunks0 ||
-      !conv3x3_dense2_eligible(A.nchunks0 + A.nchunks1, A.cout_pad, B.nchunks0 + B.nchunks1, B.cout_pad))
+      !conv3x3_dense2_eligible(A.nchunks0 + A.nchunks1, A.cout_pad, B.nchunks0 + B.nchunks1, B.cout_pad) ||
+      (double)N * H * W * rec() >= 4294967296.0)   // the fused kernel keeps 32-bit byte offsets inside a plane: bigger planes take four launches
     return false;
   if (plan_only) return true;
 #ifdef SS4K_DEV
