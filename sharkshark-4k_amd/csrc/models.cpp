@@ -635,7 +635,9 @@ size_t Model::workspace_bytes(int n, int h, int w) {
 // which is what a producing conv writes) for `pixels` pixels
 Tens Model::act(int idx, size_t pixels, int channels) {
   if ((int)acts.size() <= idx) acts.resize(idx + 1);
-  const int ch32 = (channels + 31) / 32 * 32;
+  // what a producing conv writes: one 32-cout block up to 32 channels, whole 64-cout groups beyond (pack_conv3x3's cout_pad - a
+  // 96-channel tensor is written as 128: sized to 96 its last two planes would land past the buffer)
+  const int ch32 = channels <= 32 ? 32 : (channels + 63) / 64 * 64;
   const int planes = planes_for(ch32);
   SS4K_REQUIRE(pixels < 2147483648ull, "an activation plane holds at most 2^31 pixels");
   const size_t need = (size_t)planes * pixels * rec();

@@ -65,3 +65,17 @@ def test_dense_pair_route_matches_oracle(ctx):
         want = onets.rrdbnet(x, t, 2, 2)
     got = _model(ctx, flat, 2, 2, DENSE)(x.cuda()).cpu()
     assert psnr(got, want) > 60.0
+
+
+@pytest.mark.parametrize("nf,g", [(32, 32), (96, 32), (64, 64)])
+def test_dense_pair_other_widths_bit_identical(ctx, nf, g):
+    """Trunk widths other than RealESRGAN's 64 / 32: conv_k has 2 / 6 / 4 (and conv3 6 / 10 / 12) K-chunks - the kernel build that
+    reads the chunk count from its arguments; a 64-channel growth is not a 32-cout pair and must take four launches by itself."""
+    t = W.rrdbnet_table(21, scale=2, num_feat=nf, num_block=1, num_grow_ch=g)
+    flat = W.flatten(t, W.rrdbnet_keys(1))
+    x = torch.rand(2, 3, 72, 136, generator=torch.Generator().manual_seed(nf + g)).cuda()
+    outs = []
+    for fl in (NO_DENSE | ONE, DENSE | ONE):
+        m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_feat=nf, num_block=1, num_grow_ch=g, flags=fl), flat)
+        outs.append(m(x).clone())
+    assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
