@@ -118,6 +118,16 @@ struct ss4k_ctx {
 
 namespace ss4k {
 
+// Bracket of one launch (or stage) with profiling events: prof_begin on construction, prof_end by done(); a launch that throws in
+// between gives its event pair back to the pool instead of leaking it.  A no-op unless profiling is enabled.
+struct ProfScope {
+  ss4k_ctx* ctx; hipStream_t st; ProfEvent pe; bool open;
+  ProfScope(ss4k_ctx* c, hipStream_t s, int kind) : ctx(c), st(s), pe(c->prof_begin(s, kind)), open(true) {}
+  void done(double flops) { if (open) { open = false; ctx->prof_end(pe, st, flops); } }
+  ~ProfScope() { if (open && pe.a) ctx->prof_pool.push_back(pe); }
+  ProfScope(const ProfScope&) = delete; ProfScope& operator=(const ProfScope&) = delete;
+};
+
 enum Act { ACT_NONE = 0, ACT_LRELU = 1, ACT_PRELU = 2, ACT_RELU6 = 3 };
 enum Epi {
   EPI_NHWC = 0,        // out[(n,y,x)*ocs + oco + v]

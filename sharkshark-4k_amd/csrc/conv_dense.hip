@@ -459,7 +459,7 @@ void launch_conv3x3_dense2(ss4k_ctx* ctx, const DenseArgs& a0, hipStream_t st) {
 #ifdef SS4K_DEV
   if (const char* e = std::getenv("SS4K_DENSE_GRID")) gx = std::min(ntiles, std::max(1, std::atoi(e)));   // e.g. 256: one workgroup per CU (stamps without a partner)
 #endif
-  const ProfEvent pe = ctx->prof_begin(st, PROF_CONV);
+  ProfScope prof(ctx, st, PROF_CONV);
   auto go = [&](auto kern) {
     const void* fn = reinterpret_cast<const void*>(kern);
     if (ctx->lds_attr_set.insert(fn).second)
@@ -495,7 +495,7 @@ void launch_conv3x3_dense2(ss4k_ctx* ctx, const DenseArgs& a0, hipStream_t st) {
         }
       }
     }
-    ctx->prof_end(pe, st, a0.flops);
+    prof.done(a0.flops);
     return;
   }
 #endif
@@ -505,7 +505,7 @@ void launch_conv3x3_dense2(ss4k_ctx* ctx, const DenseArgs& a0, hipStream_t st) {
     default: go(&conv3x3_dense2_kernel<0>); break;
   }
   SS4K_HIP(hipGetLastError());
-  ctx->prof_end(pe, st, a0.flops);
+  prof.done(a0.flops);
 }
 
 }  // namespace ss4k

@@ -732,7 +732,7 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
   SS4K_REQUIRE(a.act != ACT_LRELU || (a.slope >= 0.f && a.slope <= 1.f), "conv3x3: LeakyReLU slope must be in [0,1]");
   SS4K_REQUIRE(!a.ups2 || ((a.H % 2 == 0) && (a.W % 2 == 0)), "conv3x3: ups2 needs even grid");
   SS4K_REQUIRE((double)a.N * a.H * a.W < 2147483648.0, "conv3x3: a plane holds at most 2^31 pixels");
-  const ProfEvent pe = ctx->prof_begin(st, PROF_CONV);
+  ProfScope prof(ctx, st, PROF_CONV);
   // fp16 tile shapes <couts/32, rows per wave, waves>; see DESIGN.md 4.3 and profiles/NOTES_r01_r03.md 4.1 for how they were chosen
   // fp16 layers of a supported shape with a plain epilogue: register-stationary weights on the 16x16x32 MFMA
   if (a.wrs && dtype == SS4K_F16 && !a.dbg && a.epi == EPI_NHWC && !a.bsvd_resid && a.act != ACT_RELU6) {
@@ -798,7 +798,7 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
     else { if (nb == 1) { SS4K_LAUNCH_EK(float, 1) } else { SS4K_LAUNCH_EK(float, 2) } }
 #undef SS4K_LAUNCH_EK
   }
-  ctx->prof_end(pe, st, a0.flops);
+  prof.done(a0.flops);
 }
 
 }  // namespace ss4k

@@ -343,7 +343,7 @@ void launch_conv3x3_pair(ss4k_ctx* ctx, const PairArgs& a, hipStream_t st) {
   SS4K_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && (a.planes_a == 1 || a.planes_a == 2), "conv3x3_pair: shape");
   SS4K_REQUIRE(a.epi == 0 || a.res, "conv3x3_pair: the residual epilogues need the skip tensor");
   SS4K_REQUIRE(a.epi != 2 || (a.cout_real >= 1 && a.cout_real <= 8), "conv3x3_pair: NCHW output takes at most 8 channels");
-  const ProfEvent pe = ctx->prof_begin(st, PROF_CONV);
+  ProfScope prof(ctx, st, PROF_CONV);
 #define SS4K_PAIR(PA_) \
   switch (a.epi) { \
     case 0: launch_t<PA_, EPI_RELU6>(ctx, a, st); break; \
@@ -352,7 +352,7 @@ void launch_conv3x3_pair(ss4k_ctx* ctx, const PairArgs& a, hipStream_t st) {
   }
   if (a.planes_a == 1) { SS4K_PAIR(1) } else { SS4K_PAIR(2) }
 #undef SS4K_PAIR
-  ctx->prof_end(pe, st, a.flops);
+  prof.done(a.flops);
 }
 
 }  // namespace ss4k

@@ -1157,7 +1157,7 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
   // instructions per value, as many as the whole exact vector-ALU chain: not kept)
   // per-stage timing for bench.py's stage rooflines (ss4k_prof_read_kind); algorithmic FLOPs per LR pixel and plane:
   // head 2 * (25 * 56 + 56 * 12), mapping 2 * 4 * 9 * 12 * 12, tail 2 * (12 * 56 + 81 * 56)  (12 464 MAC in all)
-  ProfEvent pe = ctx->prof_begin(st, PROF_FS_HEAD);
+  ProfScope prof_head(ctx, st, PROF_FS_HEAD);
   // fp16 mode and the default fp32-grade mode run the head on the matrix cores (k_fs_head_m: one | three MFMAs per product); the exact
   // mode keeps the vector-ALU kernel
   if (!exact) {
@@ -1174,8 +1174,8 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
   } else
   hipLaunchKernelGGL(k_fs_head, grid, block, 0, st, in, ws12a, W.w_feat, W.b_feat, W.a_feat, W.w_shrink, W.b_shrink,
                      W.a_shrink, planes, h, w);
-  ctx->prof_end(pe, st, 4144.0 * (double)total);
-  pe = ctx->prof_begin(st, PROF_FS_MAP);
+  prof_head.done(4144.0 * (double)total);
+  ProfScope prof_map(ctx, st, PROF_FS_MAP);
   constexpr int FS_MAP_R = 4;
   const dim3 mgrid((unsigned)(((size_t)planes * ((h + FS_MAP_R - 1) / FS_MAP_R) * w + 255) / 256));
   float* cur = ws12a; float* nxt = ws12b;
@@ -1236,9 +1236,9 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
     }
     std::swap(cur, nxt);
   }
-  ctx->prof_end(pe, st, 10368.0 * (double)total);
+  prof_map.done(10368.0 * (double)total);
   SS4K_REQUIRE(factor == 2 || factor == 4, "FSRCNN: scale must be 2 or 4");
-  pe = ctx->prof_begin(st, PROF_FS_TAIL);
+  ProfScope prof_tail(ctx, st, PROF_FS_TAIL);
   const int ci = exact ? FS_CI : 4 * (factor == 2 ? FsTailGeo<2>::CI : FsTailGeo<4>::CI);   // interior LR columns per workgroup
   const int strips = (w + ci - 1) / ci;
   // one round of workgroups at three per CU; every band re-does 4 halo rows (fp16 mode: 4, 5 or 6 per CU measured, no gain)
@@ -1256,7 +1256,7 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
     if (exact) launch_tail(k_fs_tail<4>, 4); else if (half && out_half) launch_tail(k_fs_tail_r<4, false, true>, 4);
     else if (half) launch_tail(k_fs_tail_r<4, false>, 4); else launch_tail(k_fs_tail_r<4, true>, 4);
   }
-  ctx->prof_end(pe, st, 10416.0 * (double)total);
+  prof_tail.done(10416.0 * (double)total);
   SS4K_HIP(hipGetLastError());
 }
 

@@ -532,9 +532,9 @@ void Model::chain_run(int N, int H, int W, hipStream_t st) {
 #endif
   double flops = 0;
   for (const auto& l : chain_layers) flops += l.flops;
-  const ProfEvent pe = ctx->prof_begin(st, PROF_CONV);
+  ProfScope prof(ctx, st, PROF_CONV);
   launch_conv_chain(ctx, ca, mb, st);
-  ctx->prof_end(pe, st, flops);
+  prof.done(flops);
   SS4K_HIP(hipEventRecord(chain_done, st));   // ss4k_model_check(wait) waits for THIS launch before it reads the sticky word
   chain_pending = true;
 #ifdef SS4K_DEV
