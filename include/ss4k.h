@@ -100,7 +100,9 @@ enum {
                                    hand x1 / x3 over in LDS); bit-identical results.  Default: fused */
   SS4K_MODEL_DENSE = 2048,      /* ... fused pairs pinned (today's default; a test or caller that must not follow a later change of
                                    the default policy sets it) */
-  SS4K_MODEL_FLAGS_ALL = 4095
+  SS4K_MODEL_NO_WIDE = 4096,    /* fp16 layers with 64-cout groups and a plain epilogue (RRDBNet trunk / tail, SRVGG body, BSVD) on
+                                   conv_mfma.hip's <2,4,4> build instead of conv_dense.hip's single-layer build; bit-identical results */
+  SS4K_MODEL_FLAGS_ALL = 8191
 };
 
 int ss4k_abi_version(void);

@@ -147,6 +147,7 @@ struct ConvArgs {
   float grid_share;                     // size the persistent grid for this share of the chip's workgroup slots (0 = all)
   int mb_override;                      // 0: tile height of the 32-cout layers by image height; 4 / 5: rows per wave forced (A/B)
   int s3;                               // 32-cout layers without residuals on the three-stage kernel (conv_s3.hip)
+  int wide;                             // 64-cout-group layers with a plain epilogue on conv_dense.hip's single-layer build (conv3x3_wide_kernel)
   int no_band;                          // dev experiment: tiles dealt round-robin over the workgroups instead of one contiguous band per XCD
   int ups2;                             // input is the nearest-x2 upsampling of an (H/2, W/2) tensor
   const void* wpk;                      // packed weights [group][chunk][dx,ks][dy][nb][lane][E]
@@ -245,6 +246,10 @@ struct DenseArgs {
   unsigned long long* dbg_buf;                          // dev library, SS4K_DENSE_STAMP=1: per-wave phase cycle counters
 };
 bool conv3x3_dense2_eligible(int nchunks_a, int cout_pad_a, int nchunks_b, int cout_pad_b);
+// conv_dense.hip: one layer, 64 couts per workgroup, plain epilogue (bit-identical to conv_mfma.hip's <__half,2,4,4> build)
+struct ConvArgs;
+bool conv3x3_wide_eligible(const ConvArgs& a, int dtype);
+void launch_conv3x3_wide(ss4k_ctx* ctx, const ConvArgs& a, hipStream_t st);
 void launch_conv3x3_dense2(ss4k_ctx* ctx, const DenseArgs& a, hipStream_t st);
 
 int conv_cw(int dtype);  // channels per plane / K-chunk: 16

@@ -441,6 +441,308 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_dense2_kernel(const DenseA
 
 }  // namespace dense
 
+// =====================================================================================================================
+// conv3x3_wide_kernel: ONE 3x3 layer with 64 output channels per workgroup on the fused kernel's machinery (round 4) - the x-phase
+// above with the two cout blocks of one layer as its accumulator sets.  Against conv_mfma.hip's <__half,2,4,4> build (same tile,
+// same MFMA order per output: bit-identical results): three rotating activation-fragment registers instead of a fragment per row, the
+// halo tile's DMAs issued first and none in the last tap column, accumulators initialised by LDS reads, packed epilogue arithmetic,
+// weights as six 6 KB units (= two double-buffered stages addressed by tap column).  18 x 34 halo tile: 76 KB, two workgroups per CU.
+// Plain layout epilogue (activation, alpha, up to two residuals, in-place safe), nearest-x2 upsampled input as an address mode.
+namespace wide {
+
+constexpr int NW = 4, MB = 4, TH = NW * MB;
+constexpr int XH = TH + 2, XW = TW + 2;
+constexpr int REC = 32, SPR = 2;
+constexpr int ROWX = XW * REC;                      // 1088
+constexpr int XT_SLOTS = XH * XW * SPR;             // 1224
+constexpr int XT_BYTES = XT_SLOTS * 16;             // 19584
+constexpr int XT_DMA = (XT_SLOTS + 63) / 64;        // 20
+constexpr int DMA_PER_WAVE = (XT_DMA + NW - 1) / NW;  // 5
+constexpr int WU = 6 * 1024, NSLOT = 6;             // a unit = one tap column of one chunk: [dy][cout block][lane] fragments, as packed
+constexpr int NDMA = DMA_PER_WAVE + 5;
+constexpr int W_OFF = 2 * XT_BYTES, B_OFF = W_OFF + NSLOT * WU;
+constexpr size_t LDS_BYTES = B_OFF + 2 * 64 * 4;    // + bias and slope of the group's 64 couts
+static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+
+__global__ __launch_bounds__(64 * NW, 2) void conv3x3_wide_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int grp = blockIdx.y;
+  const int K = a.nchunks0 + a.nchunks1;
+  const int ntiles = a.N * a.tiles_y * a.tiles_x;
+  const char* wbase = reinterpret_cast<const char*>(a.wpk) + (size_t)grp * K * (3 * WU);
+  const int Hs = a.ups2 ? (a.H >> 1) : a.H, Ws = a.ups2 ? (a.W >> 1) : a.W;
+
+  const bool banded = (gridDim.x % 8 == 0) && ntiles >= (int)gridDim.x && !a.no_band;
+  const int tpx = (ntiles + 7) / 8;
+  auto tile_of = [&](int k) -> int {
+    if (!banded) {
+      const int t = blockIdx.x + k * gridDim.x;
+      return t < ntiles ? (a.reverse ? ntiles - 1 - t : t) : -1;
+    }
+    const int base = (blockIdx.x & 7) * tpx, len = min(tpx, ntiles - base);
+    const int j = (blockIdx.x >> 3) + k * (gridDim.x >> 3);
+    return j < len ? base + (a.reverse ? len - 1 - j : j) : -1;
+  };
+  auto swz = [](int x) { return (x >> 3) & 1; };
+  int rd_base[3];   // buffer (row r, column c) <-> image (y0 - 1 + r, x0 - 1 + c); wave w reads rows 4w .. 4w+5 at columns lane + dx
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) { const int c = lr + dx; rd_base[dx] = (((wave * MB) * XW + c) * SPR + (lh ^ swz(c))) * 16; }
+
+  uint32_t src_off[DMA_PER_WAVE];
+  auto setup_tile = [&](int tile, int& n, int& y0, int& x0) {
+    const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
+    const int ty = tyn % a.tiles_y;
+    n = a.n0 + tyn / a.tiles_y; y0 = ty * TH; x0 = tx * TW;
+#pragma unroll
+    for (int j = 0; j < DMA_PER_WAVE; ++j) {
+      const int s = (wave + NW * j) * 64 + lane;
+      const int p = s >> 1, gq = s & 1;
+      const int row = p / XW, x = p - row * XW;
+      const int iy = y0 - 1 + row, ix = x0 - 1 + x;
+      const bool ok = s < XT_SLOTS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const int sy = a.ups2 ? (iy >> 1) : iy, sx = a.ups2 ? (ix >> 1) : ix;
+      src_off[j] = ok ? ((uint32_t)(n * Hs + sy) * (uint32_t)Ws + (uint32_t)sx) * REC + (uint32_t)((gq ^ swz(x)) * 16) : OOB;
+    }
+  };
+  auto plane_of = [&](int c) {
+    return (c < a.nchunks0) ? a.in0 + (size_t)(a.in0_plane0 + c) * a.in0_plane_bytes
+                            : a.in1 + (size_t)(a.in1_plane0 + c - a.nchunks0) * a.in1_plane_bytes;
+  };
+  const char* pf_plane = nullptr; const char* pf_w = nullptr; uint32_t pf_tdst = 0; int pf_slot = 0; bool pf_on = false;
+  auto slot_add = [](int s, int k) { const int t = s + k; return t >= NSLOT ? t - NSLOT : t; };
+  // DMA slots idx 0..9: the halo tile first (5), then the chunk's 18 KB of weights (18 pieces over 5 slots)
+  auto dma_op = [&](int idx) {
+    if (!pf_on) return;
+    if (idx < DMA_PER_WAVE) {
+      const int k = wave + NW * idx;
+      if (k < XT_DMA) {
+        const char* src = src_off[idx] != OOB ? pf_plane + src_off[idx] : a.zero_page + (lane & 3) * 16;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(pf_tdst + k * 1024);
+        if (k * 64 + lane < XT_SLOTS) dma16(src, dst);
+      }
+    } else if (idx < NDMA) {
+      const int k = wave + NW * (idx - DMA_PER_WAVE);   // piece 0..17 of the chunk = unit k / 6, piece k % 6
+      if (k < 18) dma16(pf_w + k * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(lds0 + W_OFF + slot_add(pf_slot, k / 6) * WU + (k % 6) * 1024));
+    }
+  };
+  auto slot_of = [](int g, int m) { return (m & 1) ? (g == 0 ? m / 2 : g == 1 && m / 2 < 5 ? 6 + m / 2 : -1) : -1; };
+
+  float* epi_lds = reinterpret_cast<float*>(smem + B_OFF);   // [64 bias][64 slope]
+  if (tid < 64) {
+    const int v = grp * 64 + tid;
+    epi_lds[tid] = v < a.cout_pad ? a.bias[v] : 0.f;
+    epi_lds[64 + tid] = a.act == ACT_PRELU ? (v < a.cout_pad ? a.prelu[v] : 1.f) : (a.act == ACT_LRELU ? a.slope : (a.act == ACT_RELU6 ? 0.f : 1.f));
+  }
+
+  int kt = 0;
+  int tile = tile_of(0);
+  if (tile < 0) return;
+  int n, y0, x0;
+  setup_tile(tile, n, y0, x0);
+  int tb = 0, slot = 0;
+  pf_on = true; pf_plane = plane_of(0); pf_tdst = lds0; pf_w = wbase; pf_slot = 0;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) if (i < NDMA) dma_op(i);
+  dma_wait();
+  __syncthreads();
+  const int lane16 = lane * 16;
+
+  while (true) {
+    f32x16 acc[2][MB];
+    {
+      typedef float f32x4v __attribute__((ext_vector_type(4)));
+      const uint32_t bl = lds0 + B_OFF + lh * 32;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4v b;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b) : "v"(bl), "i"(nb * 128 + 64 * (q >> 1) + 16 * (q & 1)));
+            acc[nb][mb][4 * q] = b.x; acc[nb][mb][4 * q + 1] = b.y; acc[nb][mb][4 * q + 2] = b.z; acc[nb][mb][4 * q + 3] = b.w;
+          }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    const int cur_n = n, cur_y0 = y0, cur_x0 = x0;
+    const int next_tile = tile_of(kt + 1);
+
+#pragma unroll 1
+    for (int c = 0; c < K; ++c) {
+      if (c + 1 < K) { pf_on = true; pf_plane = plane_of(c + 1); pf_w = wbase + (size_t)(c + 1) * (3 * WU); }
+      else if (next_tile >= 0) { setup_tile(next_tile, n, y0, x0); pf_on = true; pf_plane = plane_of(0); pf_w = wbase; }
+      else pf_on = false;
+      pf_tdst = lds0 + (tb ^ 1) * XT_BYTES; pf_slot = slot_add(slot, 3);
+      const char* tbp = smem + tb * XT_BYTES;
+      uint4 wf[3][2], af[3];
+      auto af_load = [&](int t) { return *reinterpret_cast<const uint4*>(tbp + rd_base[t / (MB + 2)] + (t % (MB + 2)) * ROWX); };
+      const char* wbp = smem + W_OFF + slot * WU + lane16;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) wf[dy][nb] = *reinterpret_cast<const uint4*>(wbp + (dy * 2 + nb) * 1024);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) af[t] = af_load(t);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const bool more = g + 1 < 3;
+        const char* wbn = smem + W_OFF + slot_add(slot, g + 1) * WU + lane16;
+        int m = 0;
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ir = 0; ir < MB + 2; ++ir) {
+          const int t = g * (MB + 2) + ir;
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const int mb = ir - dy;
+            if (mb >= 0 && mb < MB) {
+              acc[0][mb] = mma<__half>(wf[dy][0], af[t % 3], acc[0][mb]);
+              acc[1][mb] = mma<__half>(wf[dy][1], af[t % 3], acc[1][mb]);
+              if (slot_of(g, m) >= 0 && slot_of(g, m) < NDMA) {
+                __builtin_amdgcn_sched_barrier(0);
+                dma_op(slot_of(g, m));
+                __builtin_amdgcn_sched_barrier(0);
+              }
+              ++m;
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (t + 3 < 3 * (MB + 2)) af[t % 3] = af_load(t + 3);
+          if (more && ir >= MB - 1) {
+            const int dy = ir - (MB - 1);
+            wf[dy][0] = *reinterpret_cast<const uint4*>(wbn + (dy * 2) * 1024);
+            wf[dy][1] = *reinterpret_cast<const uint4*>(wbn + (dy * 2 + 1) * 1024);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+      }
+      // the next chunk (or the next tile's first chunk: the hand-over happens BEFORE the epilogue, its stores drain under MFMAs)
+      if (pf_on) { dma_wait(); __syncthreads(); }
+      tb ^= 1; slot = slot_add(slot, 3);
+    }
+
+    // ---------------- epilogue (conv_mfma.hip's plain-layout fast path, the same expressions: results are bit-identical) ----------------
+    {
+      const float alpha = a.alpha, gamma = a.gamma;
+      int lhe = lh;
+      asm volatile("" : "+v"(lhe));
+      const int xo = cur_x0 + lr;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int vblock = (grp * 2 + nb) * 32;
+        if (vblock >= a.cout_pad) continue;
+        float slope_v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 s4 = *reinterpret_cast<const float4*>(epi_lds + 64 + nb * 32 + 16 * (q >> 1) + 8 * lhe + 4 * (q & 1));
+          slope_v[4 * q] = s4.x; slope_v[4 * q + 1] = s4.y; slope_v[4 * q + 2] = s4.z; slope_v[4 * q + 3] = s4.w;
+        }
+        const int opl = vblock / CW;
+        const size_t sub = (size_t)lhe * 16;
+        const char* r1p = a.res1 ? a.res1 + (size_t)(a.r1_plane0 + opl) * a.r1_plane_bytes + sub : nullptr;
+        const char* r2p = a.res2 ? a.res2 + (size_t)(a.r2_plane0 + opl) * a.r2_plane_bytes + sub : nullptr;
+        char* outp = a.out + (size_t)(a.out_plane0 + opl) * a.out_plane_bytes + sub;
+        const size_t pix0 = ((size_t)cur_n * a.H + cur_y0 + wave * MB) * a.W + xo;
+        if (!r1p && !r2p) {
+          const bool select_form = a.act == ACT_PRELU;
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            const bool ok = (cur_y0 + wave * MB + mb) < a.H && xo < a.W;
+            float v[16];
+            if (a.act == ACT_RELU6) {
+#pragma unroll
+              for (int i = 0; i < 16; ++i) v[i] = fminf(fmaxf(acc[nb][mb][i], 0.f), 6.f) * alpha;
+            } else if (select_form) {
+#pragma unroll
+              for (int i = 0; i < 16; ++i) { const float t = acc[nb][mb][i], neg = t * slope_v[i]; v[i] = (t >= 0.f ? t : neg) * alpha; }
+            } else {
+#pragma unroll
+              for (int i = 0; i < 16; ++i) {
+                const float t = acc[nb][mb][i], st = t * slope_v[i];
+                float mx;
+                asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(t), "v"(st));   // = fmaxf(t, st) for every non-NaN input, one instruction
+                v[i] = mx * alpha;
+              }
+            }
+            if (ok) {
+              char* o = outp + (pix0 + (size_t)mb * a.W) * REC;
+              store8<__half>(o, v);
+              store8<__half>(o + a.out_plane_bytes, v + 8);
+            }
+          }
+        } else {
+          constexpr int RB = 1;   // 128 accumulator registers leave room for one row of residuals at a time
+#pragma unroll
+          for (int mb0 = 0; mb0 < MB; mb0 += RB) {
+            uint4 r1v[2], r2v[2];
+            const int mb = mb0;
+            const bool ok = (cur_y0 + wave * MB + mb) < a.H && xo < a.W;
+            const size_t rec = (pix0 + (size_t)mb * a.W) * REC;
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+              r1v[hq] = (r1p && ok) ? *reinterpret_cast<const uint4*>(r1p + hq * (size_t)a.r1_plane_bytes + rec) : make_uint4(0, 0, 0, 0);
+              r2v[hq] = (r2p && ok) ? *reinterpret_cast<const uint4*>(r2p + hq * (size_t)a.r2_plane_bytes + rec) : make_uint4(0, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float v[16], r1[16], r2[16];
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+              load8<__half>(reinterpret_cast<const char*>(&r1v[hq]), r1 + 8 * hq);
+              load8<__half>(reinterpret_cast<const char*>(&r2v[hq]), r2 + 8 * hq);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              float t = acc[nb][mb][i];
+              const float neg = t * slope_v[i];
+              t = t >= 0.f ? t : neg;
+              if (a.act == ACT_RELU6) t = fminf(t, 6.f);
+              t = t * alpha + r1[i];
+              v[i] = t * gamma + r2[i];
+            }
+            if (ok) {
+              char* o = outp + rec;
+              store8<__half>(o, v);
+              store8<__half>(o + a.out_plane_bytes, v + 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (next_tile < 0) break;
+    tile = next_tile; ++kt;
+  }
+}
+
+}  // namespace wide
+
+bool conv3x3_wide_eligible(const ConvArgs& a, int dtype) {
+  return dtype == SS4K_F16 && a.epi == EPI_NHWC && !a.bsvd_resid && !a.dbg && a.cout_pad >= 64 && a.cout_pad % 64 == 0 &&
+         (double)a.N * a.H * a.W * 32.0 < 4294967296.0 && (!a.ups2 || (a.H % 2 == 0 && a.W % 2 == 0));
+}
+
+void launch_conv3x3_wide(ss4k_ctx* ctx, const ConvArgs& a0, hipStream_t st) {
+  using namespace wide;
+  ConvArgs a = a0;
+  a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = (a.H + TH - 1) / TH;
+  a.zero_page = ctx->zero_page();
+  const int groups = a.cout_pad / 64;
+  const int ntiles = a.N * a.tiles_y * a.tiles_x;
+  const void* fn = reinterpret_cast<const void*>(&conv3x3_wide_kernel);
+  if (ctx->lds_attr_set.insert(fn).second)
+    SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+  const int gx = std::min(ntiles, std::max(1, (int)(ctx->num_cu * 2 / groups * (a.grid_share > 0.f ? a.grid_share : 1.f))));
+  hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(gx, groups), dim3(64 * NW), LDS_BYTES, st, a);
+  SS4K_HIP(hipGetLastError());
+}
+
 bool conv3x3_dense2_eligible(int nchunks_a, int cout_pad_a, int nchunks_b, int cout_pad_b) {
   return cout_pad_a == 32 && cout_pad_b == 32 && nchunks_b == nchunks_a + 2 && nchunks_a >= 2 && nchunks_a % 2 == 0;
 }

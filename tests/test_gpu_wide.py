@@ -1,0 +1,53 @@
+"""GPU: conv_dense.hip's single-layer build (conv3x3_wide_kernel: 64 couts per workgroup on the fused kernel's machinery) against
+conv_mfma.hip's <__half,2,4,4> build it replaces for fp16 layers with a plain epilogue.  Same tile, same packed fragments, same MFMA
+order per output, the same epilogue expressions: results must be BIT-IDENTICAL - through every epilogue form the networks use
+(LeakyReLU / PReLU / ReLU6 / none, alpha, one and two residuals written in place, several cout groups, concat inputs, nearest-x2
+upsampled input, odd K-chunk counts)."""
+import numpy as np
+import pytest
+import torch
+
+import sharkshark4k_amd  # noqa: F401
+from sharkshark4k_amd import _capi
+from sharkshark4k_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+NO_WIDE, NO_RS, NO_DENSE, ONE, TWO = _capi.MODEL_NO_WIDE, _capi.MODEL_NO_RS, _capi.MODEL_NO_DENSE, _capi.MODEL_ONE_CHAIN, _capi.MODEL_TWO_CHAINS
+
+
+@pytest.mark.parametrize("scale,shape,base", [(2, (1, 3, 144, 208), ONE), (2, (2, 3, 92, 200), TWO), (4, (1, 3, 37, 70), ONE),
+                                              (1, (1, 3, 128, 256), ONE), (4, (3, 3, 9, 33), ONE), (2, (2, 3, 34, 62), NO_DENSE | TWO)])
+def test_wide_bit_identical_rrdbnet(ctx, scale, shape, base):
+    """Trunk / tail layers (incl. both up-sampling convs) and - with conv5 routed off the register-stationary kernel - conv5 of every
+    RDB: residual x 0.2 + x, and (x ... ) x 0.2 + block input written in place over it."""
+    t = W.rrdbnet_table(17, scale=scale, num_block=2)
+    flat = W.flatten(t, W.rrdbnet_keys(2))
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[2] * 7 + shape[3])).cuda()
+    for extra in (0, NO_RS):
+        want = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=2, flags=base | extra | NO_WIDE), flat)(x).clone()
+        m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=2, flags=base | extra), flat)
+        for _ in range(2):
+            got = m(x)
+            assert torch.isfinite(got).all() and torch.equal(got, want), f"{shape} flags {base | extra}: max |d| {float((got - want).abs().max()):.3g}"
+
+
+@pytest.mark.parametrize("nf,shape,up", [(64, (2, 3, 72, 130), 4), (64, (1, 3, 33, 47), 2), (128, (1, 3, 40, 64), 2)])
+def test_wide_bit_identical_srvgg(ctx, nf, shape, up):
+    """SRVGG body: PReLU slopes per channel (select form); 128 features = two cout groups per layer."""
+    t = W.dni_blend(W.srvgg_table(3, num_feat=nf, num_conv=4, upscale=up), W.srvgg_table(4, num_feat=nf, num_conv=4, upscale=up), 0.5)
+    flat = W.flatten(t, W.srvgg_keys(4))
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(nf + shape[3])).cuda()
+    outs = [_capi.Model(ctx, _capi.make_desc(_capi.SRVGG, _capi.F16, scale=up, num_feat=nf, num_block=4, flags=fl), flat)(x).clone()
+            for fl in (NO_WIDE, 0)]
+    assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("chns,shape", [((32, 64, 128), (2, 4, 64, 96)), ((64, 128, 256), (1, 4, 48, 80))])
+def test_wide_bit_identical_bsvd(ctx, chns, shape):
+    """BSVD's half- and quarter-resolution layers: ReLU6, inputs that start at a later plane (the F = 1 BiBufferConv skips its dead
+    planes), 128 / 256 couts = several cout groups."""
+    t = W.bsvd_table(5, chns=chns)
+    flat = W.flatten(t, W.bsvd_keys(chns=chns))
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[2])).cuda()
+    outs = [_capi.Model(ctx, _capi.make_desc(_capi.BSVD, _capi.F16, scale=1, bsvd_chns=chns, flags=fl), flat)(x).clone() for fl in (NO_WIDE, 0)]
+    assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
