@@ -1,4 +1,5 @@
-"""Dev tool: determinism soak of the round-3 kernels - BSVD with the fused layer pairs, FSRCNN in fp16 mode, SRVGG with the fp16
+"""Dev tool: determinism soak of the round-3 / round-4 kernels - RRDBNet with the fused dense-block pairs and the single-layer wide
+kernel (round 4), BSVD with the fused layer pairs, FSRCNN in fp16 mode, SRVGG with the fp16
 HR tensor, the RRDBNet chain kernel - each job repeated N times on ragged and full sizes; every repeat must reproduce the
 first output bit for bit (a hand-off or LDS-DMA race shows up as a differing frame).  usage: python tools/soak.py [repeats=200]"""
 import os, sys, time
@@ -23,6 +24,10 @@ for shape in ((12, 1, 720, 1280), (3, 1, 97, 130)):
 rr = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=4, flags=_capi.MODEL_CHAIN),
                  W.flatten(W.rrdbnet_table(5, scale=2, num_block=4), W.rrdbnet_keys(4)))
 jobs.append(("rrdbnet chain (1, 3, 360, 500)", rr, torch.rand(1, 3, 360, 500, generator=g).cuda()))
+# round 4: the default route (fused pairs + wide kernel + register-stationary conv5), two launch chains and one, ragged and full size
+rd = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=6), W.flatten(W.rrdbnet_table(6, scale=2, num_block=6), W.rrdbnet_keys(6)))
+for shape in ((4, 3, 720, 1280), (1, 3, 720, 1280), (3, 3, 250, 330), (2, 3, 70, 66)):
+    jobs.append((f"rrdbnet fused pairs {shape}", rd, torch.rand(*shape, generator=g).cuda()))
 sv = factory.build_model_esrgan(ctx, "realesr-general-x4v3", weights="synthetic", dtype="f16", seed=3)
 up = _capi.Upscaler(ctx, sv, (180, 320), (360, 640), True, False, None, 0.5)
 fr = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (4, 180, 320, 3), dtype=np.uint8)).cuda()
