@@ -1,13 +1,13 @@
 """Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/<round>_conv3x3_pmc_traffic.json.
 usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> <frames_per_launch> <steps_run> <frames_per_step>
 Counts the dispatches of the 3x3 conv kernels (conv3x3_kernel = LDS weights, conv3x3_rs_kernel = register-stationary weights,
-conv3x3_dense2_kernel = fused dense-block layer pairs) - the same launches bench.py's roofline leg times; FETCH_SIZE is doubled per
+conv3x3_dense2_kernel = fused dense-block layer pairs, conv3x3_wide_kernel = one 64-cout layer on the fused kernel's machinery) - the same launches bench.py's roofline leg times; FETCH_SIZE is doubled per
 MI355X_MICROARCH.md (HBM section).  The figure bench.py uses is bytes per STEP (all conv launches of a step together): the
 kernels differ too much for a per-launch average to mean anything."""
 import csv, glob, json, sys
 from collections import defaultdict
 
-FAMILIES = ("conv3x3_rs_kernel", "conv3x3_dense2_kernel", "conv3x3_kernel")
+FAMILIES = ("conv3x3_rs_kernel", "conv3x3_dense2_kernel", "conv3x3_wide_kernel", "conv3x3_kernel")
 
 
 def per_dispatch(d, counter):
@@ -36,7 +36,7 @@ for fam in FAMILIES:
 out = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps %d --warmup 1 "
               "--no-cpu-baseline --no-roofline --no-also (RRDBNet x2 720p fp16, %d frames per step, %d per launch: SS4K_LANES=2), "
-              "every launch of the three 3x3 conv kernels" % (steps - 1, fps, n),
+              "every launch of the 3x3 conv kernels" % (steps - 1, fps, n),
     "launches_counted": len(fetch_d), "steps": steps, "frames_per_step": fps, "frames_per_launch": n,
     "correction": "FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as is; KB x1024",
     "traffic_bytes_per_step": total / steps,
