@@ -1,0 +1,36 @@
+"""Dev tool: random-shape fuzz of the round-4 routes - RRDBNet on the default route (fused dense-block pairs + single-layer wide
+kernel) against SS4K_MODEL_NO_DENSE | NO_WIDE (one launch per layer on conv_mfma.hip), which must agree BIT FOR BIT; both under
+one and two launch chains.  usage: python tools/fuzz_routes.py [cases=150] [seed=0]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import sharkshark4k_amd  # noqa
+from sharkshark4k_amd import _capi, weights as W
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+ctx = _capi.Context(0)
+models = {}
+def model(scale, flags):
+    k = (scale, flags)
+    if k not in models:
+        t = W.rrdbnet_table(40 + scale, scale=scale, num_block=1)
+        models[k] = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=1, flags=flags), W.flatten(t, W.rrdbnet_keys(1)))
+    return models[k]
+bad = 0
+for i in range(cases):
+    scale = int(rng.choice([1, 2, 4]))
+    r = {1: 4, 2: 2, 4: 1}[scale]
+    n = int(rng.integers(1, 5))
+    gh, gw = int(rng.integers(1, 70)), int(rng.integers(1, 140))   # interior grid (what the fused kernels see)
+    if rng.random() < 0.3: gh = int(rng.choice([15, 16, 17, 31, 32, 33, 48]))
+    if rng.random() < 0.3: gw = int(rng.choice([30, 31, 32, 33, 34, 63, 64, 65, 96]))
+    lanes = _capi.MODEL_TWO_CHAINS if (n % 2 == 0 and rng.random() < 0.5) else _capi.MODEL_ONE_CHAIN
+    x = torch.rand(n, 3, gh * r, gw * r, generator=torch.Generator().manual_seed(i)).cuda()
+    want = model(scale, lanes | _capi.MODEL_NO_DENSE | _capi.MODEL_NO_WIDE)(x).clone()
+    got = model(scale, lanes)(x)
+    ok = bool(torch.isfinite(got).all()) and torch.equal(got, want)
+    if not ok:
+        bad += 1
+        print(f"case {i}: scale {scale} n {n} grid {gh}x{gw} lanes {lanes}: MISMATCH max |d| {float((got - want).abs().max()):.3g}", flush=True)
+print(f"{cases} cases, {bad} mismatching:", "FUZZ FAILED" if bad else "FUZZ OK")
