@@ -122,6 +122,8 @@ class HipUpscalerService(BaseUpscalerService):
             prof = getattr(self, "profiler", None)
             up = self._get_upscaler()
             out = up(frames)
+            if getattr(self, "model_flags", 0) & 128:   # SS4K_MODEL_CHAIN: its one asynchronous failure mode (a work unit timed out)
+                self.model.check(wait=False)              # is reported here at the latest one job later; never blocks (include/ss4k.h)
             if prof is not None:
                 # the reference's span keys (fsrcnn_upscaler.py:276-278,290-300): host time around the
                 # asynchronous stage launches, measured inside the library
