@@ -102,7 +102,11 @@ enum {
                                    the default policy sets it) */
   SS4K_MODEL_NO_WIDE = 4096,    /* fp16 layers with 64-cout groups and a plain epilogue (RRDBNet trunk / tail, SRVGG body, BSVD) on
                                    conv_mfma.hip's <2,4,4> build instead of conv_dense.hip's single-layer build; bit-identical results */
-  SS4K_MODEL_FLAGS_ALL = 8191
+  SS4K_MODEL_NO_UPS_PRESUM = 8192, /* RRDBNet fp16: conv_up1 / conv_up2 (3x3 convs on a nearest-x2 up-sampled tensor) in the direct form.
+                                   Default: two of the three input rows an output row reads are the same low-resolution row, so their two
+                                   MFMAs per tap column run as one with the weight fragments added in fp16 (6 instead of 9 MFMAs per
+                                   pixel).  The only routing bit that is NOT bit-identical: one more fp16 rounding of a weight sum */
+  SS4K_MODEL_FLAGS_ALL = 16383
 };
 
 int ss4k_abi_version(void);

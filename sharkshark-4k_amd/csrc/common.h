@@ -150,6 +150,7 @@ struct ConvArgs {
   int wide;                             // 64-cout-group layers with a plain epilogue on conv_dense.hip's single-layer build (conv3x3_wide_kernel)
   int no_band;                          // dev experiment: tiles dealt round-robin over the workgroups instead of one contiguous band per XCD
   int ups2;                             // input is the nearest-x2 upsampling of an (H/2, W/2) tensor
+  int ups_presum;                       // ... and the wide kernel may add the weight fragments of the two taps that read the same input row
   const void* wpk;                      // packed weights [group][chunk][dx,ks][dy][nb][lane][E]
   const void* wrs;                      // conv_rs.hip layout [group][cout group][chunk32][tap][cb][lane][8] or null
   int rs_wide;                          // wrs is packed for the eight-wave variant of the shape

@@ -464,6 +464,12 @@ constexpr int W_OFF = 2 * XT_BYTES, B_OFF = W_OFF + NSLOT * WU;
 constexpr size_t LDS_BYTES = B_OFF + 2 * 64 * 4;    // + bias and slope of the group's 64 couts
 static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 
+// UPS: the input is the nearest-x2 up-sampling of a half-resolution tensor (RRDBNet's conv_up1 / conv_up2) and the layer asked for the
+// pre-summed form.  Two of the three input rows an output row reads are then the SAME low-resolution row (rows y, y + 1 for an even y;
+// y - 1, y for an odd one): their two MFMAs per tap column become one with the two weight fragments added (fp16, four v_pk_add_f16 per
+// fragment and tap column) - 6 instead of 9 MFMAs per output pixel and K-chunk.  Not bit-identical to the direct form (one more fp16
+// rounding of a weight sum, a different order of fp32 additions); SS4K_MODEL_NO_UPS_PRESUM selects the direct form.
+template <bool UPS>
 __global__ __launch_bounds__(64 * NW, 2) void conv3x3_wide_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -529,7 +535,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_wide_kernel(const ConvArgs
       if (k < 18) dma16(pf_w + k * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(lds0 + W_OFF + slot_add(pf_slot, k / 6) * WU + (k % 6) * 1024));
     }
   };
-  auto slot_of = [](int g, int m) { return (m & 1) ? (g == 0 ? m / 2 : g == 1 && m / 2 < 5 ? 6 + m / 2 : -1) : -1; };
+  // DMA slot after MFMA pair m of tap column g (12 pairs per column; UPS: 8, and a slot after every pair)
+  auto slot_of = [](int g, int m) {
+    if (UPS) return g == 0 ? m : g == 1 ? 8 + m : -1;
+    return (m & 1) ? (g == 0 ? m / 2 : g == 1 && m / 2 < 5 ? 6 + m / 2 : -1) : -1;
+  };
 
   float* epi_lds = reinterpret_cast<float*>(smem + B_OFF);   // [64 bias][64 slope]
   if (tid < 64) {
@@ -594,15 +604,34 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_wide_kernel(const ConvArgs
         int m = 0;
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
+        // UPS: the summed fragments of this tap column (this wave's rows start at an even output row: tile rows and 4w are even)
+        uint4 ws01[2], ws12[2];
+        if constexpr (UPS) {
+          typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+          auto addh = [](const uint4& p, const uint4& q) {
+            uint4 r;
+            const uint32_t* pp = &p.x; const uint32_t* qq = &q.x; uint32_t* rr = &r.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rr[k] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, pp[k]) + __builtin_bit_cast(h2, qq[k]));
+            return r;
+          };
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) { ws01[nb] = addh(wf[0][nb], wf[1][nb]); ws12[nb] = addh(wf[1][nb], wf[2][nb]); }
+        }
 #pragma unroll
         for (int ir = 0; ir < MB + 2; ++ir) {
           const int t = g * (MB + 2) + ir;
 #pragma unroll
           for (int dy = 0; dy < 3; ++dy) {
             const int mb = ir - dy;
-            if (mb >= 0 && mb < MB) {
-              acc[0][mb] = mma<__half>(wf[dy][0], af[t % 3], acc[0][mb]);
-              acc[1][mb] = mma<__half>(wf[dy][1], af[t % 3], acc[1][mb]);
+            // UPS, even output row: rows (y - 1) and (y, y + 1 summed): dy 0 plain, dy 1 with w1 + w2, dy 2 skipped;
+            //      odd output row:  (y - 1, y summed) and y + 1:        dy 0 with w0 + w1, dy 1 skipped, dy 2 plain
+            const bool skip = UPS && ((mb & 1) ? dy == 1 : dy == 2);
+            if (mb >= 0 && mb < MB && !skip) {
+              const uint4& w0 = !UPS ? wf[dy][0] : (mb & 1) ? (dy == 0 ? ws01[0] : wf[2][0]) : (dy == 0 ? wf[0][0] : ws12[0]);
+              const uint4& w1 = !UPS ? wf[dy][1] : (mb & 1) ? (dy == 0 ? ws01[1] : wf[2][1]) : (dy == 0 ? wf[0][1] : ws12[1]);
+              acc[0][mb] = mma<__half>(w0, af[t % 3], acc[0][mb]);
+              acc[1][mb] = mma<__half>(w1, af[t % 3], acc[1][mb]);
               if (slot_of(g, m) >= 0 && slot_of(g, m) < NDMA) {
                 __builtin_amdgcn_sched_barrier(0);
                 dma_op(slot_of(g, m));
@@ -735,11 +764,14 @@ void launch_conv3x3_wide(ss4k_ctx* ctx, const ConvArgs& a0, hipStream_t st) {
   a.zero_page = ctx->zero_page();
   const int groups = a.cout_pad / 64;
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
-  const void* fn = reinterpret_cast<const void*>(&conv3x3_wide_kernel);
-  if (ctx->lds_attr_set.insert(fn).second)
-    SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
   const int gx = std::min(ntiles, std::max(1, (int)(ctx->num_cu * 2 / groups * (a.grid_share > 0.f ? a.grid_share : 1.f))));
-  hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(gx, groups), dim3(64 * NW), LDS_BYTES, st, a);
+  auto go = [&](auto kern) {
+    const void* fn = reinterpret_cast<const void*>(kern);
+    if (ctx->lds_attr_set.insert(fn).second)
+      SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(gx, groups), dim3(64 * NW), LDS_BYTES, st, a);
+  };
+  if (a.ups2 && a.ups_presum) go(&conv3x3_wide_kernel<true>); else go(&conv3x3_wide_kernel<false>);
   SS4K_HIP(hipGetLastError());
 }
 

@@ -198,6 +198,7 @@ void Model::build(const float* w, size_t n) {
   if (fl & SS4K_MODEL_DENSE) dense_mode = 2;
   if (fl & SS4K_MODEL_HR_F32) hr_f32 = true;
   if (fl & SS4K_MODEL_NO_WIDE) use_wide = false;
+  if (fl & SS4K_MODEL_NO_UPS_PRESUM) ups_presum = false;
   if (!(fl & (SS4K_MODEL_ONE_CHAIN | SS4K_MODEL_TWO_CHAINS)))
     if (const char* e = std::getenv("SS4K_LANES")) lanes_mode = std::max(0, std::min(2, std::atoi(e)));
   if (const char* e = std::getenv("SS4K_FS_EXACT")) fs_exact = fs_exact || e[0] == '1';
@@ -210,6 +211,7 @@ void Model::build(const float* w, size_t n) {
   if (const char* e = std::getenv("SS4K_MB")) mb_override = std::atoi(e);
   if (const char* e = std::getenv("SS4K_S3")) use_s3 = e[0] == '1';
   if (const char* e = std::getenv("SS4K_DENSE_MASK")) dense_mask = std::atoi(e);   // A/B switch: which layer pairs of an RDB run fused
+  if (const char* e = std::getenv("SS4K_UPS_PRESUM")) ups_presum = e[0] == '1';   // A/B switch: pre-summed weights in the up-sampling convs
   if (const char* e = std::getenv("SS4K_WIDE")) use_wide = e[0] == '1';            // A/B switch: 64-cout layers on conv3x3_wide_kernel
   if (const char* e = std::getenv("SS4K_DENSE_MODE")) dense_mode = std::atoi(e);   // A/B switch: 0 default policy, 1 never, 2 every job
   if (const char* e = std::getenv("SS4K_LANE_GRID")) lane_grid_share = (float)std::atof(e);   // A/B switch: grid of a lane's launch as a share of the chip's slots
@@ -313,7 +315,7 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
   a.bsvd_resid = o.bsvd_resid;
   a.epi = o.epi; a.out = o.out.p; a.out_plane_bytes = o.out.plane_bytes; a.out_plane0 = o.out.plane0;
   a.cout_real = L.cout_real; a.cout_pad = L.cout_pad;
-  a.dbg = dbg; a.dbg_buf = dbg_buf; a.mb_override = mb_override; a.s3 = use_s3 ? 1 : 0; a.wide = use_wide ? 1 : 0;
+  a.dbg = dbg; a.dbg_buf = dbg_buf; a.mb_override = mb_override; a.s3 = use_s3 ? 1 : 0; a.wide = use_wide ? 1 : 0; a.ups_presum = ups_presum ? 1 : 0;
 #ifdef SS4K_DEV
   static const bool no_band = std::getenv("SS4K_NO_BAND") && std::getenv("SS4K_NO_BAND")[0] == '1';
   a.no_band = no_band ? 1 : 0;

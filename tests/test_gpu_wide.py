@@ -13,6 +13,7 @@ from sharkshark4k_amd import weights as W
 
 pytestmark = pytest.mark.gpu
 NO_WIDE, NO_RS, NO_DENSE, ONE, TWO = _capi.MODEL_NO_WIDE, _capi.MODEL_NO_RS, _capi.MODEL_NO_DENSE, _capi.MODEL_ONE_CHAIN, _capi.MODEL_TWO_CHAINS
+DIRECT_UPS = _capi.MODEL_NO_UPS_PRESUM   # the pre-summed up-sampling convs are the one route that is not bit-identical: pinned off here
 
 
 @pytest.mark.parametrize("scale,shape,base", [(2, (1, 3, 144, 208), ONE), (2, (2, 3, 92, 200), TWO), (4, (1, 3, 37, 70), ONE),
@@ -23,7 +24,7 @@ def test_wide_bit_identical_rrdbnet(ctx, scale, shape, base):
     t = W.rrdbnet_table(17, scale=scale, num_block=2)
     flat = W.flatten(t, W.rrdbnet_keys(2))
     x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[2] * 7 + shape[3])).cuda()
-    for extra in (0, NO_RS):
+    for extra in (DIRECT_UPS, DIRECT_UPS | NO_RS):
         want = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=2, flags=base | extra | NO_WIDE), flat)(x).clone()
         m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=2, flags=base | extra), flat)
         for _ in range(2):
@@ -51,3 +52,25 @@ def test_wide_bit_identical_bsvd(ctx, chns, shape):
     x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[2])).cuda()
     outs = [_capi.Model(ctx, _capi.make_desc(_capi.BSVD, _capi.F16, scale=1, bsvd_chns=chns, flags=fl), flat)(x).clone() for fl in (NO_WIDE, 0)]
     assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("scale,shape", [(2, (2, 3, 96, 136)), (4, (1, 3, 45, 67)), (2, (1, 3, 62, 30))])
+def test_ups_presum_vs_direct_and_oracle(ctx, scale, shape):
+    """conv_up1 / conv_up2 in the pre-summed form (two taps that read the same low-resolution row share one MFMA, their weight
+    fragments added in fp16) against the direct form and against the CPU oracle: the two forms agree far inside the fp16 path's own
+    error, and the pre-summed one is as close to the oracle as the direct one (odd / ragged output sizes, image borders: zero padding
+    of the UP-SAMPLED image, which the pre-summed rows must reproduce)."""
+    from oracle import nets as onets
+    from tests.helpers import psnr
+    t = W.rrdbnet_table(29, scale=scale, num_block=1)
+    flat = W.flatten(t, W.rrdbnet_keys(1))
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[3]))
+    with torch.no_grad():
+        want = onets.rrdbnet(x, t, scale, 1)
+    direct = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=1, flags=DIRECT_UPS), flat)(x.cuda()).cpu()
+    presum = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=1), flat)(x.cuda()).cpu()
+    peak = float(want.abs().max())
+    p_forms, p_direct, p_presum = psnr(presum / peak, direct / peak), psnr(direct / peak, want / peak), psnr(presum / peak, want / peak)
+    print(f"x{scale} {shape}: presum vs direct {p_forms:.1f} dB; vs oracle: direct {p_direct:.1f} dB, presum {p_presum:.1f} dB")
+    assert not torch.equal(presum, direct)           # the flag does select another form
+    assert p_forms > 66.0 and p_presum > p_direct - 1.0
