@@ -106,7 +106,12 @@ enum {
                                    Default: two of the three input rows an output row reads are the same low-resolution row, so their two
                                    MFMAs per tap column run as one with the weight fragments added in fp16 (6 instead of 9 MFMAs per
                                    pixel).  The only routing bit that is NOT bit-identical: one more fp16 rounding of a weight sum */
-  SS4K_MODEL_FLAGS_ALL = 16383
+  SS4K_MODEL_CONV5_RS = 16384,  /* RRDBNet fp16: conv5 of every RDB on the register-stationary kernel for every job size.  Default: jobs with
+                                   fewer than three rounds of 16 x 32 tiles per 256 workgroup slots (one 720p frame) take conv_dense.hip's
+                                   single-layer build with the residual through the matrix core (+ 4.5 % on one-frame jobs).  The two
+                                   kernels add in a different order: with this bit a frame's bits do not depend on the size of the job
+                                   it arrived in; without it they are the same for every job of one shape */
+  SS4K_MODEL_FLAGS_ALL = 32767
 };
 
 int ss4k_abi_version(void);

@@ -147,6 +147,7 @@ struct ConvArgs {
   float grid_share;                     // size the persistent grid for this share of the chip's workgroup slots (0 = all)
   int mb_override;                      // 0: tile height of the 32-cout layers by image height; 4 / 5: rows per wave forced (A/B)
   int s3;                               // 32-cout layers without residuals on the three-stage kernel (conv_s3.hip)
+  int wide_rl;                          // ... and a residual that is the layer's own input may go through the matrix core there (conv5 of an RDB)
   int wide;                             // 64-cout-group layers with a plain epilogue on conv_dense.hip's single-layer build (conv3x3_wide_kernel)
   int no_band;                          // dev experiment: tiles dealt round-robin over the workgroups instead of one contiguous band per XCD
   int ups2;                             // input is the nearest-x2 upsampling of an (H/2, W/2) tensor

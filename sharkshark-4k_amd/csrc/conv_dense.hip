@@ -469,7 +469,11 @@ static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 // y - 1, y for an odd one): their two MFMAs per tap column become one with the two weight fragments added (fp16, four v_pk_add_f16 per
 // fragment and tap column) - 6 instead of 9 MFMAs per output pixel and K-chunk.  Not bit-identical to the direct form (one more fp16
 // rounding of a weight sum, a different order of fp32 additions); SS4K_MODEL_NO_UPS_PRESUM selects the direct form.
-template <bool UPS>
+// RL: res1 is the layer's own input tensor and the first four K-chunks are its planes (conv5 of an RDB: out = conv * alpha + x, no
+// activation): x's centre pixels are in LDS as part of those chunks, so they are added to the accumulators there - one more MFMA per
+// output row and chunk with a (1 / alpha) * I fragment on the centre tap, as conv_rs.hip does - instead of being read from memory a
+// second time in the epilogue (measured on the layer in isolation: 225 -> 210 us per 4 frames, tools/conv5_routes.py).
+template <bool UPS, bool RL = false>
 __global__ __launch_bounds__(64 * NW, 2) void conv3x3_wide_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -560,6 +564,19 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_wide_kernel(const ConvArgs
   dma_wait();
   __syncthreads();
   const int lane16 = lane * 16;
+  // RL: A fragments of (1 / alpha) * I for the two planes of a 32-cout block.  MFMA row rho of a block is virtual cout
+  // v(rho) = 16 (rho >> 4) + 8 ((rho >> 2) & 1) + (rho & 3) + 4 ((rho >> 3) & 1) (pack.cpp); this lane holds k = 8 lh .. 8 lh + 7
+  uint4 iid[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+  if constexpr (RL) {
+    const int rho = lane & 31, v = 16 * (rho >> 4) + 8 * ((rho >> 2) & 1) + (rho & 3) + 4 * ((rho >> 3) & 1);
+    const unsigned hv = (unsigned)__half_as_ushort(__float2half(1.f / a.alpha));
+    auto frag = [&](int p) {
+      const int e = v - 16 * p - 8 * lh;   // element of this lane's 8 k-values that meets row rho on plane p, if any
+      const uint32_t w = hv << (16 * (e & 1));
+      return make_uint4((e >> 1) == 0 ? w : 0u, (e >> 1) == 1 ? w : 0u, (e >> 1) == 2 ? w : 0u, (e >> 1) == 3 ? w : 0u);
+    };
+    iid[0] = frag(0); iid[1] = frag(1);
+  }
 
   while (true) {
     f32x16 acc[2][MB];
@@ -632,6 +649,15 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_wide_kernel(const ConvArgs
               const uint4& w1 = !UPS ? wf[dy][1] : (mb & 1) ? (dy == 0 ? ws01[1] : wf[2][1]) : (dy == 0 ? wf[0][1] : ws12[1]);
               acc[0][mb] = mma<__half>(w0, af[t % 3], acc[0][mb]);
               acc[1][mb] = mma<__half>(w1, af[t % 3], acc[1][mb]);
+              if constexpr (RL) {
+                if (g == 1 && dy == 1 && c < 4) {   // centre tap of an x chunk: + x / alpha on the block that holds this plane's couts
+                  const uint32_t pm = (c & 1) ? 0xFFFFFFFFu : 0u;   // plane 1 or plane 0 of the block (wave-uniform)
+                  const uint4 idf = make_uint4((iid[1].x & pm) | (iid[0].x & ~pm), (iid[1].y & pm) | (iid[0].y & ~pm),
+                                               (iid[1].z & pm) | (iid[0].z & ~pm), (iid[1].w & pm) | (iid[0].w & ~pm));
+                  if (c < 2) acc[0][mb] = mma<__half>(idf, af[t % 3], acc[0][mb]);
+                  else acc[1][mb] = mma<__half>(idf, af[t % 3], acc[1][mb]);
+                }
+              }
               if (slot_of(g, m) >= 0 && slot_of(g, m) < NDMA) {
                 __builtin_amdgcn_sched_barrier(0);
                 dma_op(slot_of(g, m));
@@ -674,7 +700,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_wide_kernel(const ConvArgs
         }
         const int opl = vblock / CW;
         const size_t sub = (size_t)lhe * 16;
-        const char* r1p = a.res1 ? a.res1 + (size_t)(a.r1_plane0 + opl) * a.r1_plane_bytes + sub : nullptr;
+        const char* r1p = (a.res1 && !RL) ? a.res1 + (size_t)(a.r1_plane0 + opl) * a.r1_plane_bytes + sub : nullptr;
         const char* r2p = a.res2 ? a.res2 + (size_t)(a.r2_plane0 + opl) * a.r2_plane_bytes + sub : nullptr;
         char* outp = a.out + (size_t)(a.out_plane0 + opl) * a.out_plane_bytes + sub;
         const size_t pix0 = ((size_t)cur_n * a.H + cur_y0 + wave * MB) * a.W + xo;
@@ -771,7 +797,13 @@ void launch_conv3x3_wide(ss4k_ctx* ctx, const ConvArgs& a0, hipStream_t st) {
       SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(gx, groups), dim3(64 * NW), LDS_BYTES, st, a);
   };
-  if (a.ups2 && a.ups_presum) go(&conv3x3_wide_kernel<true>); else go(&conv3x3_wide_kernel<false>);
+  // conv5 of an RDB with its residual through the matrix core (RL): res1 must be the conv's own input tensor = its first four planes
+  const bool rl = a.wide_rl && a.res1 && a.act == ACT_NONE && a.alpha != 0.f && a.nchunks0 == 4 && a.cout_pad == 64 && !a.ups2 &&
+                  a.res1 + (size_t)a.r1_plane0 * a.r1_plane_bytes == a.in0 + (size_t)a.in0_plane0 * a.in0_plane_bytes &&
+                  a.r1_plane_bytes == a.in0_plane_bytes;
+  if (rl) go(&conv3x3_wide_kernel<false, true>);
+  else if (a.ups2 && a.ups_presum) go(&conv3x3_wide_kernel<true>);
+  else go(&conv3x3_wide_kernel<false>);
   SS4K_HIP(hipGetLastError());
 }
 

@@ -118,9 +118,15 @@ def test_config2_rrdbnet_x2_720p_fp16_service_vs_oracle(ctx):
     # measured 57.5 dB / 1 LSB (profiles/r0N_parity_measured.json): asserted at measured - 2 dB / + 1 LSB like configs[3] / [4]
     assert p >= 55.5, f"PSNR {p:.2f} dB"
     assert int(d.max()) <= 2, f"max |delta| {int(d.max())} LSB"
-    # a 4-frame job gives every frame the same result as a 1-frame job (frames are independent)
+    # frames are independent: a 4-frame job gives every frame the result of a 1-frame job - within 1 LSB on the default route
+    # (conv5 runs on another kernel for one-frame jobs: another order of fp32 additions), bit for bit with SS4K_MODEL_CONV5_RS
     four = torch.cat([frames, torch.from_numpy(smooth_u8(124, (3, 720, 1280, 3)))]).cuda()
-    assert torch.equal(up(four)[0].cpu(), got[0])
+    d4 = (up(four)[0].cpu().int() - got[0].int()).abs()
+    # measured: 1 LSB in 6.2 % of the bytes (against the fp32 oracle the fp16 path itself differs in 11.6 %)
+    assert int(d4.max()) <= 1 and float((d4 > 0).float().mean()) < 0.09, (int(d4.max()), float((d4 > 0).float().mean()))
+    sr_p = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, flags=_capi.MODEL_CONV5_RS), W.flatten(table, W.rrdbnet_keys(23)))
+    up_p = _capi.Upscaler(ctx, sr_p, (720, 1280), None, True, False, None, 1.0)
+    assert torch.equal(up_p(four)[0].cpu(), up_p(frames.cuda())[0].cpu())
 
 
 # ------------------------------------------------------------------------------ (c) configs[3]: BSVD + RRDBNet, per-frame path

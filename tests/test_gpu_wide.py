@@ -24,7 +24,8 @@ def test_wide_bit_identical_rrdbnet(ctx, scale, shape, base):
     t = W.rrdbnet_table(17, scale=scale, num_block=2)
     flat = W.flatten(t, W.rrdbnet_keys(2))
     x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[2] * 7 + shape[3])).cuda()
-    for extra in (DIRECT_UPS, DIRECT_UPS | NO_RS):
+    # (conv5 pinned to the register-stationary kernel, or routed off it with its residual read from memory: the two forms that exist on both sides)
+    for extra in (DIRECT_UPS | _capi.MODEL_CONV5_RS, DIRECT_UPS | NO_RS):
         want = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=2, flags=base | extra | NO_WIDE), flat)(x).clone()
         m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=2, flags=base | extra), flat)
         for _ in range(2):
@@ -74,3 +75,23 @@ def test_ups_presum_vs_direct_and_oracle(ctx, scale, shape):
     print(f"x{scale} {shape}: presum vs direct {p_forms:.1f} dB; vs oracle: direct {p_direct:.1f} dB, presum {p_presum:.1f} dB")
     assert not torch.equal(presum, direct)           # the flag does select another form
     assert p_forms > 66.0 and p_presum > p_direct - 1.0
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 144, 208), (2, 3, 66, 94)])
+def test_conv5_small_job_route_vs_pinned_and_oracle(ctx, shape):
+    """Jobs with fewer than three rounds of tiles run conv5 of every RDB on the wide kernel with its residual through the matrix core
+    ((conv + x / alpha) * alpha; default) instead of the register-stationary kernel (SS4K_MODEL_CONV5_RS): another order of fp32
+    additions, the same accuracy against the oracle; every RDB (one residual, and two with the block's input written in place)."""
+    from oracle import nets as onets
+    from tests.helpers import psnr
+    t = W.rrdbnet_table(33, scale=2, num_block=3)
+    flat = W.flatten(t, W.rrdbnet_keys(3))
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[3]))
+    with torch.no_grad():
+        want = onets.rrdbnet(x, t, 2, 3)
+    small = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=3), flat)(x.cuda()).cpu()
+    pinned = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=3, flags=_capi.MODEL_CONV5_RS), flat)(x.cuda()).cpu()
+    peak = float(want.abs().max())
+    p_routes, p_small, p_pinned = psnr(small / peak, pinned / peak), psnr(small / peak, want / peak), psnr(pinned / peak, want / peak)
+    print(f"{shape}: routes {p_routes:.1f} dB apart; vs oracle: wide + matrix-core residual {p_small:.2f} dB, register-stationary {p_pinned:.2f} dB")
+    assert not torch.equal(small, pinned) and p_routes > 70.0 and abs(p_small - p_pinned) < 0.5
