@@ -620,7 +620,7 @@ int Model::tune_step(std::map<std::tuple<int, int, int>, LaneTune>& tab, int n, 
 
 void Model::lanes_begin(int n, int h, int w, hipStream_t st) {
   cur_lanes = 1; cur_n = n; forked = false; tune_timed = nullptr;
-  if (plan_only || lanes_mode == 1 || n % 2 != 0 || desc.dtype != SS4K_F16 || dbg) return;
+  if (plan_only || lanes_mode == 1 || n < 2 || desc.dtype != SS4K_F16 || dbg) return;   // (an odd job splits 1 : 2, 2 : 3, ...)
   if (lanes_mode == 2) { cur_lanes = 2; return; }
   cur_lanes = tune_step(lane_tune, n, h, w, st);
 }

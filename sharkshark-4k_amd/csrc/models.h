@@ -57,7 +57,7 @@ struct Model {
   bool can_half_out() const {
     return (desc.kind == SS4K_SRVGG || (desc.kind == SS4K_FSRCNN && !fs_exact)) && desc.dtype == SS4K_F16 && !plan_only && !hr_f32;
   }
-  // frame lanes: the frames of a job are independent, so an even batch can go through the conv layers as TWO concurrent
+  // frame lanes: the frames of a job are independent, so a batch of two or more frames can go through the conv layers as TWO concurrent
   // launch chains - lane 0 on the caller's stream, lane 1 on the context's lane stream, each working on its own half of
   // the frames of the same tensors, every launch still sized for the whole chip.  The hardware dispatcher then fills any
   // CU one chain leaves free (launch boundary, prologue, the partly filled last round of tiles) with waiting workgroups

@@ -277,9 +277,11 @@ def test_rrdbnet_fp16_full_gain_weights(ctx):
 
 
 # ------------------------------------------------------------------------------ frame lanes (two concurrent launch chains)
+@pytest.mark.parametrize("n", [4, 3, 5, 2])
 @pytest.mark.parametrize("kind", ["rrdbnet", "bsvd", "srvgg"])
-def test_frame_lanes_bit_identical(ctx, monkeypatch, kind):
-    """An even fp16 batch may go through the conv layers as two concurrent launch chains (csrc/models.h, frame lanes).
+def test_frame_lanes_bit_identical(ctx, monkeypatch, kind, n):
+    """An fp16 batch of two or more frames may go through the conv layers as two concurrent launch chains (csrc/models.h,
+    frame lanes); an odd batch splits unevenly (3 = 1 + 2, 5 = 2 + 3), so the two chains run different grid sizes.
     One chain (SS4K_LANES=1), two chains (=2) and the measured choice (unset: calls 0-1 two chains, 2-3 one, then the
     faster) must give bit-identical tensors, call after call, for every conv network."""
     def build():
@@ -291,7 +293,7 @@ def test_frame_lanes_bit_identical(ctx, monkeypatch, kind):
         t = W.srvgg_table(2, num_feat=64, num_conv=4)
         return _capi.Model(ctx, _capi.make_desc(_capi.SRVGG, _capi.F16, scale=4, num_feat=64, num_block=4), W.flatten(t, W.srvgg_keys(4)))
     cin = 4 if kind == "bsvd" else 3
-    x = torch.rand(4, cin, 72, 104, generator=torch.Generator().manual_seed(11)).cuda()
+    x = torch.rand(n, cin, 72, 104, generator=torch.Generator().manual_seed(11)).cuda()
     outs = {}
     for mode in ("1", "2", None):
         if mode is None:
