@@ -75,16 +75,29 @@ __global__ __launch_bounds__(256, 3) void conv3x3_pair_kernel(const PairArgs a) 
 
   // this wave's layer: weight fragments [(chunk*3 + dx)*3 + dy] and the bias of the channels its accumulators hold
   uint4 Wt[18];
-  float bias[16];
   {
     const char* wsrc = (roleA ? a.wA : a.wB) + lane * 16;
     const int nfr = roleA ? 9 * PA : 18;
 #pragma unroll
     for (int i = 0; i < 18; ++i) Wt[i] = i < nfr ? *reinterpret_cast<const uint4*>(wsrc + i * 1024) : make_uint4(0u, 0u, 0u, 0u);
+  }
+  // the bias of the channels a lane's accumulator holds (element i = channel 16 (i >> 3) + 8 h + (i & 7)): both halves' values are wave-uniform
+  // (scalar registers), a lane selects its half's per row - held as sixteen vector registers through the march three of the six builds
+  // spilled 6-10 registers at the 168 of three workgroups per CU
+  float bias_s[2][16];
+  {
     const float* bs = roleA ? a.biasA : a.biasB;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) bias[i] = bs[16 * (i >> 3) + 8 * h + (i & 7)];
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bias_s[hh][i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bs[16 * (i >> 3) + 8 * hh + (i & 7)])));
   }
+  auto acc_init = [&](f32x16& acc) {
+    int hh = h;
+    asm volatile("" : "+v"(hh));   // selected per row: hoisted out of the march the sixteen values are vector registers again
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = hh ? bias_s[1][i] : bias_s[0][i];
+  };
   // pixel operand of tap dx: record 32*unit + n + dx of the ring row (conv A: input column x0-2 + that; conv B: inter
   // column x0-1 + that), 16-byte half h
   int rd[3];
@@ -183,8 +196,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_pair_kernel(const PairArgs a) 
           uint4 o0 = make_uint4(0u, 0u, 0u, 0u), o1 = o0;
           if (yq >= 0 && yq < a.H) {   // wave-uniform; a row outside the image is conv B's zero padding
             f32x16 acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = bias[i];
+            acc_init(acc);
             const char* rowp[3];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) rowp[dy] = in_ring + wrap(s6 + dy) * IN_SLOTB;
@@ -220,8 +232,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_pair_kernel(const PairArgs a) 
         const int P = t - 3, y = ylo + P;
         if (P >= 0 && y < yhi) {
           f32x16 acc;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[i] = bias[i];
+          acc_init(acc);
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             uint4 b[9];
