@@ -111,7 +111,10 @@ enum {
                                    single-layer build with the residual through the matrix core (+ 4.5 % on one-frame jobs).  The two
                                    kernels add in a different order: with this bit a frame's bits do not depend on the size of the job
                                    it arrived in; without it they are the same for every job of one shape */
-  SS4K_MODEL_FLAGS_ALL = 32767
+  SS4K_MODEL_W16 = 32768,       /* fp16 layers with 64-cout groups, a plain epilogue and an even number of 16-channel input planes (SRVGG body,
+                                   RRDBNet trunk / tail, BSVD) on conv_w16.hip: the same tile on v_mfma_f32_16x16x32_f16.  Not bit-identical to the
+                                   default route (an MFMA sums 32 products where the other sums 16); the same accuracy against the oracle */
+  SS4K_MODEL_FLAGS_ALL = 65535
 };
 
 int ss4k_abi_version(void);

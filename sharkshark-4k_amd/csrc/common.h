@@ -155,8 +155,10 @@ struct ConvArgs {
   const void* wpk;                      // packed weights [group][chunk][dx,ks][dy][nb][lane][E]
   const void* wrs;                      // conv_rs.hip layout [group][cout group][chunk32][tap][cb][lane][8] or null
   int rs_wide;                          // wrs is packed for the eight-wave variant of the shape
+  const void* w16;                      // conv_w16.hip layout [group of 64][chunk pair][phase][dy][16-cout block][lane][8] or null
   const float* bias;                    // [cout_pad] virtual order
   const float* prelu;                   // [cout_pad] or null
+  int prelu_le1;                        // every PReLU slope of the layer is <= 1: t >= 0 ? t : t s == max(t, t s)
   int act; float slope;
   float alpha, gamma;                   // v = (act(acc+bias)*alpha + res1)*gamma + res2
   const char* res1; size_t r1_plane_bytes; int r1_plane0;
@@ -253,6 +255,9 @@ struct ConvArgs;
 bool conv3x3_wide_eligible(const ConvArgs& a, int dtype);
 void launch_conv3x3_wide(ss4k_ctx* ctx, const ConvArgs& a, hipStream_t st);
 void launch_conv3x3_dense2(ss4k_ctx* ctx, const DenseArgs& a, hipStream_t st);
+// the same single-layer tile on v_mfma_f32_16x16x32_f16 (conv_w16.hip): needs ConvArgs.w16
+bool conv3x3_w16_eligible(const ConvArgs& a, int dtype);
+void launch_conv3x3_w16(ss4k_ctx* ctx, const ConvArgs& a, hipStream_t st);
 
 int conv_cw(int dtype);  // channels per plane / K-chunk: 16
 // three-stage-ring build of the 32-cout tile body (conv_s3.hip)
@@ -280,6 +285,8 @@ struct PackedConv {
 PackedConv pack_conv3x3(const PackSpec& s, const float* w_oihw, const float* bias, const float* prelu);
 // conv_rs.hip weight order for a layer shape <nch, rows, cb> (fp16 only); same virtual cout order / bias as pack_conv3x3
 std::vector<uint8_t> pack_conv3x3_rs(const PackSpec& s, const float* w_oihw, int cout_pad, int nch, int cb, int cg);
+// conv_w16.hip weight order (fp16, 64-cout groups, an even number of K-chunks); same virtual cout order / bias as pack_conv3x3
+std::vector<uint8_t> pack_conv3x3_w16(const PackSpec& s, const float* w_oihw, int cout_pad);
 int virt_to_real_cout(const PackSpec& s, int v);
 
 }  // namespace ss4k

@@ -121,6 +121,11 @@ int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool h
     weight_bytes += wr.size();
     L.rs_wide = rs_wide;
   }
+  if (use_w16 && use_wide && desc.dtype == SS4K_F16 && p.nb == 2 && p.cout_pad % 64 == 0 && (s.nchunks0 + s.nchunks1) % 2 == 0 && !s.ps2) {
+    const std::vector<uint8_t> w6 = pack_conv3x3_w16(s, w, p.cout_pad);
+    upload(L.w16, w6.data(), w6.size());
+    weight_bytes += w6.size();
+  }
   if (chainable && chain_mode == 2 && desc.dtype == SS4K_F16 && p.nb == 2) {
     PackSpec s1 = s; s1.force_nb1 = 1;
     const PackedConv p1 = pack_conv3x3(s1, w, b, a);
@@ -128,6 +133,7 @@ int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool h
     weight_bytes += p1.w.size();
   }
   L.has_prelu = a != nullptr;
+  if (a) { L.prelu_le1 = true; for (int c = 0; c < cout; ++c) L.prelu_le1 = L.prelu_le1 && a[c] <= 1.f; }
   L.cout_real = cout; L.cout_pad = p.cout_pad; L.nchunks0 = s.nchunks0; L.nchunks1 = s.nchunks1;
   L.cin_real = 0;
   for (int c : s.cin_map) L.cin_real += c >= 0;
@@ -200,6 +206,7 @@ void Model::build(const float* w, size_t n) {
   if (fl & SS4K_MODEL_NO_WIDE) use_wide = false;
   if (fl & SS4K_MODEL_NO_UPS_PRESUM) ups_presum = false;
   if (fl & SS4K_MODEL_CONV5_RS) conv5_mode = 1;
+  if (fl & SS4K_MODEL_W16) use_w16 = true;
   if (!(fl & (SS4K_MODEL_ONE_CHAIN | SS4K_MODEL_TWO_CHAINS)))
     if (const char* e = std::getenv("SS4K_LANES")) lanes_mode = std::max(0, std::min(2, std::atoi(e)));
   if (const char* e = std::getenv("SS4K_FS_EXACT")) fs_exact = fs_exact || e[0] == '1';
@@ -216,6 +223,7 @@ void Model::build(const float* w, size_t n) {
   if (const char* e = std::getenv("SS4K_CONV5_MODE")) conv5_mode = std::atoi(e);    // A/B switch: 0 by job size, 1 always conv_rs.hip
   if (const char* e = std::getenv("SS4K_WIDE_RL")) wide_rl = e[0] == '1';          // A/B switch: conv5's residual through the matrix core on the wide kernel
   if (const char* e = std::getenv("SS4K_WIDE")) use_wide = e[0] == '1';            // A/B switch: 64-cout layers on conv3x3_wide_kernel
+  if (const char* e = std::getenv("SS4K_W16")) use_w16 = e[0] == '1';              // A/B switch: ... on conv3x3_w16_kernel
   if (const char* e = std::getenv("SS4K_DENSE_MODE")) dense_mode = std::atoi(e);   // A/B switch: 0 default policy, 1 never, 2 every job
   if (const char* e = std::getenv("SS4K_LANE_GRID")) lane_grid_share = (float)std::atof(e);   // A/B switch: grid of a lane's launch as a share of the chip's slots
   if (const char* e = std::getenv("SS4K_FAIL_AT_CONV")) fail_at_conv = std::atoi(e);   // fault injection: the k-th conv call of every
@@ -311,7 +319,7 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
   if (in1) { a.in1 = in1->p; a.in1_plane_bytes = in1->plane_bytes; a.in1_plane0 = in1->plane0; a.nchunks1 = L.nchunks1; }
   SS4K_REQUIRE((in1 != nullptr) == (L.nchunks1 > 0), "internal: conv segment mismatch");
   a.N = N; a.H = H; a.W = W; a.ups2 = o.ups2;
-  a.wpk = L.w.ptr; a.wrs = L.wrs.ptr; a.rs_wide = L.rs_wide ? 1 : 0; a.bias = L.bias.as<float>(); a.prelu = L.has_prelu ? L.prelu.as<float>() : nullptr;
+  a.wpk = L.w.ptr; a.wrs = L.wrs.ptr; a.w16 = L.w16.ptr; a.rs_wide = L.rs_wide ? 1 : 0; a.bias = L.bias.as<float>(); a.prelu = L.has_prelu ? L.prelu.as<float>() : nullptr; a.prelu_le1 = L.prelu_le1 ? 1 : 0;
   a.act = o.act; a.slope = o.slope; a.alpha = o.alpha; a.gamma = o.gamma;
   if (o.res1) { a.res1 = o.res1->p; a.r1_plane_bytes = o.res1->plane_bytes; a.r1_plane0 = o.res1->plane0; }
   if (o.res2) { a.res2 = o.res2->p; a.r2_plane_bytes = o.res2->plane_bytes; a.r2_plane0 = o.res2->plane0; }

@@ -125,4 +125,39 @@ std::vector<uint8_t> pack_conv3x3_rs(const PackSpec& s, const float* w, int cout
   return out;
 }
 
+// conv_w16.hip: one 64-cout group of a layer as v_mfma_f32_16x16x32_f16 A fragments, [group][pair of K-chunks q][phase][dy][16-cout
+// block mbk][lane][8 fp16].  lane l: MFMA row m = l & 15 of block mbk, k-group kq = l >> 4; element e: channel 8 (kq & 1) + e of
+//   phase 0: plane 2q,            tap column dx = kq >> 1       (taps dx 0 | dx 1 of one plane)
+//   phase 1: plane 2q + (kq >> 1), tap column dx = 2            (tap dx 2 of both planes)
+//   phase 2: plane 2q + 1,        tap column dx = kq >> 1
+// Row m = 4 rg + i of block mbk = 2 j + e2 is virtual cout 64 g + 32 j + 16 (rg >> 1) + 8 (rg & 1) + 4 e2 + i: result lane (pixel, rg)
+// then holds channels 8 (rg & 1) .. + 7 of plane 2 j + (rg >> 1) in blocks 2 j and 2 j + 1 (one 16-byte store).
+std::vector<uint8_t> pack_conv3x3_w16(const PackSpec& s, const float* w, int cout_pad) {
+  SS4K_REQUIRE(s.dtype == SS4K_F16, "pack_conv3x3_w16: fp16 only");
+  const int nplanes = s.nchunks0 + s.nchunks1;
+  SS4K_REQUIRE((int)s.cin_map.size() == nplanes * 16 && nplanes % 2 == 0 && cout_pad % 64 == 0, "pack_conv3x3_w16: shape");
+  const int groups = cout_pad / 64, np = nplanes / 2;
+  std::vector<uint8_t> out((size_t)groups * np * 3 * 3 * 4 * 64 * 8 * 2, 0);
+  size_t idx = 0;
+  for (int g = 0; g < groups; ++g)
+    for (int q = 0; q < np; ++q)
+      for (int ph = 0; ph < 3; ++ph)
+        for (int dy = 0; dy < 3; ++dy)
+          for (int mbk = 0; mbk < 4; ++mbk)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int m = lane & 15, kq = lane >> 4, rg = m >> 2, i = m & 3;
+              const int co = virt_to_real_cout(s, g * 64 + 32 * (mbk >> 1) + 16 * (rg >> 1) + 8 * (rg & 1) + 4 * (mbk & 1) + i);
+              const int plane = ph == 0 ? 2 * q : ph == 1 ? 2 * q + (kq >> 1) : 2 * q + 1;
+              const int dx = ph == 1 ? 2 : (kq >> 1);
+              for (int e = 0; e < 8; ++e, ++idx) {
+                const int ci = s.cin_map[(size_t)plane * 16 + 8 * (kq & 1) + e];
+                float val = 0.f;
+                if (ci >= 0 && co >= 0) val = w[((size_t)co * s.cin_total + ci) * 9 + dy * 3 + dx];
+                const uint16_t h = f32_to_f16_bits(val);
+                std::memcpy(&out[idx * 2], &h, 2);
+              }
+            }
+  return out;
+}
+
 }  // namespace ss4k
