@@ -106,14 +106,16 @@ enum {
                                    Default: two of the three input rows an output row reads are the same low-resolution row, so their two
                                    MFMAs per tap column run as one with the weight fragments added in fp16 (6 instead of 9 MFMAs per
                                    pixel).  The only routing bit that is NOT bit-identical: one more fp16 rounding of a weight sum */
-  SS4K_MODEL_CONV5_RS = 16384,  /* RRDBNet fp16: conv5 of every RDB on the register-stationary kernel for every job size.  Default: jobs with
-                                   fewer than three rounds of 16 x 32 tiles per 256 workgroup slots (one 720p frame) take conv_dense.hip's
-                                   single-layer build with the residual through the matrix core (+ 4.5 % on one-frame jobs).  The two
-                                   kernels add in a different order: with this bit a frame's bits do not depend on the size of the job
-                                   it arrived in; without it they are the same for every job of one shape */
-  SS4K_MODEL_W16 = 32768,       /* fp16 layers with 64-cout groups, a plain epilogue and an even number of 16-channel input planes (SRVGG body,
-                                   RRDBNet trunk / tail, BSVD) on conv_w16.hip: the same tile on v_mfma_f32_16x16x32_f16.  Not bit-identical to the
-                                   default route (an MFMA sums 32 products where the other sums 16); the same accuracy against the oracle */
+  SS4K_MODEL_CONV5_RS = 16384,  /* RRDBNet fp16: conv5 of every RDB on the register-stationary kernel (conv_rs.hip) for every job size.  Default:
+                                   conv_w16.hip with the residual through the matrix core, for every job size (4 frames of 720p + 1.6 %, one frame
+                                   + 3.9 %); with SS4K_MODEL_NO_W16 the round-3 rule: jobs with fewer than three rounds of 16 x 32 tiles per 256
+                                   workgroup slots (one 720p frame) on the wide kernel, larger ones on conv_rs.hip - then, and only then, a
+                                   frame's last bits depend on the size of the job it arrived in */
+  SS4K_MODEL_NO_W16 = 32768,    /* fp16 layers with 64-cout groups, a plain epilogue and an even number of 16-channel input planes (SRVGG body, RRDBNet
+                                   trunk / tail, BSVD) on the v_mfma_f32_32x32x16_f16 build of the tile (conv_dense.hip's wide kernel) instead of
+                                   conv_w16.hip's v_mfma_f32_16x16x32_f16 build (default since round 4: the chip runs these layers at its power cap
+                                   and holds a 10 % higher clock on that shape; SRVGG x4 720p + 12 %).  The two builds add the same products in a
+                                   different order: results differ in the last bits, the accuracy against the oracle is the same */
   SS4K_MODEL_FLAGS_ALL = 65535
 };
 

@@ -41,7 +41,7 @@ class ModelDesc(C.Structure):
 
 # ss4k_model_desc.flags (include/ss4k.h)
 MODEL_FS_EXACT, MODEL_ONE_CHAIN, MODEL_TWO_CHAINS, MODEL_NO_RS, MODEL_TILE_ROWS_16, MODEL_TILE_ROWS_20 = 1, 2, 4, 8, 16, 32
-MODEL_NO_CHAIN, MODEL_CHAIN, MODEL_NO_PAIR, MODEL_HR_F32, MODEL_NO_DENSE, MODEL_DENSE, MODEL_NO_WIDE, MODEL_NO_UPS_PRESUM, MODEL_CONV5_RS, MODEL_W16 = 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768
+MODEL_NO_CHAIN, MODEL_CHAIN, MODEL_NO_PAIR, MODEL_HR_F32, MODEL_NO_DENSE, MODEL_DENSE, MODEL_NO_WIDE, MODEL_NO_UPS_PRESUM, MODEL_CONV5_RS, MODEL_NO_W16 = 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768
 
 
 class UpscaleCfg(C.Structure):

@@ -54,7 +54,12 @@ __device__ __forceinline__ f32x4 mma16(const uint4& w, const uint4& x, f32x4 acc
 }
 
 //   STAMP (dev library, SS4K_W16_STAMP=1): per-wave cycle totals of the tile's parts (s_memtime), see launch_conv3x3_w16
-template <bool STAMP = false>
+//   RL: res1 is the layer's own input tensor and its first four K-chunks are that tensor's planes (conv5 of an RDB: out = conv * alpha + x,
+//   no activation): x's centre pixels pass through LDS as the dx 1 half of phases 0 / 2 of the first two chunk pairs, so they are added
+//   there - one more MFMA per accumulator with a (1 / alpha) I fragment on tap (dy 1, dx 1), as conv_rs.hip and the wide kernel do -
+//   instead of being read from memory again in the epilogue.  Output plane P = 2 jw + (kg >> 1) is input plane P: wave pair jw adds during
+//   chunk pair q == jw, rows of row groups kg >> 1 == 0 in phase 0 (plane 2 jw), kg >> 1 == 1 in phase 2 (plane 2 jw + 1).
+template <bool STAMP = false, bool RL = false>
 __global__ __launch_bounds__(64 * NW, 2) void conv3x3_w16_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -101,32 +106,34 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_w16_kernel(const ConvArgs 
     rdX[hn] = (((rgp * MB) * XW + 16 * hn + n16 + 2) * 2 + (kg & 1)) * 16 + (kg >> 1) * XT_BYTES;
   }
 
-  uint32_t src_off[DMA_PER_WAVE];
+  // (n, y0, x0): the tile whose planes are being REQUESTED (the next tile's from the last phase of the current one on)
   auto setup_tile = [&](int tile, int& n, int& y0, int& x0) {
     const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
     const int ty = tyn % a.tiles_y;
     n = a.n0 + tyn / a.tiles_y; y0 = ty * TH; x0 = tx * TW;
-#pragma unroll
-    for (int j = 0; j < DMA_PER_WAVE; ++j) {
-      const int s = (wave + NW * j) * 64 + lane;
-      const int p = s >> 1, gq = s & 1;
-      const int row = p / XW, x = p - row * XW;
-      const int iy = y0 - 1 + row, ix = x0 - 1 + x;
-      const bool ok = s < XT_SLOTS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      src_off[j] = ok ? ((uint32_t)(n * a.H + iy) * (uint32_t)a.W + (uint32_t)ix) * REC + (uint32_t)(gq * 16) : OOB;
-    }
+  };
+  // per-lane source of halo-tile DMA instruction k: LDS slot s = 64 k + lane holds pixel (row, x) = (s / 2) divmod 34, half s & 1; byte offset
+  // inside a plane, OOB = the zero page.  Recomputed at every issue (a division by a constant) instead of five registers held through the MFMA loops.
+  auto tile_src = [&](int k, int n, int y0, int x0) -> uint32_t {
+    const int s = k * 64 + lane;
+    const int p = s >> 1, gq = s & 1;
+    const int row = p / XW, x = p - row * XW;
+    const int iy = y0 - 1 + row, ix = x0 - 1 + x;
+    const bool ok = s < XT_SLOTS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    return ok ? ((uint32_t)(n * a.H + iy) * (uint32_t)a.W + (uint32_t)ix) * REC + (uint32_t)(gq * 16) : OOB;
   };
   auto plane_of = [&](int c) {
     return (c < a.nchunks0) ? a.in0 + (size_t)(a.in0_plane0 + c) * a.in0_plane_bytes
                             : a.in1 + (size_t)(a.in1_plane0 + c - a.nchunks0) * a.in1_plane_bytes;
   };
   // prefetch of the running phase: an optional halo tile into buffer pf_buf and an optional 12 KB of weights into ring slot pf_slot
-  const char* pf_plane = nullptr; const char* pf_w = nullptr; int pf_buf = 0, pf_slot = 0; bool pf_tile = false, pf_wt = false;
+  const char* pf_plane = nullptr; const char* pf_w = nullptr; int pf_buf = 0, pf_slot = 0, pf_n = 0, pf_y0 = 0, pf_x0 = 0; bool pf_tile = false, pf_wt = false;
   auto dma_op = [&](int idx) {
     if (idx < DMA_PER_WAVE) {
       const int k = wave + NW * idx;
       if (pf_tile && k < XT_DMA) {
-        const char* src = src_off[idx] != OOB ? pf_plane + src_off[idx] : a.zero_page + (lane & 3) * 16;
+        const uint32_t so = tile_src(k, pf_n, pf_y0, pf_x0);
+        const char* src = so != OOB ? pf_plane + so : a.zero_page + (lane & 3) * 16;
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + pf_buf * XT_BYTES + k * 1024);
         if (k * 64 + lane < XT_SLOTS) dma16(src, dst);
       }
@@ -151,6 +158,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_w16_kernel(const ConvArgs 
   if (tile < 0) return;
   int n, y0, x0;
   setup_tile(tile, n, y0, x0);
+  pf_n = n; pf_y0 = y0; pf_x0 = x0;
   int ws = 0;   // ring slot of the running phase's weights
   // before phase 0 of the first tile: buffer 0 <- plane 0, weights of phases 0 and 1
   pf_tile = true; pf_plane = plane_of(0); pf_buf = 0; pf_wt = true; pf_w = wbase; pf_slot = 0;
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_w16_kernel(const ConvArgs 
         else {
           pf_buf = 0;
           if (!last_q) { pf_tile = true; pf_plane = plane_of(2 * q + 2); }
-          else if (next_tile >= 0) { setup_tile(next_tile, n, y0, x0); pf_tile = true; pf_plane = plane_of(0); }
+          else if (next_tile >= 0) { setup_tile(next_tile, n, y0, x0); pf_n = n; pf_y0 = y0; pf_x0 = x0; pf_tile = true; pf_plane = plane_of(0); }
           else pf_tile = false;
         }
         const bool more = !(last_q && ph == 2) || next_tile >= 0;   // a phase follows: re-fill the weight fragments for it
@@ -209,6 +217,18 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_w16_kernel(const ConvArgs 
         const char* wbn = smem + W_OFF + slot_inc(ws) * WP + wsub;
         uint4 bf[3][2];
         auto bf_load = [&](int t, int hn) { return *reinterpret_cast<const uint4*>(tb + rd[hn] + t * ROWX); };
+        // RL: A fragments of (1 / alpha) I for this phase's plane.  As an A operand this lane is MFMA row m = lane & 15 (row group m >> 2,
+        // i = m & 3: channel 8 (rg & 1) + 4 e2 + i of plane 2 jw + (rg >> 1) in block e2) and k-group kg: elements e = channel 8 (kg & 1) + e
+        // of tap dx = kg >> 1 - the one at e = 4 e2 + i meets its row when kg >= 2 (dx 1), kg & 1 == rg & 1 and rg >> 1 == the plane's parity
+        bool rl_on = false;
+        uint32_t idw[2] = {0u, 0u};   // the two words of the lane's four elements 4 e2 .. 4 e2 + 3 (the other six words of a fragment are zero)
+        if constexpr (RL && ph != 1) {
+          rl_on = q == jw;
+          const int rg = (lane & 15) >> 2, i = lane & 3;
+          const bool hit = kg >= 2 && (kg & 1) == (rg & 1) && (rg >> 1) == (ph >> 1);
+          const uint32_t hv = hit ? (uint32_t)__half_as_ushort(__float2half(1.f / a.alpha)) << (16 * (i & 1)) : 0u;
+          idw[0] = (i >> 1) == 0 ? hv : 0u; idw[1] = (i >> 1) == 1 ? hv : 0u;
+        }
 #pragma unroll
         for (int t = 0; t < 3; ++t) { bf[t][0] = bf_load(t, 0); bf[t][1] = bf_load(t, 1); }
         int m = 0;
@@ -224,6 +244,13 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_w16_kernel(const ConvArgs 
               for (int hn = 0; hn < 2; ++hn) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) acc[r][hn][e] = mma16(wf[dy][e], bf[ir % 3][hn], (first && dy == 0) ? bias4[e] : acc[r][hn][e]);
+                if constexpr (RL && ph != 1) {
+                  if (dy == 1 && rl_on) {   // wave-uniform
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                      acc[r][hn][e] = mma16(e == 0 ? make_uint4(idw[0], idw[1], 0u, 0u) : make_uint4(0u, 0u, idw[0], idw[1]), bf[ir % 3][hn], acc[r][hn][e]);
+                  }
+                }
                 // DMA slots (48 MFMA pairs per phase): the halo tile after pairs 1, 3, 5, 7, 9, the weights after pairs 13, 17, 21
                 const int sl = (m & 1) && m < 10 ? m >> 1 : (m == 13 || m == 17 || m == 21) ? DMA_PER_WAVE + (m - 13) / 4 : -1;
                 if (sl >= 0) {
@@ -272,7 +299,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_w16_kernel(const ConvArgs 
       }
       const int opl = grp * 4 + 2 * jw + (kge >> 1);
       const size_t sub = (size_t)(kge & 1) * 16;
-      const char* r1p = a.res1 ? a.res1 + (size_t)(a.r1_plane0 + opl) * a.r1_plane_bytes + sub : nullptr;
+      const char* r1p = (a.res1 && !RL) ? a.res1 + (size_t)(a.r1_plane0 + opl) * a.r1_plane_bytes + sub : nullptr;
       const char* r2p = a.res2 ? a.res2 + (size_t)(a.r2_plane0 + opl) * a.r2_plane_bytes + sub : nullptr;
       char* outp = a.out + (size_t)(a.out_plane0 + opl) * a.out_plane_bytes + sub;
       const bool resid = r1p || r2p;
@@ -362,6 +389,10 @@ void launch_conv3x3_w16(ss4k_ctx* ctx, const ConvArgs& a0, hipStream_t st) {
   const int groups = a.cout_pad / 64;
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
   const int gx = std::min(ntiles, std::max(1, (int)(ctx->num_cu * 2 / groups * (a.grid_share > 0.f ? a.grid_share : 1.f))));
+  // conv5 of an RDB with its residual through the matrix core (RL): res1 must be the conv's own input tensor = its first four planes
+  const bool rl = a.wide_rl && a.res1 && a.act == ACT_NONE && a.alpha != 0.f && a.nchunks0 == 4 && a.cout_pad == 64 &&
+                  a.res1 + (size_t)a.r1_plane0 * a.r1_plane_bytes == a.in0 + (size_t)a.in0_plane0 * a.in0_plane_bytes &&
+                  a.r1_plane_bytes == a.in0_plane_bytes;
 #ifdef SS4K_DEV
   static const bool stamp_mode = std::getenv("SS4K_W16_STAMP") && std::getenv("SS4K_W16_STAMP")[0] == '1';
   if (stamp_mode) {   // cycle counters of every wave of the first 1024 workgroups of cout group 0
@@ -369,9 +400,10 @@ void launch_conv3x3_w16(ss4k_ctx* ctx, const ConvArgs& a0, hipStream_t st) {
     if (!dbuf) SS4K_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), 1024 * 4 * 8 * 8));
     SS4K_HIP(hipMemsetAsync(dbuf, 0, 1024 * 4 * 8 * 8, st));
     a.dbg_buf = dbuf;
-    const void* fs = reinterpret_cast<const void*>(&conv3x3_w16_kernel<true>);
+    const void* fs = rl ? reinterpret_cast<const void*>(&conv3x3_w16_kernel<true, true>) : reinterpret_cast<const void*>(&conv3x3_w16_kernel<true, false>);
     if (ctx->lds_attr_set.insert(fs).second) SS4K_HIP(hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    hipLaunchKernelGGL(conv3x3_w16_kernel<true>, dim3(gx, groups), dim3(64 * NW), LDS_BYTES, st, a);
+    if (rl) hipLaunchKernelGGL((conv3x3_w16_kernel<true, true>), dim3(gx, groups), dim3(64 * NW), LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((conv3x3_w16_kernel<true, false>), dim3(gx, groups), dim3(64 * NW), LDS_BYTES, st, a);
     SS4K_HIP(hipStreamSynchronize(st));
     std::vector<unsigned long long> hb(1024 * 4 * 8);
     SS4K_HIP(hipMemcpy(hb.data(), dbuf, hb.size() * 8, hipMemcpyDeviceToHost));
@@ -393,10 +425,11 @@ void launch_conv3x3_w16(ss4k_ctx* ctx, const ConvArgs& a0, hipStream_t st) {
     return;
   }
 #endif
-  const void* fn = reinterpret_cast<const void*>(&conv3x3_w16_kernel<false>);
+  const void* fn = rl ? reinterpret_cast<const void*>(&conv3x3_w16_kernel<false, true>) : reinterpret_cast<const void*>(&conv3x3_w16_kernel<false, false>);
   if (ctx->lds_attr_set.insert(fn).second)
     SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-  hipLaunchKernelGGL(conv3x3_w16_kernel<false>, dim3(gx, groups), dim3(64 * NW), LDS_BYTES, st, a);
+  if (rl) hipLaunchKernelGGL((conv3x3_w16_kernel<false, true>), dim3(gx, groups), dim3(64 * NW), LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((conv3x3_w16_kernel<false, false>), dim3(gx, groups), dim3(64 * NW), LDS_BYTES, st, a);
   SS4K_HIP(hipGetLastError());
 }
 

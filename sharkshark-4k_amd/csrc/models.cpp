@@ -206,7 +206,7 @@ void Model::build(const float* w, size_t n) {
   if (fl & SS4K_MODEL_NO_WIDE) use_wide = false;
   if (fl & SS4K_MODEL_NO_UPS_PRESUM) ups_presum = false;
   if (fl & SS4K_MODEL_CONV5_RS) conv5_mode = 1;
-  if (fl & SS4K_MODEL_W16) use_w16 = true;
+  if (fl & SS4K_MODEL_NO_W16) use_w16 = false;
   if (!(fl & (SS4K_MODEL_ONE_CHAIN | SS4K_MODEL_TWO_CHAINS)))
     if (const char* e = std::getenv("SS4K_LANES")) lanes_mode = std::max(0, std::min(2, std::atoi(e)));
   if (const char* e = std::getenv("SS4K_FS_EXACT")) fs_exact = fs_exact || e[0] == '1';
@@ -220,7 +220,7 @@ void Model::build(const float* w, size_t n) {
   if (const char* e = std::getenv("SS4K_S3")) use_s3 = e[0] == '1';
   if (const char* e = std::getenv("SS4K_DENSE_MASK")) dense_mask = std::atoi(e);   // A/B switch: which layer pairs of an RDB run fused
   if (const char* e = std::getenv("SS4K_UPS_PRESUM")) ups_presum = e[0] == '1';   // A/B switch: pre-summed weights in the up-sampling convs
-  if (const char* e = std::getenv("SS4K_CONV5_MODE")) conv5_mode = std::atoi(e);    // A/B switch: 0 by job size, 1 always conv_rs.hip
+  if (const char* e = std::getenv("SS4K_CONV5_MODE")) conv5_mode = std::atoi(e);    // A/B switch: 0 default, 1 always conv_rs.hip
   if (const char* e = std::getenv("SS4K_WIDE_RL")) wide_rl = e[0] == '1';          // A/B switch: conv5's residual through the matrix core on the wide kernel
   if (const char* e = std::getenv("SS4K_WIDE")) use_wide = e[0] == '1';            // A/B switch: 64-cout layers on conv3x3_wide_kernel
   if (const char* e = std::getenv("SS4K_W16")) use_w16 = e[0] == '1';              // A/B switch: ... on conv3x3_w16_kernel
@@ -348,15 +348,17 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
   static const bool split64 = std::getenv("SS4K_SPLIT64") && std::getenv("SS4K_SPLIT64")[0] == '1';
   if (split64 && L.wch.ptr && a.cout_pad == 64 && a.epi == EPI_NHWC) { a.wpk = L.wch.ptr; a.wrs = nullptr; a.cout_pad = -64; }
 #endif
-  // conv5 of an RDB (residual = the conv's own input): the register-stationary kernel runs one persistent workgroup per CU, so a job
-  // with fewer than three rounds of 16 x 32 tiles for 256 slots (one 720p frame: 460 tiles = 1.8) leaves a tenth of them idle and
-  // amortises the 54 KB of weights per workgroup over two tiles.  Such jobs take the wide kernel (512 slots, LDS weights) with the residual
-  // through the matrix core instead: + 4.5 % on one-frame 720p jobs, - 1 % on four-frame ones, which therefore stay where they are.
-  // Decided per JOB (N, H, W) - never per launch - so that a job's bits do not depend on how it is cut into launch chains.
-  // SS4K_MODEL_CONV5_RS pins the register-stationary kernel for every size (a frame's bits then do not depend on the batch it came in).
-  if (a.wrs && conv5_mode == 0 && use_wide && a.res1 && a.act == ACT_NONE && a.nchunks0 == 4 && a.cout_pad == 64 && !a.ups2 &&
+  // conv5 of an RDB (residual = the conv's own input).  Default since round 4: conv_w16.hip with the residual through the matrix core, for
+  // every job size - two workgroups per CU that co-reside with the fused dense-block launches of the other launch chain, where the
+  // register-stationary kernel's 160 KB ring and 460 registers monopolise a CU (4 frames of 720p + 1.6 %, 2 frames + 2.7 %, 1 frame + 3.9 %).
+  // A frame's bits therefore do not depend on the size of the job it arrived in.  Without the 16x16x32 build (SS4K_MODEL_NO_W16) the older
+  // rule applies: the register-stationary kernel runs one persistent workgroup per CU, so a job with fewer than three rounds of 16 x 32
+  // tiles for 256 slots (one 720p frame: 460 tiles = 1.8) takes the wide kernel with the residual through the matrix core, larger ones the
+  // register-stationary kernel - decided per JOB (N, H, W), never per launch, so that a job's bits do not depend on how it is cut into
+  // launch chains.  SS4K_MODEL_CONV5_RS pins the register-stationary kernel for every size.
+  if (a.wrs && conv5_mode != 1 && use_wide && a.res1 && a.act == ACT_NONE && a.nchunks0 == 4 && a.cout_pad == 64 && !a.ups2 &&
       a.res1 + (size_t)a.r1_plane0 * a.r1_plane_bytes == a.in0 + (size_t)a.in0_plane0 * a.in0_plane_bytes &&
-      (long long)N * ((H + 15) / 16) * ((W + 31) / 32) < 3LL * ctx->num_cu) {
+      (a.w16 || (long long)N * ((H + 15) / 16) * ((W + 31) / 32) < 3LL * ctx->num_cu)) {
     a.wrs = nullptr; a.wide_rl = 1;
   }
   if (cur_lanes <= 1 || N != cur_n) {

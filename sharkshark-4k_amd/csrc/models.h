@@ -87,9 +87,9 @@ struct Model {
   int dense_mode = 0;          // RRDBNet: (conv1, conv2) and (conv3, conv4) of every RDB as one fused launch each (conv_dense.hip): 0 = default (fused),
                                // 1 = never (SS4K_MODEL_NO_DENSE), 2 = forced (SS4K_MODEL_DENSE; the same as the default today)
   bool use_wide = true;        // 64-cout-group fp16 layers with a plain epilogue on conv_dense.hip's single-layer build (SS4K_MODEL_NO_WIDE: conv_mfma.hip's <2,4,4>)
-  bool use_w16 = false;        // ... on conv_w16.hip (v_mfma_f32_16x16x32_f16) where the layer has an even number of K-chunks and no up-sampled input
-  int conv5_mode = 0;          // RDB conv5: 0 = conv_rs.hip for jobs of at least three rounds of tiles, the wide kernel (residual through the matrix
-                               // core) below; 1 = conv_rs.hip for every size (SS4K_MODEL_CONV5_RS)
+  bool use_w16 = true;         // ... on conv_w16.hip (v_mfma_f32_16x16x32_f16) where the layer has an even number of K-chunks and no up-sampled input (SS4K_MODEL_NO_W16: never)
+  int conv5_mode = 0;          // RDB conv5: 0 = conv_w16.hip with the residual through the matrix core (without the w16 build: conv_rs.hip for jobs of at
+                               // least three rounds of tiles, the wide kernel below); 1 = conv_rs.hip for every size (SS4K_MODEL_CONV5_RS)
   bool wide_rl = false;        // conv5 of an RDB on the wide kernel with its residual through the matrix core (when it is not routed to conv_rs.hip)
   bool ups_presum = true;      // RRDBNet's conv_up1 / conv_up2 on the wide kernel's pre-summed form (6 instead of 9 MFMAs per pixel; SS4K_MODEL_NO_UPS_PRESUM)
   int dense_mask = 3;          // ... which pairs: bit 0 = (conv1, conv2), bit 1 = (conv3, conv4)

@@ -112,7 +112,7 @@ def test_model_flag_constants_match_header():
     want = {"FS_EXACT": _capi.MODEL_FS_EXACT, "ONE_CHAIN": _capi.MODEL_ONE_CHAIN, "TWO_CHAINS": _capi.MODEL_TWO_CHAINS,
             "NO_RS": _capi.MODEL_NO_RS, "TILE_ROWS_16": _capi.MODEL_TILE_ROWS_16, "TILE_ROWS_20": _capi.MODEL_TILE_ROWS_20,
             "NO_CHAIN": _capi.MODEL_NO_CHAIN, "CHAIN": _capi.MODEL_CHAIN, "NO_PAIR": _capi.MODEL_NO_PAIR, "HR_F32": _capi.MODEL_HR_F32,
-            "NO_DENSE": _capi.MODEL_NO_DENSE, "DENSE": _capi.MODEL_DENSE, "NO_WIDE": _capi.MODEL_NO_WIDE, "NO_UPS_PRESUM": _capi.MODEL_NO_UPS_PRESUM, "CONV5_RS": _capi.MODEL_CONV5_RS, "W16": _capi.MODEL_W16}
+            "NO_DENSE": _capi.MODEL_NO_DENSE, "DENSE": _capi.MODEL_DENSE, "NO_WIDE": _capi.MODEL_NO_WIDE, "NO_UPS_PRESUM": _capi.MODEL_NO_UPS_PRESUM, "CONV5_RS": _capi.MODEL_CONV5_RS, "NO_W16": _capi.MODEL_NO_W16}
     for k, v in want.items():
         assert hdr[k] == v, k
     assert hdr["FLAGS_ALL"] == sum(want.values())

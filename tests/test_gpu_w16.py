@@ -1,4 +1,4 @@
-"""GPU: conv_w16.hip (conv3x3_w16_kernel: the 64-cout single-layer tile on v_mfma_f32_16x16x32_f16, SS4K_MODEL_W16) against
+"""GPU: conv_w16.hip (conv3x3_w16_kernel: the 64-cout single-layer tile on v_mfma_f32_16x16x32_f16, the default route; SS4K_MODEL_NO_W16 selects the other) against
 conv_dense.hip's wide kernel (v_mfma_f32_32x32x16_f16) it stands in for, and against the CPU oracle.
 
 The two kernels sum the same products in a different order (an MFMA adds 32 products of two taps where the other adds 16 of one), so
@@ -16,7 +16,7 @@ from oracle import nets as onets
 from tests.helpers import psnr
 
 pytestmark = pytest.mark.gpu
-W16, ONE, TWO, NO_RS = _capi.MODEL_W16, _capi.MODEL_ONE_CHAIN, _capi.MODEL_TWO_CHAINS, _capi.MODEL_NO_RS
+NO_W16, ONE, TWO, NO_RS = _capi.MODEL_NO_W16, _capi.MODEL_ONE_CHAIN, _capi.MODEL_TWO_CHAINS, _capi.MODEL_NO_RS
 
 
 def _close(got, ref, want, what, db_forms, slack=0.5):
@@ -39,9 +39,9 @@ def test_w16_srvgg_vs_wide_and_oracle(ctx, nf, shape, up, lanes):
     with torch.no_grad():
         want = onets.srvgg(x, t, upscale=up, num_conv=4)
     outs = [_capi.Model(ctx, _capi.make_desc(_capi.SRVGG, _capi.F16, scale=up, num_feat=nf, num_block=4, flags=lanes | fl), flat)(x.cuda()).cpu()
-            for fl in (0, W16)]
+            for fl in (NO_W16, 0)]
     _close(outs[1], outs[0], want, f"srvgg {nf} {shape}", 66.0)
-    m = _capi.Model(ctx, _capi.make_desc(_capi.SRVGG, _capi.F16, scale=up, num_feat=nf, num_block=4, flags=lanes | W16), flat)
+    m = _capi.Model(ctx, _capi.make_desc(_capi.SRVGG, _capi.F16, scale=up, num_feat=nf, num_block=4, flags=lanes), flat)
     for _ in range(3):
         assert torch.equal(m(x.cuda()).cpu(), outs[1]), "w16: output changed between calls"
 
@@ -55,9 +55,11 @@ def test_w16_rrdbnet_vs_wide_and_oracle(ctx, scale, shape, base):
     x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[2] * 7 + shape[3]))
     with torch.no_grad():
         want = onets.rrdbnet(x, t, scale, 2)
-    for extra in (_capi.MODEL_CONV5_RS, NO_RS):
+    # conv5: pinned to the register-stationary kernel; on the LDS-weights kernels with its residual read from memory; and the default route
+    # of a small job - residual through the matrix core (the RL builds of the two kernels)
+    for extra in (_capi.MODEL_CONV5_RS, NO_RS, 0):
         outs = [_capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=2, flags=base | extra | fl), flat)(x.cuda()).cpu()
-                for fl in (0, W16)]
+                for fl in (NO_W16, 0)]
         _close(outs[1], outs[0], want, f"rrdbnet x{scale} {shape} flags {extra}", 60.0)
 
 
@@ -69,5 +71,28 @@ def test_w16_bsvd_vs_wide_and_oracle(ctx, chns, shape):
     x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[2]))
     with torch.no_grad():
         want = onets.bsvd_f1(x[:, None], t)[:, 0]
-    outs = [_capi.Model(ctx, _capi.make_desc(_capi.BSVD, _capi.F16, scale=1, bsvd_chns=chns, flags=fl), flat)(x.cuda()).cpu() for fl in (0, W16)]
+    outs = [_capi.Model(ctx, _capi.make_desc(_capi.BSVD, _capi.F16, scale=1, bsvd_chns=chns, flags=fl), flat)(x.cuda()).cpu() for fl in (NO_W16, 0)]
     _close(outs[1], outs[0], want, f"bsvd {chns} {shape}", 60.0)
+
+
+def test_w16_prelu_slopes_above_one_and_below_zero(ctx):
+    """The PReLU epilogue has two forms: max(t, t s) when every slope of the layer is <= 1 (host-checked at model build) and the select
+    t >= 0 ? t : t s otherwise.  Slopes in [-0.5, 1.7] put layers on both; either must match the oracle as the other route does."""
+    import numpy as np
+    t = dict(W.srvgg_table(9, num_feat=64, num_conv=4, upscale=2))
+    rng = np.random.default_rng(4)
+    n_sel = 0
+    for k in list(t):
+        a = np.asarray(t[k])
+        if a.ndim == 1 and k.endswith(".weight"):   # PReLU slopes
+            lo, hi = (-0.5, 1.7) if n_sel % 2 == 0 else (-0.5, 1.0)
+            t[k] = rng.uniform(lo, hi, a.shape).astype(np.float32)
+            n_sel += 1
+    assert n_sel >= 4
+    flat = W.flatten(t, W.srvgg_keys(4))
+    x = torch.rand(2, 3, 40, 70, generator=torch.Generator().manual_seed(2)) - 0.3
+    with torch.no_grad():
+        want = onets.srvgg(x, t, upscale=2, num_conv=4)
+    outs = [_capi.Model(ctx, _capi.make_desc(_capi.SRVGG, _capi.F16, scale=2, num_feat=64, num_block=4, flags=fl), flat)(x.cuda()).cpu()
+            for fl in (NO_W16, 0)]
+    _close(outs[1], outs[0], want, "srvgg, slopes in [-0.5, 1.7]", 60.0)

@@ -12,6 +12,7 @@ from sharkshark4k_amd import _capi
 from sharkshark4k_amd import weights as W
 
 pytestmark = pytest.mark.gpu
+WIDE = _capi.MODEL_NO_W16   # the wide kernel is the route of these layers when conv_w16.hip (the default since round 4, not bit-identical) is off
 NO_WIDE, NO_RS, NO_DENSE, ONE, TWO = _capi.MODEL_NO_WIDE, _capi.MODEL_NO_RS, _capi.MODEL_NO_DENSE, _capi.MODEL_ONE_CHAIN, _capi.MODEL_TWO_CHAINS
 DIRECT_UPS = _capi.MODEL_NO_UPS_PRESUM   # the pre-summed up-sampling convs are the one route that is not bit-identical: pinned off here
 
@@ -27,7 +28,7 @@ def test_wide_bit_identical_rrdbnet(ctx, scale, shape, base):
     # (conv5 pinned to the register-stationary kernel, or routed off it with its residual read from memory: the two forms that exist on both sides)
     for extra in (DIRECT_UPS | _capi.MODEL_CONV5_RS, DIRECT_UPS | NO_RS):
         want = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=2, flags=base | extra | NO_WIDE), flat)(x).clone()
-        m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=2, flags=base | extra), flat)
+        m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=2, flags=base | extra | WIDE), flat)
         for _ in range(2):
             got = m(x)
             assert torch.isfinite(got).all() and torch.equal(got, want), f"{shape} flags {base | extra}: max |d| {float((got - want).abs().max()):.3g}"
@@ -40,7 +41,7 @@ def test_wide_bit_identical_srvgg(ctx, nf, shape, up):
     flat = W.flatten(t, W.srvgg_keys(4))
     x = torch.rand(*shape, generator=torch.Generator().manual_seed(nf + shape[3])).cuda()
     outs = [_capi.Model(ctx, _capi.make_desc(_capi.SRVGG, _capi.F16, scale=up, num_feat=nf, num_block=4, flags=fl), flat)(x).clone()
-            for fl in (NO_WIDE, 0)]
+            for fl in (NO_WIDE, WIDE)]
     assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
 
 
@@ -51,7 +52,7 @@ def test_wide_bit_identical_bsvd(ctx, chns, shape):
     t = W.bsvd_table(5, chns=chns)
     flat = W.flatten(t, W.bsvd_keys(chns=chns))
     x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[2])).cuda()
-    outs = [_capi.Model(ctx, _capi.make_desc(_capi.BSVD, _capi.F16, scale=1, bsvd_chns=chns, flags=fl), flat)(x).clone() for fl in (NO_WIDE, 0)]
+    outs = [_capi.Model(ctx, _capi.make_desc(_capi.BSVD, _capi.F16, scale=1, bsvd_chns=chns, flags=fl), flat)(x).clone() for fl in (NO_WIDE, WIDE)]
     assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
 
 
@@ -79,9 +80,10 @@ def test_ups_presum_vs_direct_and_oracle(ctx, scale, shape):
 
 @pytest.mark.parametrize("shape", [(1, 3, 144, 208), (2, 3, 66, 94)])
 def test_conv5_small_job_route_vs_pinned_and_oracle(ctx, shape):
-    """Jobs with fewer than three rounds of tiles run conv5 of every RDB on the wide kernel with its residual through the matrix core
-    ((conv + x / alpha) * alpha; default) instead of the register-stationary kernel (SS4K_MODEL_CONV5_RS): another order of fp32
-    additions, the same accuracy against the oracle; every RDB (one residual, and two with the block's input written in place)."""
+    """Round-3 routing (SS4K_MODEL_NO_W16): jobs with fewer than three rounds of tiles run conv5 of every RDB on the wide kernel with its
+    residual through the matrix core ((conv + x / alpha) * alpha) instead of the register-stationary kernel (SS4K_MODEL_CONV5_RS): another
+    order of fp32 additions, the same accuracy against the oracle; every RDB (one residual, and two with the block's input written in place).
+    (Default routing: conv_w16.hip's build of the same form for every job size - tests/test_gpu_w16.py.)"""
     from oracle import nets as onets
     from tests.helpers import psnr
     t = W.rrdbnet_table(33, scale=2, num_block=3)
@@ -89,7 +91,7 @@ def test_conv5_small_job_route_vs_pinned_and_oracle(ctx, shape):
     x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[3]))
     with torch.no_grad():
         want = onets.rrdbnet(x, t, 2, 3)
-    small = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=3), flat)(x.cuda()).cpu()
+    small = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=3, flags=WIDE), flat)(x.cuda()).cpu()
     pinned = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=3, flags=_capi.MODEL_CONV5_RS), flat)(x.cuda()).cpu()
     peak = float(want.abs().max())
     p_routes, p_small, p_pinned = psnr(small / peak, pinned / peak), psnr(small / peak, want / peak), psnr(pinned / peak, want / peak)

@@ -1,5 +1,5 @@
-"""Dev tool: the 64-cout single-layer tile on v_mfma_f32_32x32x16_f16 (conv_dense.hip's wide kernel, default) against the same tile on
-v_mfma_f32_16x16x32_f16 (conv_w16.hip, SS4K_MODEL_W16), whole networks, interleaved rounds in one process.
+"""Dev tool: the 64-cout single-layer tile on v_mfma_f32_32x32x16_f16 (conv_dense.hip's wide kernel, SS4K_MODEL_NO_W16) against the same tile on
+v_mfma_f32_16x16x32_f16 (conv_w16.hip, default), whole networks, interleaved rounds in one process.
 usage: python tools/w16_ab.py [frames=4] [rounds=3] [srvgg|rrdbnet|bsvd ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,7 +23,7 @@ for kind in kinds:
         flat = W.flatten(W.bsvd_table(3), W.bsvd_keys())
         mk = lambda fl: _capi.Model(ctx, _capi.make_desc(_capi.BSVD, _capi.F16, scale=1, flags=fl), flat)
         x = torch.rand(n, 4, 720, 1280, device="cuda")
-    ms = {"32x32x16 (wide)": mk(0), "16x16x32 (w16)": mk(_capi.MODEL_W16)}
+    ms = {"32x32x16 (wide)": mk(_capi.MODEL_NO_W16), "16x16x32 (w16)": mk(0)}
     for m in ms.values():
         for _ in range(6): m(x)
     torch.cuda.synchronize()
