@@ -239,6 +239,7 @@ struct DenseArgs {
   const char* in1; size_t in1_plane_bytes; int in1_plane0, nchunks1;
   const char* w1; const float* bias1;                   // conv_k: packed fragments (pack.cpp, nb = 1), 32 biases
   const char* w2; const float* bias2;                   // conv_{k+1}: nchunks0 + nchunks1 + 2 K-chunks
+  const char* w16p;                                     // conv_d16.hip: both layers' fragments (pack.cpp, pack_dense_d16) or null
   float slope;                                          // LeakyReLU of both layers
   char* out1; size_t out1_plane_bytes; int out1_plane0; // x_k (two planes)
   char* out2; size_t out2_plane_bytes; int out2_plane0; // x_{k+1}
@@ -250,6 +251,9 @@ struct DenseArgs {
   unsigned long long* dbg_buf;                          // dev library, SS4K_DENSE_STAMP=1: per-wave phase cycle counters
 };
 bool conv3x3_dense2_eligible(int nchunks_a, int cout_pad_a, int nchunks_b, int cout_pad_b);
+// the same fused pair on v_mfma_f32_16x16x32_f16 (conv_d16.hip): needs DenseArgs.w16p
+bool conv3x3_d16_eligible(int nchunks_a, int cout_pad_a, int nchunks_b, int cout_pad_b);
+void launch_conv3x3_d16(ss4k_ctx* ctx, const DenseArgs& a, hipStream_t st);
 // conv_dense.hip: one layer, 64 couts per workgroup, plain epilogue (bit-identical to conv_mfma.hip's <__half,2,4,4> build)
 struct ConvArgs;
 bool conv3x3_wide_eligible(const ConvArgs& a, int dtype);
@@ -287,6 +291,8 @@ PackedConv pack_conv3x3(const PackSpec& s, const float* w_oihw, const float* bia
 std::vector<uint8_t> pack_conv3x3_rs(const PackSpec& s, const float* w_oihw, int cout_pad, int nch, int cb, int cg);
 // conv_w16.hip weight order (fp16, 64-cout groups, an even number of K-chunks); same virtual cout order / bias as pack_conv3x3
 std::vector<uint8_t> pack_conv3x3_w16(const PackSpec& s, const float* w_oihw, int cout_pad);
+// conv_d16.hip weight order of a dense-block layer pair
+std::vector<uint8_t> pack_dense_d16(const PackSpec& sa, const float* wa, const PackSpec& sb, const float* wb);
 int virt_to_real_cout(const PackSpec& s, int v);
 
 }  // namespace ss4k

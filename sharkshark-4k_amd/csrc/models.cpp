@@ -138,6 +138,18 @@ int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool h
   L.cin_real = 0;
   for (int c : s.cin_map) L.cin_real += c >= 0;
   weight_bytes += p.w.size() + p.bias.size() * 4;
+#ifdef SS4K_DEV
+  // dev experiment (SS4K_D16=1): a dense-block pair (this layer = conv_{k+1} of the previous one) once more in conv_d16.hip's order
+  if (chainable && use_d16 && use_w16 && desc.dtype == SS4K_F16 && !layers.empty() && raw_w_prev && (int)layers.size() == raw_li_prev + 1 &&
+      conv3x3_d16_eligible(layers.back().nchunks0 + layers.back().nchunks1, layers.back().cout_pad, s.nchunks0 + s.nchunks1, p.cout_pad) &&
+      layers.back().nchunks0 == s.nchunks0 && !layers.back().w16p_is_second) {
+    const std::vector<uint8_t> wp = pack_dense_d16(raw_s_prev, raw_w_prev, s, w);
+    upload(layers.back().w16p, wp.data(), wp.size());
+    weight_bytes += wp.size();
+    L.w16p_is_second = true;
+  }
+  raw_w_prev = chainable ? w : nullptr; raw_s_prev = s; raw_li_prev = (int)layers.size();
+#endif
   layers.push_back(std::move(L));
   return (int)layers.size() - 1;
 }
@@ -224,6 +236,7 @@ void Model::build(const float* w, size_t n) {
   if (const char* e = std::getenv("SS4K_WIDE_RL")) wide_rl = e[0] == '1';          // A/B switch: conv5's residual through the matrix core on the wide kernel
   if (const char* e = std::getenv("SS4K_WIDE")) use_wide = e[0] == '1';            // A/B switch: 64-cout layers on conv3x3_wide_kernel
   if (const char* e = std::getenv("SS4K_W16")) use_w16 = e[0] == '1';              // A/B switch: ... on conv3x3_w16_kernel
+  if (const char* e = std::getenv("SS4K_D16")) use_d16 = e[0] == '1';              // A/B switch: fused pairs on conv3x3_d16_kernel
   if (const char* e = std::getenv("SS4K_DENSE_MODE")) dense_mode = std::atoi(e);   // A/B switch: 0 default policy, 1 never, 2 every job
   if (const char* e = std::getenv("SS4K_LANE_GRID")) lane_grid_share = (float)std::atof(e);   // A/B switch: grid of a lane's launch as a share of the chip's slots
   if (const char* e = std::getenv("SS4K_FAIL_AT_CONV")) fail_at_conv = std::atoi(e);   // fault injection: the k-th conv call of every
@@ -448,6 +461,7 @@ bool Model::conv_dense(int li, const Tens& in0, const Tens* in1, int N, int H, i
   if (in1) { a.in1 = in1->p; a.in1_plane_bytes = in1->plane_bytes; a.in1_plane0 = in1->plane0; a.nchunks1 = A.nchunks1; }
   a.w1 = A.w.as<char>(); a.bias1 = A.bias.as<float>();
   a.w2 = B.w.as<char>(); a.bias2 = B.bias.as<float>();
+  a.w16p = A.w16p.ptr ? A.w16p.as<char>() : nullptr;
   a.slope = slope;
   a.out1 = out1.p; a.out1_plane_bytes = out1.plane_bytes; a.out1_plane0 = out1.plane0;
   a.out2 = out2.p; a.out2_plane_bytes = out2.plane_bytes; a.out2_plane0 = out2.plane0;
@@ -461,6 +475,9 @@ bool Model::conv_dense(int li, const Tens& in0, const Tens* in1, int N, int H, i
   }
   if (cur_lanes <= 1 || N != cur_n) {
     a.n0 = 0; a.N = N; a.flops = flops * N;
+#ifdef SS4K_DEV
+    if (a.w16p) { launch_conv3x3_d16(ctx, a, st); return true; }
+#endif
     launch_conv3x3_dense2(ctx, a, st);
     return true;
   }
@@ -473,6 +490,9 @@ bool Model::conv_dense(int li, const Tens& in0, const Tens* in1, int N, int H, i
     a.n0 = N * l / 2; a.N = N * (l + 1) / 2 - a.n0;
     a.grid_share = lane_grid_share;
     a.flops = flops * a.N;
+#ifdef SS4K_DEV
+    if (a.w16p) { launch_conv3x3_d16(ctx, a, l == 0 ? st : ctx->lane_stream()); continue; }
+#endif
     launch_conv3x3_dense2(ctx, a, l == 0 ? st : ctx->lane_stream());
   }
   return true;

@@ -14,8 +14,10 @@ struct ConvLayer {
   DevBuf wch;              // 64-cout fp16 body layers: the weights once more as two 32-cout groups (conv_chain.hip)
   DevBuf wrs;              // conv_rs.hip weight order (fp16 layers of a supported shape, else empty)
   bool rs_wide = false;    // ... packed for the eight-wave variant
+  DevBuf w16p;             // conv_d16.hip: this layer and the next as a fused dense-block pair (first layer of a pair only)
   DevBuf w16;              // conv_w16.hip weight order (fp16 layers with 64-cout groups and an even number of K-chunks, else empty)
   bool has_prelu = false;
+  bool w16p_is_second = false;   // this layer is conv_{k+1} of a packed pair (it cannot start another one)
   bool prelu_le1 = false;  // every slope <= 1 (the epilogue may use max(t, t s))
   int cout_real = 0, cout_pad = 0, cin_real = 0, nchunks0 = 0, nchunks1 = 0;
 };
@@ -87,6 +89,8 @@ struct Model {
   int dense_mode = 0;          // RRDBNet: (conv1, conv2) and (conv3, conv4) of every RDB as one fused launch each (conv_dense.hip): 0 = default (fused),
                                // 1 = never (SS4K_MODEL_NO_DENSE), 2 = forced (SS4K_MODEL_DENSE; the same as the default today)
   bool use_wide = true;        // 64-cout-group fp16 layers with a plain epilogue on conv_dense.hip's single-layer build (SS4K_MODEL_NO_WIDE: conv_mfma.hip's <2,4,4>)
+  bool use_d16 = false;        // dev experiment (SS4K_D16=1, dev library): fused dense-block pairs on conv_d16.hip (v_mfma_f32_16x16x32_f16, 14-row tiles)
+  const float* raw_w_prev = nullptr; PackSpec raw_s_prev{}; int raw_li_prev = -1;   // build(): the previous add_conv's source weights (pair packing)
   bool use_w16 = true;         // ... on conv_w16.hip (v_mfma_f32_16x16x32_f16) where the layer has an even number of K-chunks and no up-sampled input (SS4K_MODEL_NO_W16: never)
   int conv5_mode = 0;          // RDB conv5: 0 = conv_w16.hip with the residual through the matrix core (without the w16 build: conv_rs.hip for jobs of at
                                // least three rounds of tiles, the wide kernel below); 1 = conv_rs.hip for every size (SS4K_MODEL_CONV5_RS)

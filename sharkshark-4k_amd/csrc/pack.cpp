@@ -160,4 +160,42 @@ std::vector<uint8_t> pack_conv3x3_w16(const PackSpec& s, const float* w, int cou
   return out;
 }
 
+#ifdef SS4K_DEV
+// conv_d16.hip: a dense-block layer pair (conv_k: K1 planes -> 32 couts; conv_{k+1}: the same K1 planes + x_k's two -> 32 couts) as
+// v_mfma_f32_16x16x32_f16 A fragments.  K1 / 2 chunk pairs of three 12 KB phases [dy][conv_k b0, conv_{k+1} b0, conv_k b1, conv_{k+1} b1][lane][8],
+// then conv_{k+1}'s x_k chunk pair as three 6 KB phases [dy][b0, b1][lane][8].  Phases and k-groups as pack_conv3x3_w16; row m of block b is
+// cout 16 b + m (result lane (pixel, row group rg) holds channels 4 rg .. 4 rg + 3 of plane b).
+std::vector<uint8_t> pack_dense_d16(const PackSpec& sa, const float* wa, const PackSpec& sb, const float* wb) {
+  SS4K_REQUIRE(sa.dtype == SS4K_F16 && sb.dtype == SS4K_F16, "pack_dense_d16: fp16 only");
+  const int k1 = sa.nchunks0 + sa.nchunks1, k2 = sb.nchunks0 + sb.nchunks1;
+  SS4K_REQUIRE(k1 % 2 == 0 && k2 == k1 + 2 && (int)sa.cin_map.size() == k1 * 16 && (int)sb.cin_map.size() == k2 * 16, "pack_dense_d16: shape");
+  std::vector<uint8_t> out((size_t)(k1 / 2) * 3 * 12288 + 3 * 6144, 0);
+  size_t idx = 0;
+  auto put = [&](const PackSpec& s, const float* w, int blk, int q, int ph, int dy, int lane) {
+    const int m = lane & 15, kq = lane >> 4;
+    const int co = virt_to_real_cout(s, 16 * blk + m);
+    const int plane = ph == 0 ? 2 * q : ph == 1 ? 2 * q + (kq >> 1) : 2 * q + 1;
+    const int dx = ph == 1 ? 2 : (kq >> 1);
+    for (int e = 0; e < 8; ++e, ++idx) {
+      const int ci = s.cin_map[(size_t)plane * 16 + 8 * (kq & 1) + e];
+      float val = 0.f;
+      if (ci >= 0 && co >= 0) val = w[((size_t)co * s.cin_total + ci) * 9 + dy * 3 + dx];
+      const uint16_t h = f32_to_f16_bits(val);
+      std::memcpy(&out[idx * 2], &h, 2);
+    }
+  };
+  for (int q = 0; q < k1 / 2; ++q)
+    for (int ph = 0; ph < 3; ++ph)
+      for (int dy = 0; dy < 3; ++dy)
+        for (int t = 0; t < 4; ++t)   // table entry t: layer t & 1 (0 = conv_k), block t >> 1
+          for (int lane = 0; lane < 64; ++lane) put((t & 1) ? sb : sa, (t & 1) ? wb : wa, t >> 1, q, ph, dy, lane);
+  for (int ph = 0; ph < 3; ++ph)
+    for (int dy = 0; dy < 3; ++dy)
+      for (int blk = 0; blk < 2; ++blk)
+        for (int lane = 0; lane < 64; ++lane) put(sb, wb, blk, k1 / 2, ph, dy, lane);
+  SS4K_REQUIRE(idx * 2 == out.size(), "pack_dense_d16: size");
+  return out;
+}
+#endif  // SS4K_DEV
+
 }  // namespace ss4k

@@ -20,8 +20,12 @@ pytestmark = pytest.mark.gpu
 NO_DENSE, DENSE, ONE, TWO = _capi.MODEL_NO_DENSE, _capi.MODEL_DENSE, _capi.MODEL_ONE_CHAIN, _capi.MODEL_TWO_CHAINS
 
 
+PIN32 = _capi.MODEL_NO_W16   # this file tests conv_dense.hip (v_mfma_f32_32x32x16_f16: bit-identical to four launches of conv_mfma.hip); the default
+                             # fused route since round 4 is conv_d16.hip (16x16x32, another summation order): tests/test_gpu_d16.py
+
+
 def _model(ctx, flat, scale, nb, flags):
-    return _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=nb, flags=flags), flat)
+    return _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=nb, flags=flags | PIN32), flat)
 
 
 # shapes: interior grid (h / r, w / r) with 1 .. many tiles of 16 x 30, ragged right / bottom edges, widths just below / at / above
@@ -77,6 +81,6 @@ def test_dense_pair_other_widths_bit_identical(ctx, nf, g):
     x = torch.rand(2, 3, 72, 136, generator=torch.Generator().manual_seed(nf + g)).cuda()
     outs = []
     for fl in (NO_DENSE | ONE, DENSE | ONE):
-        m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_feat=nf, num_block=1, num_grow_ch=g, flags=fl), flat)
+        m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_feat=nf, num_block=1, num_grow_ch=g, flags=fl | PIN32), flat)
         outs.append(m(x).clone())
     assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
