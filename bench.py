@@ -40,9 +40,9 @@ PMC_TRAFFIC_FILE = "conv3x3_pmc_traffic_current.json"  # written by tools/collec
 ALGORITHMIC_BYTES_PER_FRAME, ALGORITHMIC_WEIGHT_BYTES = 2_764_800 + 11_059_200, 33.4e6
 HBM_SPEC_GBS, HBM_ACHIEVABLE_GBS = 8000.0, 6290.0  # MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured (float4 copy)
 CONV_KERNEL_NAME = ("3x3 implicit-GEMM conv, all launches of a step: ss4k::dense::conv3x3_dense2_kernel<4|8> (fused layer pairs "
-                    "(conv1, conv2) / (conv3, conv4) of every RDB, v_mfma_f32_32x32x16_f16) + ss4k::rs::conv3x3_rs_kernel<6,16,1,4> "
-                    "(register-stationary weights, v_mfma_f32_16x16x32_f16; conv5 of every RDB) + ss4k::conv3x3_kernel<__half,NB> "
-                    "(LDS weights; first / trunk / tail layers)")
+                    "(conv1, conv2) / (conv3, conv4) of every RDB, v_mfma_f32_32x32x16_f16) + ss4k::w16::conv3x3_w16_kernel "
+                    "(64-cout tile on v_mfma_f32_16x16x32_f16: conv5 of every RDB with its residual through the matrix core, trunk, conv_hr) "
+                    "+ ss4k::wide::conv3x3_wide_kernel<true> (conv_up1 / conv_up2) + ss4k::conv3x3_kernel<__half,1> (first / last layer)")
 LAUNCHES_PER_FRAME = 213  # 23 blocks x 3 RDBs x (2 fused pairs + conv5) + conv_first, conv_body, conv_up1, conv_up2, conv_hr, conv_last
 
 WORKLOADS = {

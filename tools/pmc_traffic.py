@@ -1,13 +1,13 @@
 """Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/<round>_conv3x3_pmc_traffic.json.
 usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> <frames_per_launch> <steps_run> <frames_per_step>
 Counts the dispatches of the 3x3 conv kernels (conv3x3_kernel = LDS weights, conv3x3_rs_kernel = register-stationary weights,
-conv3x3_dense2_kernel = fused dense-block layer pairs, conv3x3_wide_kernel = one 64-cout layer on the fused kernel's machinery) - the same launches bench.py's roofline leg times; FETCH_SIZE is doubled per
+conv3x3_dense2_kernel = fused dense-block layer pairs, conv3x3_wide_kernel / conv3x3_w16_kernel = one 64-cout layer on the fused kernel's machinery, 32x32x16 / 16x16x32 MFMA) - the same launches bench.py's roofline leg times; FETCH_SIZE is doubled per
 MI355X_MICROARCH.md (HBM section).  The figure bench.py uses is bytes per STEP (all conv launches of a step together): the
 kernels differ too much for a per-launch average to mean anything."""
 import csv, glob, json, sys
 from collections import defaultdict
 
-FAMILIES = ("conv3x3_rs_kernel", "conv3x3_dense2_kernel", "conv3x3_wide_kernel", "conv3x3_kernel")
+FAMILIES = ("conv3x3_rs_kernel", "conv3x3_dense2_kernel", "conv3x3_w16_kernel", "conv3x3_wide_kernel", "conv3x3_kernel")
 
 
 def per_dispatch(d, counter):
