@@ -1,4 +1,5 @@
-"""Dev tool: run one SRVGG x4 720p model variant in a loop for some seconds (flags from argv) - for sampling rocm-smi beside it."""
+"""Dev tool: run one SRVGG x4 720p model variant in a loop for some seconds (model flags and seconds from argv) - for sampling rocm-smi
+beside it (tools/power_sample.sh).  usage: python tools/power_loop.py <flags> <seconds>"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
