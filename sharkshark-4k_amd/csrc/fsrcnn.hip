@@ -811,6 +811,13 @@ __global__ __launch_bounds__(256, 2) void k_fs_head_m(const float* __restrict__ 
 constexpr int FM_U = 3, FM_COLS = 16 * FM_U, FM_HALO = 4, FM_CI = FM_COLS - 2 * FM_HALO, FM_RW = FM_COLS + 2;
 constexpr int FM_ROWB = FM_RW * 64, FM_STAGEB = 4 * FM_ROWB, FM_LDS = 4 * FM_STAGEB;
 struct FsMapW { const float* w[4]; const float* b[4]; const float* a[4]; };
+// The four 16-byte slots of ring column c (hi 0-7, hi 8-15, lo 0-7, lo 8-15) sit at slot ^ fm_swz(c).  A ds_read_b128 pass serves lanes
+// {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of a half-wave = sixteen consecutive columns with slot bits (0 x 4, 1 x 8, 0 x 4): the four
+// columns of a pass that share c & 3 must land in four different slots.  (c >> 2) & 3 (rounds 2-3) gives two of them the same one for
+// every tap: SQ_LDS_BANK_CONFLICT was 49 % of the kernel's LDS cycles and the LDS, shared by twelve waves, was the busiest unit of the CU.
+// 2 ((c >> 2) & 1) is conflict-free for the reads at all three dx (enumerated, tools/costing/fm_swizzle.py); the 8-byte stores of a row
+// (a fifth of the reads' volume) become 2-way.
+__device__ __forceinline__ int fm_swz(int c) { return ((c >> 2) & 1) << 1; }
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ in, float* __restrict__ out, const FsMapW W,
@@ -856,13 +863,13 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
   for (int ks = 0; ks < 5; ++ks) {
     const int tap = min(2 * ks + (q >> 1), 8);   // the tenth tap does not exist: its weights are zero, read the ninth's pixel
     const int dy = tap / 3, dx = tap % 3, cc = n + dx;   // ring column of unit 0 (image column x0 - 8 + n + dx - 1)
-    const int sw = (cc >> 2) & 3;
+    const int sw = fm_swz(cc);
     dyi[ks] = dy;
     col_hi[ks] = cc * 64 + (((q & 1) ^ sw) << 4);
     col_lo[ks] = cc * 64 + (((2 + (q & 1)) ^ sw) << 4);
   }
   // where this lane's output lands in the next ring: column n + 1 of unit 0, slot q >> 1 (hi) / 2 + (q >> 1) (lo), bytes 8*(q&1)
-  const int wsw = ((n + 1) >> 2) & 3;
+  const int wsw = fm_swz(n + 1);
   const int wr_hi = (n + 1) * 64 + ((((q >> 1)) ^ wsw) << 4) + 8 * (q & 1);
   const int wr_lo = (n + 1) * 64 + (((2 + (q >> 1)) ^ wsw) << 4) + 8 * (q & 1);
 
@@ -872,7 +879,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
   // input loader: thread tid < 144 moves channel group g = tid / 48 of ring column c = tid % 48 (+1) of one input row
   const int lg = tid / FM_COLS, lc = tid % FM_COLS, lx = x0 - FM_HALO + lc;
   const bool loader = tid < 3 * FM_COLS, lcol_ok = lx >= 0 && lx < w;
-  const int lsw = ((lc + 1) >> 2) & 3;
+  const int lsw = fm_swz(lc + 1);
   const int ld_hi = (lc + 1) * 64 + (((lg >> 1) ^ lsw) << 4) + 8 * (lg & 1);
   const int ld_lo = (lc + 1) * 64 + (((2 + (lg >> 1)) ^ lsw) << 4) + 8 * (lg & 1);
   // unconditional loads (address clamped into the image, zero selected when the row is stored): a load under a branch makes hipcc wait
