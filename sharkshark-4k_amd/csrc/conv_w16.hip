@@ -306,7 +306,6 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_w16_kernel(const ConvArgs 
       // one copy of the store loop per epilogue form (a single loop with the forms selected per value compiled to eleven vector
       // instructions per value: every form evaluated, the result picked with v_cndmask)
       //   0: t >= 0 ? t : t * slope (PReLU per channel)   1: max(t, t * slope) (LeakyReLU, slope in [0, 1]; none: slope 1)   2: ReLU6
-      //   3: any activation, then * alpha + res1, * gamma + res2
       auto stores = [&](auto FORM, auto ALPHA1) {
         constexpr int form = decltype(FORM)::value;
         constexpr bool alpha1 = decltype(ALPHA1)::value;   // alpha == 1: no multiply (x * 1.0f is x)
@@ -319,12 +318,54 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_w16_kernel(const ConvArgs 
             const bool ok = y < a.H && x < a.W;
             const size_t rec = (((size_t)cur_n * a.H + y) * a.W + x) * REC;
             float v[8];
-            if constexpr (form == 3) {
-              float r1[8], r2[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const float t = i < 4 ? acc[r][hn][0][i] : acc[r][hn][1][i - 4];
+              float u;
+              if constexpr (form == 0) { const float neg = t * slope_v[i]; u = t >= 0.f ? t : neg; }
+              else if constexpr (form == 1) {
+                const float st = t * slope_v[i];
+                asm("v_max_f32 %0, %1, %2" : "=v"(u) : "v"(t), "v"(st));   // = fmaxf(t, st) for every non-NaN input, one instruction
+              } else u = __builtin_amdgcn_fmed3f(t, 0.f, 6.f);
+              v[i] = alpha1 ? u : u * alpha;
+            }
+            if (ok) store8<__half>(outp + rec, v);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      // Residual epilogues (any activation, then * alpha + res1, * gamma + res2; absent residuals add nothing).  The residual records of
+      // FOUR rows (two with both residuals) are requested together, unconditionally (coordinates clamped into the image: a load under a branch makes hipcc wait with
+      // vmcnt(0) right behind it - sixteen exposed round trips per tile, + 12 % on conv5 of every third RDB), then the four rows are stored.
+      auto stores_res = [&](auto R1T, auto R2T) {
+        constexpr bool R1 = decltype(R1T)::value, R2 = decltype(R2T)::value;
+        constexpr int RB = (R1 && R2) ? 2 : 4;   // rows per request: 8 registers per row and residual next to 128 accumulators
+#pragma unroll
+        for (int r0 = 0; r0 < MB; r0 += RB) {
+          uint4 q1[RB][2], q2[RB][2];
+#pragma unroll
+          for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+            for (int hn = 0; hn < 2; ++hn) {
+              const int yc = min(cur_y0 + rgp * MB + r0 + rr, a.H - 1), xc = min(cur_x0 + 16 * hn + n16, a.W - 1);
+              const size_t recc = (((size_t)cur_n * a.H + yc) * a.W + xc) * REC;
+              if constexpr (R1) q1[rr][hn] = *reinterpret_cast<const uint4*>(r1p + recc);
+              if constexpr (R2) q2[rr][hn] = *reinterpret_cast<const uint4*>(r2p + recc);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int rr = 0; rr < RB; ++rr) {
+            const int r = r0 + rr, y = cur_y0 + rgp * MB + r;
+#pragma unroll
+            for (int hn = 0; hn < 2; ++hn) {
+              const int x = cur_x0 + 16 * hn + n16;
+              const bool ok = y < a.H && x < a.W;
+              const size_t rec = (((size_t)cur_n * a.H + y) * a.W + x) * REC;
+              float r1[8], r2[8], v[8];
 #pragma unroll
               for (int i = 0; i < 8; ++i) { r1[i] = 0.f; r2[i] = 0.f; }
-              if (r1p && ok) load8<__half>(r1p + rec, r1);
-              if (r2p && ok) load8<__half>(r2p + rec, r2);
+              if constexpr (R1) load8<__half>(reinterpret_cast<const char*>(&q1[rr][hn]), r1);
+              if constexpr (R2) load8<__half>(reinterpret_cast<const char*>(&q2[rr][hn]), r2);
 #pragma unroll
               for (int i = 0; i < 8; ++i) {
                 float t = i < 4 ? acc[r][hn][0][i] : acc[r][hn][1][i - 4];
@@ -334,20 +375,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_w16_kernel(const ConvArgs 
                 t = t * alpha + r1[i];
                 v[i] = t * gamma + r2[i];   // (conv_dense.hip's wide kernel, the same expressions)
               }
-            } else {
-#pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                const float t = i < 4 ? acc[r][hn][0][i] : acc[r][hn][1][i - 4];
-                float u;
-                if constexpr (form == 0) { const float neg = t * slope_v[i]; u = t >= 0.f ? t : neg; }
-                else if constexpr (form == 1) {
-                  const float st = t * slope_v[i];
-                  asm("v_max_f32 %0, %1, %2" : "=v"(u) : "v"(t), "v"(st));   // = fmaxf(t, st) for every non-NaN input, one instruction
-                } else u = __builtin_amdgcn_fmed3f(t, 0.f, 6.f);
-                v[i] = alpha1 ? u : u * alpha;
-              }
+              if (ok) store8<__half>(outp + rec, v);
             }
-            if (ok) store8<__half>(outp + rec, v);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -355,7 +384,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_w16_kernel(const ConvArgs 
       // PReLU with every slope of the layer <= 1 (host-checked, ConvArgs.prelu_le1): t >= 0 ? t : t s  ==  max(t, t s), one instruction less per value
       const bool max_form = a.act != ACT_PRELU || a.prelu_le1;
       const bool a1 = alpha == 1.f;
-      if (resid) stores(std::integral_constant<int, 3>{}, std::false_type{});
+      if (r1p && r2p) stores_res(std::true_type{}, std::true_type{});
+      else if (r1p) stores_res(std::true_type{}, std::false_type{});
+      else if (r2p) stores_res(std::false_type{}, std::true_type{});
       else if (a.act == ACT_RELU6) stores(std::integral_constant<int, 2>{}, std::false_type{});
       else if (max_form) { if (a1) stores(std::integral_constant<int, 1>{}, std::true_type{}); else stores(std::integral_constant<int, 1>{}, std::false_type{}); }
       else { if (a1) stores(std::integral_constant<int, 0>{}, std::true_type{}); else stores(std::integral_constant<int, 0>{}, std::false_type{}); }
