@@ -262,6 +262,9 @@ void launch_conv3x3_dense2(ss4k_ctx* ctx, const DenseArgs& a, hipStream_t st);
 // the same single-layer tile on v_mfma_f32_16x16x32_f16 (conv_w16.hip): needs ConvArgs.w16
 bool conv3x3_w16_eligible(const ConvArgs& a, int dtype);
 void launch_conv3x3_w16(ss4k_ctx* ctx, const ConvArgs& a, hipStream_t st);
+// ... and its one-block build for layers with <= 4 output channels handed over as NCHW fp32 (conv_w16n.hip: RRDBNet's conv_last)
+bool conv3x3_w16n_eligible(const ConvArgs& a, int dtype);
+void launch_conv3x3_w16n(ss4k_ctx* ctx, const ConvArgs& a, hipStream_t st);
 
 int conv_cw(int dtype);  // channels per plane / K-chunk: 16
 // three-stage-ring build of the 32-cout tile body (conv_s3.hip)
@@ -291,6 +294,7 @@ PackedConv pack_conv3x3(const PackSpec& s, const float* w_oihw, const float* bia
 std::vector<uint8_t> pack_conv3x3_rs(const PackSpec& s, const float* w_oihw, int cout_pad, int nch, int cb, int cg);
 // conv_w16.hip weight order (fp16, 64-cout groups, an even number of K-chunks); same virtual cout order / bias as pack_conv3x3
 std::vector<uint8_t> pack_conv3x3_w16(const PackSpec& s, const float* w_oihw, int cout_pad);
+std::vector<uint8_t> pack_conv3x3_w16n(const PackSpec& s, const float* w_oihw);   // one 16-cout block (conv_w16n.hip)
 // conv_d16.hip weight order of a dense-block layer pair
 std::vector<uint8_t> pack_dense_d16(const PackSpec& sa, const float* wa, const PackSpec& sb, const float* wb);
 int virt_to_real_cout(const PackSpec& s, int v);

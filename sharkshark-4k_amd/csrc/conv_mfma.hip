@@ -737,6 +737,8 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
   // fp16 layers of a supported shape with a plain epilogue: register-stationary weights on the 16x16x32 MFMA
   if (a.wrs && dtype == SS4K_F16 && !a.dbg && a.epi == EPI_NHWC && !a.bsvd_resid && a.act != ACT_RELU6) {
     launch_conv3x3_rs(ctx, a, st);
+  } else if (nb == 1 && conv3x3_w16n_eligible(a, dtype)) {
+    launch_conv3x3_w16n(ctx, a, st);   // <= 4 output channels, NCHW fp32 hand-off: one 16-cout block on the 16x16x32 MFMA (conv_w16n.hip)
   } else if (a.wide && nb == 2 && conv3x3_w16_eligible(a, dtype)) {
     launch_conv3x3_w16(ctx, a, st);    // the same tile on the 16x16x32 MFMA (conv_w16.hip; the layer has a w16 blob)
   } else if (a.wide && nb == 2 && conv3x3_wide_eligible(a, dtype)) {

@@ -126,6 +126,11 @@ int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool h
     upload(L.w16, w6.data(), w6.size());
     weight_bytes += w6.size();
   }
+  if (use_w16 && desc.dtype == SS4K_F16 && cout <= 4 && (s.nchunks0 + s.nchunks1) % 2 == 0 && !s.ps2) {   // conv_w16n.hip (a final 64 -> 3 layer)
+    const std::vector<uint8_t> w6 = pack_conv3x3_w16n(s, w);
+    upload(L.w16, w6.data(), w6.size());
+    weight_bytes += w6.size();
+  }
   if (chainable && chain_mode == 2 && desc.dtype == SS4K_F16 && p.nb == 2) {
     PackSpec s1 = s; s1.force_nb1 = 1;
     const PackedConv p1 = pack_conv3x3(s1, w, b, a);

@@ -160,6 +160,32 @@ std::vector<uint8_t> pack_conv3x3_w16(const PackSpec& s, const float* w, int cou
   return out;
 }
 
+// conv_w16n.hip: a layer with at most 16 output channels as ONE 16-row MFMA block, [pair of K-chunks q][phase][dy][lane][8 fp16]; phases and
+// k-groups as pack_conv3x3_w16; row m is output channel m
+std::vector<uint8_t> pack_conv3x3_w16n(const PackSpec& s, const float* w) {
+  SS4K_REQUIRE(s.dtype == SS4K_F16 && s.cout_real <= 16 && !s.ps2, "pack_conv3x3_w16n: fp16, at most 16 output channels");
+  const int nplanes = s.nchunks0 + s.nchunks1;
+  SS4K_REQUIRE((int)s.cin_map.size() == nplanes * 16 && nplanes % 2 == 0, "pack_conv3x3_w16n: shape");
+  std::vector<uint8_t> out((size_t)(nplanes / 2) * 3 * 3 * 64 * 8 * 2, 0);
+  size_t idx = 0;
+  for (int q = 0; q < nplanes / 2; ++q)
+    for (int ph = 0; ph < 3; ++ph)
+      for (int dy = 0; dy < 3; ++dy)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int m = lane & 15, kq = lane >> 4;
+          const int plane = ph == 0 ? 2 * q : ph == 1 ? 2 * q + (kq >> 1) : 2 * q + 1;
+          const int dx = ph == 1 ? 2 : (kq >> 1);
+          for (int e = 0; e < 8; ++e, ++idx) {
+            const int ci = s.cin_map[(size_t)plane * 16 + 8 * (kq & 1) + e];
+            float val = 0.f;
+            if (ci >= 0 && m < s.cout_real) val = w[((size_t)m * s.cin_total + ci) * 9 + dy * 3 + dx];
+            const uint16_t h = f32_to_f16_bits(val);
+            std::memcpy(&out[idx * 2], &h, 2);
+          }
+        }
+  return out;
+}
+
 #ifdef SS4K_DEV
 // conv_d16.hip: a dense-block layer pair (conv_k: K1 planes -> 32 couts; conv_{k+1}: the same K1 planes + x_k's two -> 32 couts) as
 // v_mfma_f32_16x16x32_f16 A fragments.  K1 / 2 chunk pairs of three 12 KB phases [dy][conv_k b0, conv_{k+1} b0, conv_k b1, conv_{k+1} b1][lane][8],
