@@ -12,7 +12,8 @@ from sharkshark4k_amd import _capi
 from sharkshark4k_amd import weights as W
 
 pytestmark = pytest.mark.gpu
-WIDE = _capi.MODEL_NO_W16   # the wide kernel is the route of these layers when conv_w16.hip (the default since round 4, not bit-identical) is off
+WIDE = _capi.MODEL_NO_W16   # the wide kernel is the route of these layers when conv_w16.hip (the default since round 4, not bit-identical) is off;
+                            # set on BOTH sides: it also keeps conv_last off conv_w16n.hip
 NO_WIDE, NO_RS, NO_DENSE, ONE, TWO = _capi.MODEL_NO_WIDE, _capi.MODEL_NO_RS, _capi.MODEL_NO_DENSE, _capi.MODEL_ONE_CHAIN, _capi.MODEL_TWO_CHAINS
 DIRECT_UPS = _capi.MODEL_NO_UPS_PRESUM   # the pre-summed up-sampling convs are the one route that is not bit-identical: pinned off here
 
@@ -27,7 +28,7 @@ def test_wide_bit_identical_rrdbnet(ctx, scale, shape, base):
     x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[2] * 7 + shape[3])).cuda()
     # (conv5 pinned to the register-stationary kernel, or routed off it with its residual read from memory: the two forms that exist on both sides)
     for extra in (DIRECT_UPS | _capi.MODEL_CONV5_RS, DIRECT_UPS | NO_RS):
-        want = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=2, flags=base | extra | NO_WIDE), flat)(x).clone()
+        want = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=2, flags=base | extra | NO_WIDE | WIDE), flat)(x).clone()
         m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=2, flags=base | extra | WIDE), flat)
         for _ in range(2):
             got = m(x)
@@ -41,7 +42,7 @@ def test_wide_bit_identical_srvgg(ctx, nf, shape, up):
     flat = W.flatten(t, W.srvgg_keys(4))
     x = torch.rand(*shape, generator=torch.Generator().manual_seed(nf + shape[3])).cuda()
     outs = [_capi.Model(ctx, _capi.make_desc(_capi.SRVGG, _capi.F16, scale=up, num_feat=nf, num_block=4, flags=fl), flat)(x).clone()
-            for fl in (NO_WIDE, WIDE)]
+            for fl in (NO_WIDE | WIDE, WIDE)]
     assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
 
 
@@ -52,7 +53,7 @@ def test_wide_bit_identical_bsvd(ctx, chns, shape):
     t = W.bsvd_table(5, chns=chns)
     flat = W.flatten(t, W.bsvd_keys(chns=chns))
     x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[2])).cuda()
-    outs = [_capi.Model(ctx, _capi.make_desc(_capi.BSVD, _capi.F16, scale=1, bsvd_chns=chns, flags=fl), flat)(x).clone() for fl in (NO_WIDE, WIDE)]
+    outs = [_capi.Model(ctx, _capi.make_desc(_capi.BSVD, _capi.F16, scale=1, bsvd_chns=chns, flags=fl), flat)(x).clone() for fl in (NO_WIDE | WIDE, WIDE)]
     assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
 
 
