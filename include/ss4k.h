@@ -101,7 +101,8 @@ enum {
   SS4K_MODEL_DENSE = 2048,      /* ... fused pairs pinned (today's default; a test or caller that must not follow a later change of
                                    the default policy sets it) */
   SS4K_MODEL_NO_WIDE = 4096,    /* fp16 layers with 64-cout groups and a plain epilogue (RRDBNet trunk / tail, SRVGG body, BSVD) on
-                                   conv_mfma.hip's <2,4,4> build instead of conv_dense.hip's single-layer build; bit-identical results */
+                                   conv_mfma.hip's <2,4,4> build - neither conv_dense.hip's single-layer build (bit-identical to it) nor
+                                   conv_w16.hip's (see SS4K_MODEL_NO_W16) */
   SS4K_MODEL_NO_UPS_PRESUM = 8192, /* RRDBNet fp16: conv_up1 / conv_up2 (3x3 convs on a nearest-x2 up-sampled tensor) in the direct form.
                                    Default: two of the three input rows an output row reads are the same low-resolution row, so their two
                                    MFMAs per tap column run as one with the weight fragments added in fp16 (6 instead of 9 MFMAs per
