@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -33,11 +34,20 @@ struct Error : std::runtime_error {
     if (!(cond)) throw ::ss4k::Error(SS4K_EINVAL, std::string(msg));   \
   } while (0)
 
-// A device allocation owned by the context; grows on demand, never shrinks (no hipMalloc in
-// steady state: shapes repeat frame after frame).
+// A device allocation owned by the object that holds it (a context's scratch, a model's layers and activations) and freed with it;
+// movable, never copied; grows on demand, never shrinks (no hipMalloc in steady state: shapes repeat frame after frame).
 struct DevBuf {
   void* ptr = nullptr;
   size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : ptr(o.ptr), bytes(o.bytes) { o.ptr = nullptr; o.bytes = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { release(); ptr = o.ptr; bytes = o.bytes; o.ptr = nullptr; o.bytes = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
   void ensure(size_t need) {
     if (need <= bytes) return;
     if (ptr) { (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
@@ -144,6 +154,8 @@ struct ConvArgs {
   int N, H, W;                          // conv grid (== output grid before SUB2/PS2)
   int n0;                               // first frame of this launch inside the tensors (frame lanes: a job's frames split
                                         // over concurrent launches); N counts this launch's frames
+  int job_n;                            // frames of the whole job these tensors hold (0: n0 + N).  Kernels that keep 32-bit byte offsets inside a
+                                        // plane are chosen on THIS - the same kernel for every launch chain of a job, whatever its n0
   float grid_share;                     // size the persistent grid for this share of the chip's workgroup slots (0 = all)
   int mb_override;                      // 0: tile height of the 32-cout layers by image height; 4 / 5: rows per wave forced (A/B)
   int s3;                               // 32-cout layers without residuals on the three-stage kernel (conv_s3.hip)
@@ -173,6 +185,8 @@ struct ConvArgs {
   int dbg;                              // selects an ablation build (ss4k_bench_conv only; 0 in production)
   unsigned long long* dbg_buf;          // DBG_STAMP: per-workgroup phase cycle counters
 };
+// bytes of the fp16 plane a launch's pixel offsets must reach: all frames of the job, not only this launch's (frame lanes: lane 1 starts at n0 = N / 2)
+inline double conv_plane_span_f16(const ConvArgs& a) { return (double)std::max(a.n0 + a.N, a.job_n) * a.H * a.W * 32.0; }
 enum { DBG_NO_STORE = 1, DBG_NO_MMA = 2, DBG_NO_TILE_DMA = 4, DBG_NO_W_DMA = 8, DBG_NO_EPILOGUE = 16, DBG_STAMP = 32 };  // | tile-shape id << 8 (ss4k_bench_conv)
 
 // ---- cross-layer execution of a chain of plain 32-cout-wide convs as ONE persistent launch (conv_chain.hip) -------------

@@ -378,7 +378,7 @@ void launch_conv3x3_d16(ss4k_ctx* ctx, const DenseArgs& a0, hipStream_t st) {
   SS4K_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.w16p, "dense pair (d16): empty grid or no weights");
   SS4K_REQUIRE((a.nchunks0 + a.nchunks1) % 2 == 0 && a.nchunks0 + a.nchunks1 >= 2, "dense pair: conv_k needs an even number of K-chunks");
   SS4K_REQUIRE(a.slope >= 0.f && a.slope <= 1.f, "dense pair: LeakyReLU slope must be in [0,1]");
-  SS4K_REQUIRE((double)a.N * a.H * a.W * 32.0 < 4294967296.0, "dense pair: a plane holds at most 4 GB");
+  SS4K_REQUIRE((double)(a.n0 + a.N) * a.H * a.W * 32.0 < 4294967296.0, "dense pair: a plane holds at most 4 GB");
   a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = (a.H + TH - 1) / TH;
   a.zero_page = ctx->zero_page();
   const int ntiles = a.N * a.tiles_y * a.tiles_x;

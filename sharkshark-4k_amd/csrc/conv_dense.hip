@@ -29,6 +29,7 @@
 // Results are BIT-IDENTICAL to the four launches on the LDS-weights kernel (tests/test_gpu_dense_pair.py): same packed fragments, fp32
 // accumulators start from the bias, MFMAs per output in (K-chunk, dx, dy) order, LeakyReLU as max(t, slope t), round-to-nearest fp16.
 #include "common.h"
+#include <cmath>
 #include "conv_tile.h"
 
 namespace ss4k {
@@ -780,7 +781,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_wide_kernel(const ConvArgs
 
 bool conv3x3_wide_eligible(const ConvArgs& a, int dtype) {
   return dtype == SS4K_F16 && a.epi == EPI_NHWC && !a.bsvd_resid && !a.dbg && a.cout_pad >= 64 && a.cout_pad % 64 == 0 &&
-         (double)a.N * a.H * a.W * 32.0 < 4294967296.0 && (!a.ups2 || (a.H % 2 == 0 && a.W % 2 == 0));
+         conv_plane_span_f16(a) < 4294967296.0 && (!a.ups2 || (a.H % 2 == 0 && a.W % 2 == 0));
 }
 
 void launch_conv3x3_wide(ss4k_ctx* ctx, const ConvArgs& a0, hipStream_t st) {
@@ -798,7 +799,10 @@ void launch_conv3x3_wide(ss4k_ctx* ctx, const ConvArgs& a0, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(gx, groups), dim3(64 * NW), LDS_BYTES, st, a);
   };
   // conv5 of an RDB with its residual through the matrix core (RL): res1 must be the conv's own input tensor = its first four planes
-  const bool rl = a.wide_rl && a.res1 && a.act == ACT_NONE && a.alpha != 0.f && a.nchunks0 == 4 && a.cout_pad == 64 && !a.ups2 &&
+  // ... and 1 / alpha must be an fp16 number (the identity fragment carries it: RRDBNet's 0.2 -> 5.0); any other alpha would scale the skip
+  // tensor by 1 +- 2^-11 on top of the output rounding, so it takes the epilogue that reads the residual from memory
+  const bool alpha_exact = a.alpha != 0.f && std::fabs(__half2float(__float2half(1.f / a.alpha)) * a.alpha - 1.f) <= 1.2e-7f;
+  const bool rl = a.wide_rl && a.res1 && a.act == ACT_NONE && alpha_exact && a.nchunks0 == 4 && a.cout_pad == 64 && !a.ups2 &&
                   a.res1 + (size_t)a.r1_plane0 * a.r1_plane_bytes == a.in0 + (size_t)a.in0_plane0 * a.in0_plane_bytes &&
                   a.r1_plane_bytes == a.in0_plane_bytes;
   if (rl) go(&conv3x3_wide_kernel<false, true>);
@@ -817,7 +821,7 @@ void launch_conv3x3_dense2(ss4k_ctx* ctx, const DenseArgs& a0, hipStream_t st) {
   SS4K_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0, "dense pair: empty grid");
   SS4K_REQUIRE((a.nchunks0 + a.nchunks1) % 2 == 0 && a.nchunks0 + a.nchunks1 >= 2, "dense pair: conv_k needs an even number of K-chunks");
   SS4K_REQUIRE(a.slope >= 0.f && a.slope <= 1.f, "dense pair: LeakyReLU slope must be in [0,1]");
-  SS4K_REQUIRE((double)a.N * a.H * a.W * 32.0 < 4294967296.0, "dense pair: a plane holds at most 4 GB");
+  SS4K_REQUIRE((double)(a.n0 + a.N) * a.H * a.W * 32.0 < 4294967296.0, "dense pair: a plane holds at most 4 GB");
   a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = (a.H + TH - 1) / TH;
   a.zero_page = ctx->zero_page();
   const int ntiles = a.N * a.tiles_y * a.tiles_x;

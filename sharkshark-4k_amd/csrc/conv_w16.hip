@@ -24,6 +24,7 @@
 // Results: NOT bit-identical to the 32x32x16 kernels (an MFMA sums 32 products of two taps where the other sums 16 of one); within
 // fp32 accumulation noise of them (tests/test_gpu_w16.py) - the same relation conv_rs.hip's results have to conv_mfma.hip's.
 #include "common.h"
+#include <cmath>
 #include "conv_tile.h"
 #include <type_traits>
 #include <cstdio>
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_w16_kernel(const ConvArgs 
 
 bool conv3x3_w16_eligible(const ConvArgs& a, int dtype) {
   return dtype == SS4K_F16 && a.w16 && a.epi == EPI_NHWC && !a.bsvd_resid && !a.dbg && !a.ups2 && a.cout_pad >= 64 && a.cout_pad % 64 == 0 &&
-         (a.nchunks0 + a.nchunks1) % 2 == 0 && (double)a.N * a.H * a.W * 32.0 < 4294967296.0;
+         (a.nchunks0 + a.nchunks1) % 2 == 0 && conv_plane_span_f16(a) < 4294967296.0;
 }
 
 void launch_conv3x3_w16(ss4k_ctx* ctx, const ConvArgs& a0, hipStream_t st) {
@@ -421,7 +422,10 @@ void launch_conv3x3_w16(ss4k_ctx* ctx, const ConvArgs& a0, hipStream_t st) {
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
   const int gx = std::min(ntiles, std::max(1, (int)(ctx->num_cu * 2 / groups * (a.grid_share > 0.f ? a.grid_share : 1.f))));
   // conv5 of an RDB with its residual through the matrix core (RL): res1 must be the conv's own input tensor = its first four planes
-  const bool rl = a.wide_rl && a.res1 && a.act == ACT_NONE && a.alpha != 0.f && a.nchunks0 == 4 && a.cout_pad == 64 &&
+  // ... and 1 / alpha must be an fp16 number (the identity fragment carries it: RRDBNet's 0.2 -> 5.0); any other alpha would scale the skip
+  // tensor by 1 +- 2^-11 on top of the output rounding, so it takes the epilogue that reads the residual from memory
+  const bool alpha_exact = a.alpha != 0.f && std::fabs(__half2float(__float2half(1.f / a.alpha)) * a.alpha - 1.f) <= 1.2e-7f;
+  const bool rl = a.wide_rl && a.res1 && a.act == ACT_NONE && alpha_exact && a.nchunks0 == 4 && a.cout_pad == 64 &&
                   a.res1 + (size_t)a.r1_plane0 * a.r1_plane_bytes == a.in0 + (size_t)a.in0_plane0 * a.in0_plane_bytes &&
                   a.r1_plane_bytes == a.in0_plane_bytes;
 #ifdef SS4K_DEV

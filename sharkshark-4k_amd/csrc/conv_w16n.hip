@@ -224,7 +224,7 @@ __global__ __launch_bounds__(64 * NW, 3) void conv3x3_w16n_kernel(const ConvArgs
 // a layer for the narrow build: fp16, <= 4 real output channels handed over as NCHW fp32, no activation / residual, an even number of K-chunks
 bool conv3x3_w16n_eligible(const ConvArgs& a, int dtype) {
   return dtype == SS4K_F16 && a.w16 && a.epi == EPI_NCHW_F32 && a.cout_real <= 4 && a.act == ACT_NONE && !a.res1 && !a.res2 && !a.bsvd_resid &&
-         a.alpha == 1.f && !a.dbg && !a.ups2 && (a.nchunks0 + a.nchunks1) % 2 == 0 && (double)a.N * a.H * a.W * 32.0 < 4294967296.0;
+         a.alpha == 1.f && !a.dbg && !a.ups2 && (a.nchunks0 + a.nchunks1) % 2 == 0 && conv_plane_span_f16(a) < 4294967296.0;
 }
 
 void launch_conv3x3_w16n(ss4k_ctx* ctx, const ConvArgs& a0, hipStream_t st) {

@@ -336,7 +336,7 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
   a.in0 = in0.p; a.in0_plane_bytes = in0.plane_bytes; a.in0_plane0 = in0.plane0; a.nchunks0 = L.nchunks0;
   if (in1) { a.in1 = in1->p; a.in1_plane_bytes = in1->plane_bytes; a.in1_plane0 = in1->plane0; a.nchunks1 = L.nchunks1; }
   SS4K_REQUIRE((in1 != nullptr) == (L.nchunks1 > 0), "internal: conv segment mismatch");
-  a.N = N; a.H = H; a.W = W; a.ups2 = o.ups2;
+  a.N = N; a.job_n = N; a.H = H; a.W = W; a.ups2 = o.ups2;
   a.wpk = L.w.ptr; a.wrs = L.wrs.ptr; a.w16 = L.w16.ptr; a.rs_wide = L.rs_wide ? 1 : 0; a.bias = L.bias.as<float>(); a.prelu = L.has_prelu ? L.prelu.as<float>() : nullptr; a.prelu_le1 = L.prelu_le1 ? 1 : 0;
   a.act = o.act; a.slope = o.slope; a.alpha = o.alpha; a.gamma = o.gamma;
   if (o.res1) { a.res1 = o.res1->p; a.r1_plane_bytes = o.res1->plane_bytes; a.r1_plane0 = o.res1->plane0; }

@@ -119,11 +119,14 @@ class HipUpscalerService(BaseUpscalerService):
             frames = frames.to(self.torch_device, non_blocking=True)
         if frames.ndim == 4:
             assert frames.shape[-1] == 3
+            from .. import _capi
             prof = getattr(self, "profiler", None)
             up = self._get_upscaler()
             out = up(frames)
-            if getattr(self, "model_flags", 0) & 128:   # SS4K_MODEL_CHAIN: its one asynchronous failure mode (a work unit timed out)
-                self.model.check(wait=False)              # is reported here at the latest one job later; never blocks (include/ss4k.h)
+            if getattr(self, "model_flags", 0) & _capi.MODEL_CHAIN:
+                # SS4K_MODEL_CHAIN's one asynchronous failure mode (a work unit timed out): the frames leave this worker right after
+                # this call, so the status of THIS job's launch is awaited here (include/ss4k.h: ss4k_model_check, wait = 1)
+                self.model.check(wait=True)
             if prof is not None:
                 # the reference's span keys (fsrcnn_upscaler.py:276-278,290-300): host time around the
                 # asynchronous stage launches, measured inside the library

@@ -133,6 +133,9 @@ def fsrcnn_cases():
 
 # ------------------------------------------------------------------ SRVGG
 SRVGG_CASES = [("srvgg_f64_c4_x4", 64, 4, 4, 11), ("srvgg_f32_c2_x2", 32, 2, 2, 12), ("srvgg_f16_c2_x4", 16, 2, 4, 13)]
+# the reference's SHIPPED DEFAULT at its full depth (realesr-general-x4v3: num_feat 64, num_conv 32, x4; realesrgan/factory.py:88,132-138):
+# plain generated weights, and a DNI blend (factory.py:152-157) whose PReLU slopes leave [0, 1] (both forms of the HIP epilogue)
+SRVGG_FULL_CASES = [("srvgg_f64_c32_x4", 14, None), ("srvgg_f64_c32_x4_dni_wild", 15, 16)]
 
 
 def build_ref_srvgg(table, nf, nc, up):
@@ -150,6 +153,35 @@ def srvgg_cases():
             yo = onets.srvgg(torch.from_numpy(x), table, nc, up)
         save(name, {"oracle_maxdiff": maxdiff(y, yo), "num_feat": nf, "num_conv": nc, "upscale": up,
                     "weights": f"srvgg_table(seed={seed})"}, x=x, y=y.numpy())
+
+
+def srvgg_full_depth_cases():
+    from tests.helpers import srvgg_full_table
+    for name, seed, seed_b in SRVGG_FULL_CASES:
+        table = srvgg_full_table(seed, seed_b)
+        x = np.random.default_rng(seed).random((1, 3, 22, 38), dtype=np.float32)
+        with torch.no_grad():
+            y = build_ref_srvgg(table, 64, 32, 4)(torch.from_numpy(x))
+            yo = onets.srvgg(torch.from_numpy(x), table, 32, 4)
+        save(name, {"oracle_maxdiff": maxdiff(y, yo), "num_feat": 64, "num_conv": 32, "upscale": 4,
+                    "weights": f"tests.helpers.srvgg_full_table({seed}, {seed_b})"}, x=x, y=y.numpy())
+    # ... and through the reference SERVICE on the default configuration's path: batched mode, area pre-resize to lr_shape,
+    # x4 network, statistics + local colour match, the always-bicubic resize to output_shape (fsrcnn_upscaler.py:168-233)
+    import warnings
+    warnings.filterwarnings("ignore")
+    table = srvgg_full_table(15, 16)
+    frames = smooth_u8(49, (1, 90, 140, 3))
+    lr_shape, out_shape = (72, 104), (144, 208)
+    svc = make_ref_service(build_ref_srvgg(table, 64, 32, 4), "realesrgan", False, None, lr_shape, out_shape, True, 1.0, None)
+    osv = osvc.OracleUpscaler(lambda x: onets.srvgg(x, table, 32, 4), upscaler_model="realesrgan", output_shape=out_shape, lr_shape=lr_shape)
+    ft = torch.from_numpy(frames)
+    out1, out2 = svc.upscale(ft).numpy(), svc.upscale(ft).numpy()
+    d = max(maxdiff(out1, osv.upscale(ft).numpy()), maxdiff(out2, osv.upscale(ft).numpy()))
+    save("svc_multi_srvgg64x32_x4_area_bicubic", {"oracle_maxdiff_u8": d, "mode": "realesrgan", "sr": "srvgg",
+                                                 "num_feat": 64, "num_conv": 32, "upscale": 4, "weights": "tests.helpers.srvgg_full_table(15, 16)",
+                                                 "lr_shape": list(lr_shape), "output_shape": list(out_shape), "lr_hr_resize": True,
+                                                 "denoising": False, "denoise_rate": 1.0, "single_mode": None, "bsvd_seed": 21},
+         frames=frames, out1=out1, out2=out2)
 
 
 # ------------------------------------------------------------------ BSVD
@@ -292,6 +324,7 @@ if __name__ == "__main__":
     srvgg_cases()
     bsvd_cases()
     service_cases()
+    srvgg_full_depth_cases()
     kat_cases()
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py", "torch": torch.__version__,

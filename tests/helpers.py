@@ -43,6 +43,35 @@ def rrdb_small_table(seed=5, scale=2, num_block=2):
     return W.rrdbnet_table(seed, scale=scale, num_feat=64, num_block=num_block, num_grow_ch=32)
 
 
+def srvgg_full_table(seed, seed_b=None, alpha=0.3):
+    """SRVGGNetCompact at the depth the reference ships (num_feat 64, num_conv 32, x4: realesrgan/factory.py:88,132-138).  With seed_b: the
+    DNI blend of two generated checkpoints (factory.py:152-157) whose PReLU slopes are redrawn from [-0.5, 1.7] on every other layer and
+    from [-0.5, 1.0] on the rest, so that both forms of the HIP epilogue (max(t, t s) needs every slope <= 1) run at depth."""
+    t = W.srvgg_table(seed, num_feat=64, num_conv=32, upscale=4)
+    if seed_b is None:
+        return t
+    t = W.dni_blend(t, W.srvgg_table(seed_b, num_feat=64, num_conv=32, upscale=4), alpha)
+    rng = np.random.default_rng(1000 + seed)
+    i = 0
+    for k in list(t):
+        if np.asarray(t[k]).ndim == 1 and k.endswith(".weight"):   # PReLU slopes
+            lo, hi = (-0.5, 1.7) if i % 2 == 0 else (-0.5, 1.0)
+            # mean slope 0.6 / 0.25 keeps the 33-layer chain from blowing up or dying out
+            t[k] = rng.uniform(lo, hi, t[k].shape).astype(np.float32)
+            i += 1
+    return t
+
+
+def srvgg_table_for(m):
+    """The SRVGG weight table a golden vector was generated with, from its MANIFEST entry (tests/golden/make_golden.py)."""
+    wspec = m.get("weights", "")
+    if "srvgg_full_table" in wspec:
+        a, b = wspec.split("srvgg_full_table(")[1].rstrip(")").split(",")
+        return srvgg_full_table(int(a), None if b.strip() == "None" else int(b))
+    seed = m["seed"] if "seed" in m else int(wspec.split("seed=")[1].rstrip(")"))
+    return W.srvgg_table(seed=seed, num_feat=m["num_feat"], num_conv=m["num_conv"], upscale=m["upscale"])
+
+
 def smooth_u8(seed, shape):
     n, h, w, c = shape
     g = np.random.default_rng(seed).random((n, h + 8, w + 8, c)).astype(np.float32)

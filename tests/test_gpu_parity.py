@@ -14,7 +14,7 @@ from sharkshark4k_amd.upscale import model as factory
 from oracle import nets as onets
 from oracle import service as osvc
 from tests.conftest import load_golden, manifest
-from tests.helpers import assert_close, assert_u8_close, psnr, record_measured, rrdb_small_table, smooth_u8
+from tests.helpers import assert_close, assert_u8_close, psnr, record_measured, rrdb_small_table, smooth_u8, srvgg_full_table, srvgg_table_for
 from tests.test_oracle_golden import _t91, oracle_service_from_manifest
 
 pytestmark = pytest.mark.gpu
@@ -121,8 +121,7 @@ def test_fsrcnn_ragged_shapes(ctx, shape):
 def test_srvgg_golden_fp32(ctx, name):
     mm = CASES[name]
     g = load_golden(name)
-    seed = int(mm["weights"].split("seed=")[1].rstrip(")"))
-    table = W.srvgg_table(seed=seed, num_feat=mm["num_feat"], num_conv=mm["num_conv"], upscale=mm["upscale"])
+    table = srvgg_table_for(mm)
     desc = _capi.make_desc(_capi.SRVGG, _capi.F32, scale=mm["upscale"], num_feat=mm["num_feat"], num_block=mm["num_conv"])
     m = _capi.Model(ctx, desc, W.flatten(table, W.srvgg_keys(mm["num_conv"])))
     assert_close(m(dev(g["x"])), g["y"], what=name)
@@ -214,7 +213,7 @@ def test_rrdbnet_fp16_psnr(ctx):
 # ------------------------------------------------------------------------------ service glue
 def _hip_service_from_manifest(ctx, m, dtype="f32"):
     if m["sr"] == "srvgg":
-        t = W.srvgg_table(seed=m["seed"], num_feat=m["num_feat"], num_conv=m["num_conv"], upscale=m["upscale"])
+        t = srvgg_table_for(m)
         desc = _capi.make_desc(_capi.SRVGG, _capi.F32 if dtype == "f32" else _capi.F16, scale=m["upscale"],
                                num_feat=m["num_feat"], num_block=m["num_conv"])
         sr = _capi.Model(ctx, desc, W.flatten(t, W.srvgg_keys(m["num_conv"])))
@@ -236,7 +235,7 @@ def test_service_golden_u8(ctx, name):
     assert_u8_close(up(frames), g["out2"], what=name + " job 2")
 
 
-@pytest.mark.parametrize("name", ["svc_multi_srvgg_x4_color", "svc_multi_srvgg_x4_area_bicubic",
+@pytest.mark.parametrize("name", ["svc_multi_srvgg_x4_color", "svc_multi_srvgg_x4_area_bicubic", "svc_multi_srvgg64x32_x4_area_bicubic",
                                   "svc_single_fsrcnn_x2_denoise", "svc_single_srvgg_x2_denoise"])
 def test_service_float_taps_vs_oracle(ctx, name):
     m = CASES[name]

@@ -8,6 +8,7 @@ from sharkshark4k_amd import weights as W
 from oracle import nets as onets
 from oracle import service as osvc
 from tests.conftest import load_golden, manifest
+from tests.helpers import srvgg_table_for
 
 CASES = manifest()
 
@@ -40,8 +41,7 @@ def test_fsrcnn_matches_reference(factor, tag):
 def test_srvgg_matches_reference(name):
     m = CASES[name]
     g = load_golden(name)
-    seed = int(m["weights"].split("seed=")[1].rstrip(")"))
-    table = W.srvgg_table(seed=seed, num_feat=m["num_feat"], num_conv=m["num_conv"], upscale=m["upscale"])
+    table = srvgg_table_for(m)
     with torch.no_grad():
         y = onets.srvgg(torch.from_numpy(g["x"]), table, m["num_conv"], m["upscale"]).numpy()
     assert np.array_equal(y, g["y"])
@@ -58,7 +58,7 @@ def test_bsvd_f1_matches_reference(name):
 
 def oracle_service_from_manifest(m):
     if m["sr"] == "srvgg":
-        t = W.srvgg_table(seed=m["seed"], num_feat=m["num_feat"], num_conv=m["num_conv"], upscale=m["upscale"])
+        t = srvgg_table_for(m)
         model = lambda x: onets.srvgg(x, t, m["num_conv"], m["upscale"])
     else:
         t = W.fsrcnn_table(seed=m["seed"])

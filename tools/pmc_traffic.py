@@ -7,7 +7,8 @@ kernels differ too much for a per-launch average to mean anything."""
 import csv, glob, json, sys
 from collections import defaultdict
 
-FAMILIES = ("conv3x3_rs_kernel", "conv3x3_dense2_kernel", "conv3x3_w16_kernel", "conv3x3_wide_kernel", "conv3x3_kernel")
+# most specific name first; a conv3x3 kernel none of them matches is counted under its own name (a new kernel must not crash the collection)
+FAMILIES = ("conv3x3_rs_kernel", "conv3x3_dense2_kernel", "conv3x3_w16n_kernel", "conv3x3_w16_kernel", "conv3x3_wide_kernel", "conv3x3_kernel")
 
 
 def per_dispatch(d, counter):
@@ -16,7 +17,7 @@ def per_dispatch(d, counter):
     for r in csv.DictReader(open(f)):
         if "conv3x3" in r["Kernel_Name"] and r["Counter_Name"] == counter:
             acc[r["Dispatch_Id"]] += float(r["Counter_Value"])
-            fam[r["Dispatch_Id"]] = next(k for k in FAMILIES if k in r["Kernel_Name"])
+            fam[r["Dispatch_Id"]] = next((k for k in FAMILIES if k in r["Kernel_Name"]), r["Kernel_Name"].split("(")[0].split("<")[0].split("::")[-1])
     return acc, fam
 
 
@@ -28,7 +29,7 @@ fps = int(sys.argv[6]) if len(sys.argv) > 6 else 4
 fetch_kb, write_kb = sum(fetch_d.values()), sum(write_d.values())
 total = (2 * fetch_kb + write_kb) * 1024
 by_family = {}
-for fam in FAMILIES:
+for fam in list(FAMILIES) + sorted(set(fam_f.values()) - set(FAMILIES)):
     ff = [v for k, v in fetch_d.items() if fam_f[k] == fam]; ww = [v for k, v in write_d.items() if fam_w.get(k) == fam]
     if ff and ww:
         by_family[fam] = {"launches_per_step": len(ff) / steps, "traffic_bytes_per_launch": (2 * sum(ff) / len(ff) + sum(ww) / len(ww)) * 1024,
