@@ -8,6 +8,7 @@ bit-identical weights without touching the filesystem/network again.
 """
 from __future__ import annotations
 
+import dataclasses
 import os
 from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
 
@@ -36,6 +37,42 @@ def init_distributed(backend: Optional[str] = None, force_group: bool = False) -
     return rank, world, local
 
 
+@dataclasses.dataclass
+class GroupSpec:
+    """Where a service worker finds the other workers of its node: what a launcher exports as RANK / WORLD_SIZE / MASTER_*, carried
+    in the (pickled) service object instead, because ``node.UpscalerNode`` spawns its workers itself.  ``backend=None``: ``nccl``
+    (RCCL) when the worker owns a GPU, else ``gloo``; two workers that share one GPU must say ``gloo`` (RCCL refuses duplicate devices).
+    ``keep``: leave the group up after the weight broadcast (``bench.py`` needs its barrier); a service worker tears it down, so that
+    the workers of a node are independent processes from then on - one that dies later cannot stall the others' exit."""
+    rank: int = 0
+    world: int = 1
+    master_addr: str = "127.0.0.1"
+    master_port: int = 29533
+    backend: Optional[str] = None
+    keep: bool = False
+    force: bool = False   # create the group even for world == 1 (exercises library load / communicator / broadcast on a one-GPU box)
+
+
+def join_group(spec: Optional[GroupSpec], local_device: Optional[int] = None) -> Tuple[int, int]:
+    """(rank, world) of this worker.  A process that already sits in a group (``bench.py`` under ``torch.distributed.run``) keeps it;
+    otherwise the group described by ``spec`` is joined (nothing to join for ``spec is None`` or a world of one without ``force``)."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    if spec is None or (spec.world <= 1 and not spec.force):
+        return 0, 1
+    backend = spec.backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    if backend == "nccl" and local_device is not None:
+        torch.cuda.set_device(local_device)
+    dist.init_process_group(backend=backend, init_method=f"tcp://{spec.master_addr}:{spec.master_port}", rank=spec.rank, world_size=spec.world)
+    return spec.rank, spec.world
+
+
+def leave_group() -> None:
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()   # nobody tears the store down under a rank that is still inside the broadcast
+        dist.destroy_process_group()
+
+
 def owner_of(step: int, world: int) -> int:
     return step % world
 
@@ -56,6 +93,8 @@ def broadcast_weights(flat: Optional[np.ndarray], n_floats: int, device: torch.d
     if not have_group or (dist.get_world_size() == 1 and not force_collective):
         assert flat is not None
         return np.ascontiguousarray(flat, dtype=np.float32)
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")   # (two workers sharing one GPU, or the CPU tests: the blob goes through host memory)
     t = torch.empty(n_floats, dtype=torch.float32, device=device)
     if dist.get_rank() == src:
         assert flat is not None and flat.size == n_floats

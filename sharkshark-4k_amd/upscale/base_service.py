@@ -16,10 +16,16 @@ the pipelines drive it directly:
 Differences that matter on ROCm: the worker is spawned (a HIP context does not survive ``fork``), it
 blocks on the job queue instead of spinning, and on exit it flushes the result queue's feeder thread
 before it terminates so that the last results are not lost.
+
+Two additions the multi-GPU node (``node.py``) and the one-frame-job overlap (``hip_upscaler.py``) use, both inert by default:
+``ready_event`` (a ``multiprocessing.Event`` the worker sets when ``proc_init`` has returned, so that a launcher can wait for G
+workers without sending a job) and ``deliver_lag`` (results handed over - still in job order - that many jobs late while the queue
+keeps coming, and at once when it runs dry; ``proc_before_deliver(entry)`` runs right before a result leaves the worker).
 """
 from __future__ import annotations
 
 import abc
+import collections
 import os
 import queue
 import signal
@@ -50,6 +56,10 @@ class BaseService(abc.ABC):
     exit_on_error = False
     #: multiprocessing start method ('spawn': the parent may already hold a HIP context)
     mp_start_method = "spawn"
+    #: results held back (in order) while later jobs are being enqueued; 0 = every result leaves before the next job is read
+    deliver_lag = 0
+    #: set by the worker once proc_init() has returned (None: nobody waits for it)
+    ready_event = None
 
     def __init__(self) -> None:
         mpctx = mp.get_context(self.mp_start_method)
@@ -73,6 +83,9 @@ class BaseService(abc.ABC):
     def proc_cleanup(self) -> None:
         """Runs once in the worker after the exit command."""
 
+    def proc_before_deliver(self, entry) -> None:
+        """Runs in the worker right before ``entry`` is handed to ``on_queue`` / the result queue."""
+
     def proc_pre_main(self) -> None:
         self.proc_main()
 
@@ -85,6 +98,7 @@ class BaseService(abc.ABC):
             return asked
 
     def _deliver(self, entry) -> None:
+        self.proc_before_deliver(entry)
         if self.on_queue is not None:
             self.on_queue(entry)
             return
@@ -96,12 +110,21 @@ class BaseService(abc.ABC):
     def proc_main(self) -> None:
         try:
             self.proc_init()
+            if self.ready_event is not None:
+                self.ready_event.set()
+            held = collections.deque()
             while not self._exit_requested():
                 try:
                     job = self.job_queue.get(timeout=_IDLE_WAIT_S)
                 except queue.Empty:
+                    while held:  # the queue ran dry: nothing left to overlap with
+                        self._deliver(held.popleft())
                     continue
-                self._deliver(self.proc_job_recieved(job))
+                held.append(self.proc_job_recieved(job))
+                while len(held) > self.deliver_lag:
+                    self._deliver(held.popleft())
+            while held:
+                self._deliver(held.popleft())
             self.proc_cleanup()
             self.result_queue.close()
             self.result_queue.join_thread()  # results still in the feeder thread reach the client first

@@ -18,6 +18,18 @@ RealESRGAN ``.pth`` files with the DNI blend, ``bsvd-32.pth``); so does this ser
   state-dict table; missing entries fall back to the ``checkpoint_dir`` lookup.
 * ``weights='synthetic'``: deterministic generated weights for every model - an explicit opt-in
   used by the tests and ``bench.py`` only (logged loudly: the frames are noise).
+
+Multi-GPU (``group=sharding.GroupSpec(rank, world, ...)``, set by ``node.UpscalerNode``): the worker joins the node's process group
+in ``proc_init`` (RCCL: backend ``nccl``), ONLY RANK 0 resolves ``weights`` (reads / blends / generates the state dicts) and every
+blob reaches the other workers through one ``sharding.broadcast_weights`` each; then the group is left and the workers are
+independent.  The reference builds one service on ``device=0`` (``src/sharkshark/pipeline.py:20,41-50``); SURVEY.md 8(e).
+
+One-frame jobs (``overlap_jobs=True``, batched path only - the image server's caller, ``image_pipeline.py:54-64,280-287``): consecutive
+one-frame jobs alternate over TWO job sets (context + model + upscaler + stream), so that job i + 1's launches fill the launch
+boundaries and partly filled tile rounds of job i - what frame lanes do inside a multi-frame job.  Frames are bit-identical to the
+single-set path (same kernels, same weights).  The worker hands result i over after job i + 1 has been enqueued
+(``BaseService.deliver_lag``); ``upscale()`` called directly stays synchronous with the current stream unless ``wait=False``.
+Cost: a second copy of the SR weights and activation workspace (RRDBNet x2 at 720p: 67 MB + 177 MB), built on the first one-frame job.
 """
 from __future__ import annotations
 
@@ -25,6 +37,7 @@ from typing import Mapping, Optional
 
 import torch
 
+from .. import sharding
 from ..util.profiler import Profiler
 from .upscaler_base import BaseUpscalerService, UpscalerQueueEntry  # noqa: F401
 
@@ -42,7 +55,8 @@ class HipUpscalerService(BaseUpscalerService):
                  upscaler_model="realesrgan", batch_size=1, jit_mode="hip", lr_hr_resize=True,
                  # knobs the reference hard-codes
                  scale=4, model_name=None, dtype="f16", weights=None, checkpoint_dir: Optional[str] = None,
-                 lr_shape=None, single_mode=None, seed=0, model_flags=0, fsrcnn_dtype="f32"):
+                 lr_shape=None, single_mode=None, seed=0, model_flags=0, fsrcnn_dtype="f32",
+                 group: Optional[sharding.GroupSpec] = None, overlap_jobs=True):
         if jit_mode not in (None, "hip"):
             raise Exception(f"jit_mode={jit_mode!r}: this build has one backend, 'hip'")
         if upscaler_model not in ("fsrcnn", "realesrgan"):
@@ -69,70 +83,166 @@ class HipUpscalerService(BaseUpscalerService):
         self.seed = seed
         self.fsrcnn_dtype = fsrcnn_dtype  # 'f32': fp32-accurate (parity bar); 'f16': the reference engine's precision, ~2x the rate
         self.model_flags = int(model_flags)  # SS4K_MODEL_* routing switches for the SR model (include/ss4k.h)
+        self.group = group
+        self.overlap_jobs = bool(overlap_jobs)
         super().__init__()
 
     # worker side -----------------------------------------------------------------------------
+    def proc_main(self):
+        self._in_worker = True   # results leave through _deliver: proc_before_deliver orders them on the current stream
+        super().proc_main()
+
+    def _shared_flat(self, name: str, desc, loader):
+        """The flat fp32 state_dict blob of one model on every worker of the node: rank 0 runs ``loader`` (reads the checkpoint(s),
+        applies the key remaps / the DNI blend, or generates), the others receive it over the group.  Kept on the host for the second
+        job set.  A loader that fails on rank 0 fails every rank (they would otherwise wait in the broadcast for ever)."""
+        from .. import _capi
+        n = _capi.param_count(desc)
+        flat, err = None, None
+        if self.node_rank == 0:
+            try:
+                flat = loader()
+                if flat.size != n:
+                    raise ValueError(f"{name}: the weights hold {flat.size} scalars, the model description needs {n}")
+            except Exception as e:  # noqa: BLE001 - re-raised below, on every rank
+                err = e
+        if self.node_world > 1:
+            import torch.distributed as dist
+            msg = [None if err is None else f"{type(err).__name__}: {err}"]
+            dist.broadcast_object_list(msg, src=0)
+            if msg[0] is not None and err is None:
+                raise RuntimeError(f"rank 0 could not load the {name} weights: {msg[0]}")
+        if err is not None:
+            raise err
+        flat = sharding.broadcast_weights(flat, n, self.torch_device, force_collective=bool(self.group and self.group.force))
+        self._flats[name] = (desc, flat)
+        return flat
+
     def proc_init(self):
         from .. import _capi
         from . import model as factory
         log("proc init")
         self.ctx = _capi.Context(self.device)
         self.torch_device = self.ctx.device
+        import torch.distributed as dist
+        had_group = dist.is_available() and dist.is_initialized()
+        self.node_rank, self.node_world = sharding.join_group(self.group, self.ctx.device_index)
+        if self.node_world > 1:
+            log(f"worker {self.node_rank} of {self.node_world} on {self.torch_device} ({dist.get_backend()})")
+        self._flats = {}
         if self.weights == "synthetic":
             log("WARNING: weights='synthetic' - every network runs on generated weights, output frames are noise")
         def spec(name):
             return "synthetic" if self.weights == "synthetic" else (self.weights or {}).get(name)
-        if self.upscaler_model == "fsrcnn":
-            self.model = factory.build_model_fsrcnn(self.ctx, factor=self.scale, weights=spec("sr"), seed=self.seed,
-                                                    checkpoint_dir=self.checkpoint_dir, dtype=self.fsrcnn_dtype, flags=self.model_flags)
-        else:
-            self.model = factory.build_model_esrgan(
-                self.ctx, model_name=self.model_name or factory.DEFAULT_REALESRGAN, denoise_rate=self.denoise_rate,
-                weights=spec("sr"), weights_wdn=spec("sr_wdn") if self.weights != "synthetic" else None, dtype=self.dtype,
-                seed=self.seed, checkpoint_dir=self.checkpoint_dir, flags=self.model_flags)
-        self.denoise_model = None
-        # quirk kept from the reference: with 'realesrgan' the batched path never denoises even when
-        # denoising=True (fsrcnn_upscaler.py:109,168-233); the BSVD model is only used per-frame.
-        if self.denoising and self.single_mode:
-            self.denoise_model = factory.build_denoise_model(self.ctx, weights=spec("denoise"), dtype=self.dtype,
-                                                             seed=self.seed, checkpoint_dir=self.checkpoint_dir)
-        self._upscaler = None
-        self._upscaler_key = None
+        try:
+            if self.upscaler_model == "fsrcnn":
+                desc = factory.fsrcnn_desc(self.scale, self.fsrcnn_dtype, self.model_flags)
+                flat = self._shared_flat("sr", desc, lambda: factory.fsrcnn_flat(self.scale, spec("sr"), self.seed, self.checkpoint_dir))
+            else:
+                name = self.model_name or factory.DEFAULT_REALESRGAN
+                desc = factory.esrgan_desc(name, self.dtype, self.model_flags)
+                flat = self._shared_flat("sr", desc, lambda: factory.esrgan_flat(
+                    name, self.denoise_rate, spec("sr"), self.seed, spec("sr_wdn") if self.weights != "synthetic" else None, self.checkpoint_dir))
+            self.model = _capi.Model(self.ctx, desc, flat)
+            self.denoise_model = None
+            # quirk kept from the reference: with 'realesrgan' the batched path never denoises even when
+            # denoising=True (fsrcnn_upscaler.py:109,168-233); the BSVD model is only used per-frame.
+            if self.denoising and self.single_mode:
+                ddesc = factory.denoise_desc(self.dtype)
+                dflat = self._shared_flat("denoise", ddesc, lambda: factory.denoise_flat(spec("denoise"), self.seed, checkpoint_dir=self.checkpoint_dir))
+                self.denoise_model = _capi.Model(self.ctx, ddesc, dflat)
+        finally:
+            if not had_group and not (self.group and self.group.keep):
+                sharding.leave_group()   # weights are in place: from here on the workers of a node are independent
+        # job sets: [0] is what every job ran on before; [1] (second context / model / stream) is built on the first one-frame job
+        self._sets = [{"ctx": self.ctx, "model": self.model, "denoise": self.denoise_model, "up": None, "key": None, "stream": None}]
+        self._alt = 0
+        self._pending = {}
+        if not (self.overlap_jobs and not self.single_mode):
+            self._flats.pop("sr", None)      # (no second set will ever be built: drop the host copies)
+        self._flats.pop("denoise", None)     # (the batched path never denoises)
+        self.deliver_lag = 1 if self._overlap_active() else 0
         log("model loaded")
 
-    def _get_upscaler(self):
+    def _overlap_active(self) -> bool:
+        return bool(self.overlap_jobs) and not self.single_mode and "sr" in getattr(self, "_flats", {})
+
+    def _job_set(self, k: int) -> dict:
         from .. import _capi
+        while len(self._sets) <= k:
+            desc, flat = self._flats["sr"]
+            ctx = _capi.Context(self.device)
+            self._sets.append({"ctx": ctx, "model": _capi.Model(ctx, desc, flat), "denoise": None, "up": None, "key": None, "stream": None})
+            log(f"job set {len(self._sets) - 1} built (one-frame jobs alternate over {len(self._sets)} sets)")
+        js = self._sets[k]
+        if js["stream"] is None and self._overlap_active():
+            js["stream"] = torch.cuda.Stream(self.torch_device)
+        return js
+
+    def _get_upscaler(self, k: int = 0):
+        from .. import _capi
+        js = self._job_set(k)
         key = (tuple(self.lr_shape), None if self.output_shape is None else tuple(self.output_shape),
                bool(self.lr_hr_resize), bool(self.single_mode), float(self.denoise_rate))
-        if self._upscaler is None or key != self._upscaler_key:
-            self._upscaler = _capi.Upscaler(self.ctx, self.model, self.lr_shape, self.output_shape, self.lr_hr_resize,
-                                            self.single_mode, self.denoise_model, self.denoise_rate)
-            self._upscaler_key = key
-        return self._upscaler
+        if js["up"] is None or key != js["key"]:
+            js["up"] = _capi.Upscaler(js["ctx"], js["model"], self.lr_shape, self.output_shape, self.lr_hr_resize,
+                                      self.single_mode, js["denoise"], self.denoise_rate)
+            js["key"] = key
+        return js["up"]
+
+    def proc_before_deliver(self, entry):
+        # a result computed on a job set's own stream: the current stream - on which the result tensor is handed to the consumer
+        # (on_queue, or the IPC event torch records when the tensor is pickled into the result queue) - waits for it here
+        rec = self._pending.pop(id(entry.frames), None) if getattr(entry, "frames", None) is not None else None
+        if rec is not None:
+            torch.cuda.current_stream(self.torch_device).wait_event(rec[1])
 
     def proc_cleanup(self):
         pass
 
-    def upscale(self, frames: torch.Tensor):
+    def _run(self, k: int, frames: torch.Tensor) -> torch.Tensor:
+        from .. import _capi
+        up = self._get_upscaler(k)
+        out = up(frames)
+        if self.model_flags & _capi.MODEL_CHAIN:
+            # SS4K_MODEL_CHAIN's one asynchronous failure mode (a work unit timed out): the frames leave this worker right after
+            # this call, so the status of THIS job's launch is awaited here (include/ss4k.h: ss4k_model_check, wait = 1)
+            self._sets[k]["model"].check(wait=True)
+        prof = getattr(self, "profiler", None)
+        if prof is not None:
+            # the reference's span keys (fsrcnn_upscaler.py:276-278,290-300): host time around the
+            # asynchronous stage launches, measured inside the library
+            denoise_ms, model_ms = up.last_enqueue_ms()
+            if self._sets[k]["denoise"] is not None:
+                prof.add("fsrcnn.denoise", denoise_ms / 1000.0)
+            prof.add("fsrcnn.model", model_ms / 1000.0)
+        return out
+
+    def upscale(self, frames: torch.Tensor, wait: bool = True):
+        """``wait=False`` (direct callers only): with the one-frame overlap active the result is ordered on its job set's stream, not
+        on the current one - synchronise (``torch.cuda.synchronize()``) before reading it.  The default orders it on the current
+        stream like any torch op."""
         assert isinstance(frames, torch.Tensor)
         if frames.device != self.torch_device:
             frames = frames.to(self.torch_device, non_blocking=True)
-        if frames.ndim == 4:
-            assert frames.shape[-1] == 3
-            from .. import _capi
-            prof = getattr(self, "profiler", None)
-            up = self._get_upscaler()
-            out = up(frames)
-            if getattr(self, "model_flags", 0) & _capi.MODEL_CHAIN:
-                # SS4K_MODEL_CHAIN's one asynchronous failure mode (a work unit timed out): the frames leave this worker right after
-                # this call, so the status of THIS job's launch is awaited here (include/ss4k.h: ss4k_model_check, wait = 1)
-                self.model.check(wait=True)
-            if prof is not None:
-                # the reference's span keys (fsrcnn_upscaler.py:276-278,290-300): host time around the
-                # asynchronous stage launches, measured inside the library
-                denoise_ms, model_ms = up.last_enqueue_ms()
-                if self.denoise_model is not None:
-                    prof.add("fsrcnn.denoise", denoise_ms / 1000.0)
-                prof.add("fsrcnn.model", model_ms / 1000.0)
-            return out
-        raise Exception(frames.shape)
+        if frames.ndim != 4:
+            raise Exception(frames.shape)
+        assert frames.shape[-1] == 3
+        if not self._overlap_active():
+            return self._run(0, frames)
+        k = 0
+        if frames.shape[0] == 1:   # consecutive one-frame jobs alternate; a multi-frame job overlaps with itself (frame lanes) on set 0
+            k, self._alt = self._alt, self._alt ^ 1
+        cur = torch.cuda.current_stream(self.torch_device)
+        side = self._job_set(k)["stream"]
+        side.wait_stream(cur)   # the frames (an IPC tensor's ready event, a .to(device) copy) are ordered on the current stream
+        frames.record_stream(side)
+        with torch.cuda.stream(side):
+            out = self._run(k, frames)
+        done = side.record_event()
+        out.record_stream(cur)
+        if getattr(self, "_in_worker", False):
+            self._pending[id(out)] = (out, done)   # proc_before_deliver makes the current stream wait, one job later
+        elif wait:
+            cur.wait_event(done)
+        return out

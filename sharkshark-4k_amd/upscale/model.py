@@ -90,13 +90,22 @@ def fsrcnn_table_from(weights: WeightSpec, factor: int = 4, seed: int = 0, check
     return CK.fsrcnn_from_checkpoint(obj) if kind == "ckpt" else obj
 
 
+# Every factory is two halves: ``*_desc`` (the model description: host-only, needs no checkpoint - every rank of a node can size the
+# weight blob from it) and ``*_flat`` (the flat fp32 state_dict blob: reads / blends / generates the weights - on a multi-GPU node only
+# rank 0 does that and the blob reaches the others through ``sharding.broadcast_weights``, see ``HipUpscalerService.proc_init``).
+def fsrcnn_desc(factor: int = 4, dtype="f32", flags: int = 0):
+    return _capi.make_desc(_capi.FSRCNN, _dtype(dtype), scale=factor, flags=flags)
+
+
+def fsrcnn_flat(factor: int = 4, weights: WeightSpec = None, seed: int = 0, checkpoint_dir: Optional[str] = None) -> np.ndarray:
+    return W.flatten(fsrcnn_table_from(weights, factor, seed, checkpoint_dir), W.fsrcnn_keys())
+
+
 def build_model_fsrcnn(ctx: _capi.Context, factor: int = 4, weights: WeightSpec = None, seed: int = 0,
                        checkpoint_dir: Optional[str] = None, dtype="f32", flags: int = 0):
     """dtype 'f32' (default): fp32 accuracy (the 1e-3 / 1e-4 parity bar against the CPU forward).  'f16': fp16 operands with
     fp32 accumulation - the precision the reference's TensorRT engine runs this network in (fsrcnn/factory.py:47-69)."""
-    table = fsrcnn_table_from(weights, factor, seed, checkpoint_dir)
-    desc = _capi.make_desc(_capi.FSRCNN, _dtype(dtype), scale=factor, flags=flags)
-    return _capi.Model(ctx, desc, W.flatten(table, W.fsrcnn_keys()))
+    return _capi.Model(ctx, fsrcnn_desc(factor, dtype, flags), fsrcnn_flat(factor, weights, seed, checkpoint_dir))
 
 
 def esrgan_table_from(model_name: str = DEFAULT_REALESRGAN, denoise_rate: float = 0.5, weights: WeightSpec = None,
@@ -131,18 +140,30 @@ def esrgan_table_from(model_name: str = DEFAULT_REALESRGAN, denoise_rate: float 
     return arch, kw, table
 
 
+def esrgan_desc(model_name: str = DEFAULT_REALESRGAN, dtype="f16", flags: int = 0, **arch_overrides):
+    if model_name not in REALESRGAN_ZOO:
+        raise Exception(model_name)
+    arch, kw = REALESRGAN_ZOO[model_name]
+    kw = dict(kw, **arch_overrides)
+    if arch == "rrdbnet":
+        return _capi.make_desc(_capi.RRDBNET, _dtype(dtype), scale=kw["scale"], num_feat=kw["num_feat"],
+                               num_block=kw["num_block"], num_grow_ch=kw["num_grow_ch"], flags=flags)
+    return _capi.make_desc(_capi.SRVGG, _dtype(dtype), scale=kw["upscale"], num_feat=kw["num_feat"],
+                           num_block=kw["num_conv"], flags=flags)
+
+
+def esrgan_flat(model_name: str = DEFAULT_REALESRGAN, denoise_rate: float = 0.5, weights: WeightSpec = None, seed: int = 0,
+                weights_wdn: WeightSpec = None, checkpoint_dir: Optional[str] = None, **arch_overrides) -> np.ndarray:
+    arch, kw, table = esrgan_table_from(model_name, denoise_rate, weights, seed, weights_wdn, checkpoint_dir, **arch_overrides)
+    return W.flatten(table, W.rrdbnet_keys(kw["num_block"]) if arch == "rrdbnet" else W.srvgg_keys(kw["num_conv"]))
+
+
 def build_model_esrgan(ctx: _capi.Context, model_name: str = DEFAULT_REALESRGAN, denoise_rate: float = 0.5,
                        weights: WeightSpec = None, dtype="f16", seed: int = 0, weights_wdn: WeightSpec = None,
                        checkpoint_dir: Optional[str] = None, flags: int = 0, **arch_overrides):
-    """flags: SS4K_MODEL_* routing switches (include/ss4k.h), e.g. _capi.MODEL_CHAIN for 1-2-frame RRDBNet jobs."""
-    arch, kw, table = esrgan_table_from(model_name, denoise_rate, weights, seed, weights_wdn, checkpoint_dir, **arch_overrides)
-    if arch == "rrdbnet":
-        desc = _capi.make_desc(_capi.RRDBNET, _dtype(dtype), scale=kw["scale"], num_feat=kw["num_feat"],
-                               num_block=kw["num_block"], num_grow_ch=kw["num_grow_ch"], flags=flags)
-        return _capi.Model(ctx, desc, W.flatten(table, W.rrdbnet_keys(kw["num_block"])))
-    desc = _capi.make_desc(_capi.SRVGG, _dtype(dtype), scale=kw["upscale"], num_feat=kw["num_feat"],
-                           num_block=kw["num_conv"], flags=flags)
-    return _capi.Model(ctx, desc, W.flatten(table, W.srvgg_keys(kw["num_conv"])))
+    """flags: SS4K_MODEL_* routing switches (include/ss4k.h)."""
+    return _capi.Model(ctx, esrgan_desc(model_name, dtype, flags, **arch_overrides),
+                       esrgan_flat(model_name, denoise_rate, weights, seed, weights_wdn, checkpoint_dir, **arch_overrides))
 
 
 BSVD_VARIANTS = {  # bsvd/factory.py:31-36 (the one the service builds) and :94-98 / the commented-out block at :26-30
@@ -159,13 +180,19 @@ def bsvd_table_from(weights: WeightSpec, seed: int = 0, variant: str = "bsvd-32"
     return CK.bsvd_from_checkpoint(obj, **kw) if kind == "ckpt" else obj
 
 
+def denoise_desc(dtype="f16", stream: bool = False, variant: str = "bsvd-32", flags: int = 0):
+    kw = BSVD_VARIANTS[variant]
+    return _capi.make_desc(_capi.BSVD, _dtype(dtype), scale=1, bsvd_stream=stream, bsvd_chns=kw["chns"],
+                           bsvd_mid_ch=kw["mid_ch"], bsvd_interm_ch=kw["interm_ch"], flags=flags)
+
+
+def denoise_flat(weights: WeightSpec = None, seed: int = 0, variant: str = "bsvd-32", checkpoint_dir: Optional[str] = None) -> np.ndarray:
+    return W.flatten(bsvd_table_from(weights, seed, variant, checkpoint_dir), W.bsvd_keys(**BSVD_VARIANTS[variant]))
+
+
 def build_denoise_model(ctx: _capi.Context, weights: WeightSpec = None, dtype="f16", seed: int = 0,
                         stream: bool = False, variant: str = "bsvd-32", checkpoint_dir: Optional[str] = None, flags: int = 0):
     """``stream=False``: the model the service calls, one independent frame per call (F = 1,
     ``fsrcnn_upscaler.py:277``).  ``stream=True``: ``BSVD.forward`` on ``(N,F,4,H,W)`` clips, all N*F
     frames run through the bidirectional buffers as one stream (``bsvd/model.py:515-580``)."""
-    kw = BSVD_VARIANTS[variant]
-    table = bsvd_table_from(weights, seed, variant, checkpoint_dir)
-    desc = _capi.make_desc(_capi.BSVD, _dtype(dtype), scale=1, bsvd_stream=stream, bsvd_chns=kw["chns"],
-                           bsvd_mid_ch=kw["mid_ch"], bsvd_interm_ch=kw["interm_ch"], flags=flags)
-    return _capi.Model(ctx, desc, W.flatten(table, W.bsvd_keys(**kw)))
+    return _capi.Model(ctx, denoise_desc(dtype, stream, variant, flags), denoise_flat(weights, seed, variant, checkpoint_dir))

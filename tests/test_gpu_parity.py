@@ -133,7 +133,9 @@ def test_srvgg_fp16_psnr(ctx):
     table = W.srvgg_table(seed=11, num_feat=64, num_conv=4, upscale=4)
     desc = _capi.make_desc(_capi.SRVGG, _capi.F16, scale=4, num_feat=64, num_block=4)
     m = _capi.Model(ctx, desc, W.flatten(table, W.srvgg_keys(4)))
-    assert psnr(m(dev(g["x"])), g["y"]) > 50.0
+    p = psnr(m(dev(g["x"])), g["y"])
+    record_measured("srvgg_f64_c4_x4_fp16_vs_reference_golden", psnr_db=p, asserted="PSNR > 60 dB (peak 1.0)")
+    assert p > 60.0, p   # (tightened to measured - 2 dB once recorded); the 32-conv default: tests/test_gpu_srvgg_default.py
 
 
 # ------------------------------------------------------------------------------ BSVD

@@ -61,8 +61,8 @@ def test_srvgg32_wild_slopes_reach_both_epilogue_forms():
 
 
 # asserted at measured - 2 dB / + 1 LSB; measured values: profiles/r05_parity_measured.json
-S32_PSNR_DB, S32_MAX_LSB = 48.0, 3
-S32W_PSNR_DB, S32W_MAX_LSB = 48.0, 3
+S32_PSNR_DB, S32_MAX_LSB = 61.8, 2     # measured 63.89 dB, 1 LSB (2.7 % of the bytes differ)
+S32W_PSNR_DB, S32W_MAX_LSB = 61.5, 2   # measured 63.56 dB, 1 LSB (2.9 %)
 
 
 @pytest.mark.parametrize("seeds,tag,bar", [((14, None), "plain", (S32_PSNR_DB, S32_MAX_LSB)), ((15, 16), "dni_wild", (S32W_PSNR_DB, S32W_MAX_LSB))])
@@ -93,11 +93,12 @@ def test_srvgg32_720p_fp16_service_vs_oracle(ctx, seeds, tag, bar):
 def test_srvgg32_fp16_network_vs_reference_golden(ctx, flags, what):
     """The fp16 network's float output against what the REFERENCE's SRVGGNetCompact produced at full depth (fp32), both weight tables, on
     both builds of the 64-cout tile: the two must be equally far from it."""
-    for name, seeds in (("srvgg_f64_c32_x4", (14, None)), ("srvgg_f64_c32_x4_dni_wild", (15, 16))):
+    # measured (peak 1.0; the output is the input plus a small residue, so the fp32 base dominates): 102.4 dB / 115.9 dB on either tile
+    for name, seeds, bar in (("srvgg_f64_c32_x4", (14, None), 100.0), ("srvgg_f64_c32_x4_dni_wild", (15, 16), 113.5)):
         g = load_golden(name)
         y = _model(ctx, srvgg_full_table(*seeds), _capi.F16, flags)(torch.from_numpy(g["x"]).cuda()).cpu()
         p = psnr(y, torch.from_numpy(g["y"]))
         record_measured(f"{name}_fp16_{'w16' if flags == 0 else 'wide'}", psnr_db=p, max_abs_err=float((y - torch.from_numpy(g['y'])).abs().max()),
-                        asserted="PSNR >= 60 dB (peak 1.0)")
+                        asserted=f"PSNR >= {bar} dB (peak 1.0)")
         print(f"{name} fp16 on the {what}: {p:.1f} dB vs the reference's fp32 output")
-        assert p >= 60.0, (name, what, p)
+        assert p >= bar, (name, what, p)
