@@ -7,8 +7,11 @@ Default workload (BASELINE.json configs[2], the one the >=24 fps target is quote
 RealESRGAN RRDBNet x2 (23 blocks), fp16 storage / fp32 accumulate.  Other BASELINE configs via
 --workload {fsrcnn,rrdbnet,pipeline,srvgg}.
 
+Every rank IS the product's service worker: ``HipUpscalerService(device=local_rank, ...).proc_init()`` joins the process group the launcher
+set up, ONLY RANK 0 generates / repacks the weights and ``sharding.broadcast_weights`` (RCCL) hands the blobs to the others - the very code
+``node.UpscalerNode``'s spawned workers run - and a step is ``service.upscale(frames)``.
 Multi-GPU: one rank per GPU, frames sharded one-per-GPU with no data-path collective (weak scaling:
-every rank runs the same per-GPU batch); the weight blob is broadcast once from rank 0 over RCCL.
+every rank runs the same per-GPU batch); the weight blobs are broadcast once from rank 0 over RCCL.
 Launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (ranks read
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or directly as ``python bench.py
 --gpus N``: with WORLD_SIZE unset the parent starts the N ranks itself as fresh child processes
@@ -31,6 +34,7 @@ sys.path.insert(0, ROOT)
 import sharkshark4k_amd  # noqa: E402,F401
 from sharkshark4k_amd import _capi, sharding, weights as W  # noqa: E402
 from sharkshark4k_amd.upscale import model as factory  # noqa: E402
+from sharkshark4k_amd.upscale.hip_upscaler import HipUpscalerService  # noqa: E402
 
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16
 F32_VECTOR_PEAK_TFLOPS = 157.3
@@ -39,10 +43,6 @@ PMC_TRAFFIC_FILE = "conv3x3_pmc_traffic_current.json"  # written by tools/collec
 # (33.4 MB) once per step: 88.7 MB for a 4-frame step
 ALGORITHMIC_BYTES_PER_FRAME, ALGORITHMIC_WEIGHT_BYTES = 2_764_800 + 11_059_200, 33.4e6
 HBM_SPEC_GBS, HBM_ACHIEVABLE_GBS = 8000.0, 6290.0  # MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured (float4 copy)
-CONV_KERNEL_NAME = ("3x3 implicit-GEMM conv, all launches of a step: ss4k::dense::conv3x3_dense2_kernel<4|8> (fused layer pairs "
-                    "(conv1, conv2) / (conv3, conv4) of every RDB, v_mfma_f32_32x32x16_f16) + ss4k::w16::conv3x3_w16_kernel "
-                    "(64-cout tile on v_mfma_f32_16x16x32_f16: conv5 of every RDB with its residual through the matrix core, trunk, conv_hr) "
-                    "+ ss4k::wide::conv3x3_wide_kernel<true> (conv_up1 / conv_up2) + ss4k::conv3x3_kernel<__half,1> (first / last layer)")
 LAUNCHES_PER_FRAME = 213  # 23 blocks x 3 RDBs x (2 fused pairs + conv5) + conv_first, conv_body, conv_up1, conv_up2, conv_hr, conv_last
 
 WORKLOADS = {
@@ -55,46 +55,29 @@ WORKLOADS = {
 }
 
 
-def build_upscaler(ctx, workload, device, lr_shape=(720, 1280), flags=0):
-    """Returns (upscaler, keepalive, algorithmic FLOPs per frame of the networks)."""
-    px = lr_shape[0] * lr_shape[1]
-    def bcast(table, keys):
-        flat = W.flatten(table, keys) if table is not None else None
-        n = sum(int(np.prod(v.shape)) for v in table.values()) if table is not None else 0
-        return flat, n
-    rank = int(os.environ.get("RANK", "0"))
-    if workload in ("fsrcnn", "fsrcnn_f16"):
-        table = W.fsrcnn_table(0)
-        flat = sharding.broadcast_weights(W.flatten(table, W.fsrcnn_keys()) if rank == 0 else None, 12809, device)
-        sr = _capi.Model(ctx, _capi.make_desc(_capi.FSRCNN, _capi.F16 if workload == "fsrcnn_f16" else _capi.F32, scale=2), flat)
-        up = _capi.Upscaler(ctx, sr, lr_shape, None, True, True, None, 1.0)
-        return up, (sr,), 74784.0 * px
-    if workload in ("rrdbnet", "pipeline"):
-        n = 16_703_171
-        flat = sharding.broadcast_weights(W.flatten(W.rrdbnet_table(0, scale=2), W.rrdbnet_keys(23)) if rank == 0 else None, n, device)
-        sr = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, flags=flags), flat)
-        flops = 8.263e12 * px / (720 * 1280)
-        if workload == "rrdbnet":
-            up = _capi.Upscaler(ctx, sr, lr_shape, None, True, False, None, 1.0)
-            return up, (sr,), flops
-        nb = 2_454_583
-        fb = sharding.broadcast_weights(W.flatten(W.bsvd_table(0), W.bsvd_keys()) if rank == 0 else None, nb, device)
-        dn = _capi.Model(ctx, _capi.make_desc(_capi.BSVD, _capi.F16, scale=1), fb)
-        up = _capi.Upscaler(ctx, sr, lr_shape, None, True, True, dn, 1.0)
-        return up, (sr, dn), flops + 590256.0 * px
-    if workload == "rrdbnet_x4":
-        n = 16_697_987
-        flat = sharding.broadcast_weights(W.flatten(W.rrdbnet_table(0, scale=4), W.rrdbnet_keys(23)) if rank == 0 else None, n, device)
-        sr = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=4), flat)
-        up = _capi.Upscaler(ctx, sr, lr_shape, (2160, 3840), True, False, None, 1.0)
-        return up, (sr,), 74.35e12 * px / (1080 * 1920)
-    if workload == "srvgg":
-        t = W.dni_blend(W.srvgg_table(0), W.srvgg_table(1), 0.5)
-        flat = sharding.broadcast_weights(W.flatten(t, W.srvgg_keys(32)) if rank == 0 else None, 1_213_296, device)
-        sr = _capi.Model(ctx, _capi.make_desc(_capi.SRVGG, _capi.F16, scale=4, num_feat=64, num_block=32), flat)
-        up = _capi.Upscaler(ctx, sr, lr_shape, (1440, 2560), True, False, None, 1.0)
-        return up, (sr,), 2.0 * 1_209_024 * px
-    raise SystemExit(f"unknown workload {workload}")
+# workload -> (HipUpscalerService keyword arguments, output_shape, algorithmic FLOPs per input pixel).  Synthetic weights = the generated
+# tables of weights.py (seed 0): there is no network on the GPU boxes to fetch checkpoints from.
+SERVICE_OF = {
+    "fsrcnn": (dict(upscaler_model="fsrcnn", scale=2, denoising=False, fsrcnn_dtype="f32"), None, 74784.0),
+    "fsrcnn_f16": (dict(upscaler_model="fsrcnn", scale=2, denoising=False, fsrcnn_dtype="f16"), None, 74784.0),
+    "rrdbnet": (dict(upscaler_model="realesrgan", model_name="RealESRGAN_x2plus", denoising=False), None, 8.263e12 / (720 * 1280)),
+    "pipeline": (dict(upscaler_model="realesrgan", model_name="RealESRGAN_x2plus", denoising=True, single_mode=True), None,
+                 8.263e12 / (720 * 1280) + 590256.0),
+    "rrdbnet_x4": (dict(upscaler_model="realesrgan", model_name="RealESRGAN_x4plus", denoising=False), (2160, 3840), 74.35e12 / (1080 * 1920)),
+    "srvgg": (dict(upscaler_model="realesrgan", model_name="realesr-general-x4v3", denoise_rate=0.5, denoising=False), (1440, 2560), 2.0 * 1_209_024),
+}
+
+
+def build_service(workload, local, lr_shape=(720, 1280), flags=0, overlap_jobs=True):
+    """-> (service with proc_init() done IN THIS PROCESS - the rank is the worker -, algorithmic FLOPs per frame of its networks).
+    proc_init joins the rank's process group if there is one: rank 0 builds the weight blobs, the others receive them (RCCL)."""
+    if workload not in SERVICE_OF:
+        raise SystemExit(f"unknown workload {workload}")
+    kw, out_shape, flop_px = SERVICE_OF[workload]
+    svc = HipUpscalerService(device=local, weights="synthetic", seed=0, dtype="f16", lr_shape=lr_shape, model_flags=flags, overlap_jobs=overlap_jobs, **kw)
+    svc.output_shape = out_shape
+    svc.proc_init()
+    return svc, flop_px * lr_shape[0] * lr_shape[1]
 
 
 def synthetic_frames(batch, shape, seed):
@@ -233,14 +216,16 @@ def world_seen(world_env):
     return 1
 
 
-def conv_roofline(ctx, up, frames, out, psteps=3):
+def conv_roofline(svc, frames, psteps=3, by_kernel=False):
     """Dominant kernel timed live with HIP events on the launch stream (untimed extra steps)."""
+    ctx = svc.ctx
     ctx.prof_reset(); ctx.prof_enable(True)
     for _ in range(psteps):
-        up(frames, out)
+        svc.upscale(frames, wait=False)
     torch.cuda.synchronize()
     launches, ms, flops = ctx.prof_read()
     sec_ms = ctx.prof_read_section_ms()
+    fams = ctx.prof_read_families() if by_kernel else None
     ctx.prof_enable(False)
     if launches <= 0 or ms <= 0 or sec_ms <= 0:
         return None
@@ -250,19 +235,25 @@ def conv_roofline(ctx, up, frames, out, psteps=3):
     # launches / section time = FLOPs per launch / (average launch duration / launches in flight).  With one chain the
     # section time is the sum of the launch durations plus the boundaries between them.
     ach = flops / (sec_ms * 1e-3) / 1e12
-    return {"achieved": ach, "frac": ach / MFMA_F16_DENSE_PEAK_TFLOPS, "launches_per_step": launches / psteps,
-            "avg_launch_us": 1000.0 * ms / launches, "algorithmic_gflop_per_launch": flops / launches / 1e9,
-            "concurrent_launches": ms / sec_ms, "conv_ms_per_step": sec_ms / psteps}
+    out = {"achieved": ach, "frac": ach / MFMA_F16_DENSE_PEAK_TFLOPS, "launches_per_step": launches / psteps,
+           "avg_launch_us": 1000.0 * ms / launches, "algorithmic_gflop_per_launch": flops / launches / 1e9,
+           "concurrent_launches": ms / sec_ms, "conv_ms_per_step": sec_ms / psteps}
+    if fams:
+        out["by_kernel"] = [{"kernel": name, "launches_per_step": n / psteps, "algorithmic_gflop_per_launch": fl / n / 1e9, "avg_launch_us": 1000.0 * t / n,
+                             "share_of_kernel_time": t / ms, "tflops": fl / (t * 1e-3) / 1e12, "frac": fl / (t * 1e-3) / 1e12 / MFMA_F16_DENSE_PEAK_TFLOPS}
+                            for name, n, t, fl in sorted(fams, key=lambda f: -f[2]) if n > 0 and t > 0]
+    return out
 
 
-def fsrcnn_stage_rooflines(ctx, up, frames, out, psteps=3, half=False):
+def fsrcnn_stage_rooflines(svc, frames, psteps=3, half=False):
     """FSRCNN's three stages timed live (events around each stage on the launch stream), each against the unit that bounds it:
     all three run on the fp16 matrix cores with hi/lo-split operands - three MFMAs per product, so their algorithmic bound is the
     dense fp16 peak / 3 (the exact-fp32 vector-ALU head is kept for SS4K_MODEL_FS_EXACT).  half (dtype f16): every stage is
     one fp16 MFMA per product, against the dense fp16 peak."""
+    ctx = svc.ctx
     ctx.prof_reset(); ctx.prof_enable(True)
     for _ in range(psteps):
-        up(frames, out)
+        svc.upscale(frames, wait=False)
     torch.cuda.synchronize()
     stages = {}
     table = ((1, "head (5x5 conv 1->56 + 1x1 56->12, fp16 MFMA)", MFMA_F16_DENSE_PEAK_TFLOPS, "dense fp16 MFMA peak"),
@@ -322,17 +313,18 @@ def main():
     world = world_seen(world_env)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    ctx = _capi.Context(local)
     in_shape = (1080, 1920) if args.workload == "rrdbnet_x4" else (720, 1280)
-    # SS4K_BENCH_MODEL_FLAGS: SS4K_MODEL_* bits for the headline network (A/B of bit-identical routes under the profiler)
-    up, keep, flops_per_frame = build_upscaler(ctx, args.workload, device, lr_shape=in_shape, flags=int(os.environ.get("SS4K_BENCH_MODEL_FLAGS", "0")))
+    # SS4K_BENCH_MODEL_FLAGS: SS4K_MODEL_* bits for the headline network (A/B of routes under the profiler)
+    svc, flops_per_frame = build_service(args.workload, local, lr_shape=in_shape, flags=int(os.environ.get("SS4K_BENCH_MODEL_FLAGS", "0")))
+    ctx = svc.ctx
 
     # every rank gets its own shard of the synthetic stream: frames rank, rank+world, ...
     frames = synthetic_frames(args.batch, in_shape, seed=1000 + rank).to(device)
-    oh, ow = up.out_shape(args.batch, *in_shape)
-    out = torch.empty((args.batch, oh, ow, 3), dtype=torch.uint8, device=device)
+    oh, ow = svc._get_upscaler().out_shape(args.batch, *in_shape)
 
-    elapsed = run_timed(lambda: up(frames, out), args.steps, args.warmup, world, torch.cuda.synchronize, device)
+    # a step = one job through the service's frame-in/frame-out call; results are ordered on the job set's stream (wait=False, what the
+    # worker loop does) and the timed region ends with a device-wide synchronise
+    elapsed = run_timed(lambda: svc.upscale(frames, wait=False), args.steps, args.warmup, world, torch.cuda.synchronize, device)
     total_frames = args.batch * args.steps * world
     fps = total_frames / elapsed
 
@@ -344,13 +336,14 @@ def main():
         "dtype": "f32" if args.workload == "fsrcnn" else "f16", "data": "synthetic",
         "config": {"workload": WORKLOADS[args.workload], "frames_per_step_per_gpu": args.batch,
                    "in": [in_shape[0], in_shape[1], 3], "out": [oh, ow, 3], "io": "uint8 NHWC resident in HBM",
+                   "path": "HipUpscalerService.upscale -> ss4k_upscale_frames (every rank is a service worker: proc_init joins the group, rank 0 loads, RCCL broadcast)",
                    "parallelism": (f"frame-sharded x{world}, weights broadcast once from rank 0 (RCCL)" if torch.distributed.is_initialized()
                                    else "one GPU, no process group (frames shard one-per-GPU at N > 1; the only collective is the weight broadcast)"),
                    "fps_per_gpu": fps / world, "net_tflops_per_gpu": flops_per_frame * fps / world / 1e12},
     }
 
     if rank == 0 and not args.no_roofline:
-        rl = conv_roofline(ctx, up, frames, out)
+        rl = conv_roofline(svc, frames, by_kernel=True)
         if rl is not None:
             traffic, traffic_src = None, None
             pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
@@ -391,17 +384,34 @@ def main():
                                   "frac": mfma["frac"], "mfma": mfma, "fabric": hbm, "traffic": traffic,
                                   "algorithmic_bytes_per_step": alg_bytes_step,
                                   "traffic_unit": "bytes per launch, L2 <-> fabric (Infinity Cache / HBM), PMC", "traffic_source": traffic_src,
-                                  "kernel": CONV_KERNEL_NAME,
+                                  # the kernel builds this run's conv launches were routed to (ss4k_prof_read_family), by share of kernel time
+                                  "kernel": "3x3 implicit-GEMM conv, all launches of a step: " + " + ".join(k["kernel"].split(" (")[0] for k in rl.get("by_kernel", [])),
                                   "launches_per_step": rl["launches_per_step"],
                                   "avg_launch_us": rl["avg_launch_us"],
                                   "algorithmic_gflop_per_launch": rl["algorithmic_gflop_per_launch"],
                                   "concurrent_launches": rl["concurrent_launches"],
                                   "launches_per_frame_chain": LAUNCHES_PER_FRAME,
                                   "kernel_time_share_of_step": rl["conv_ms_per_step"] / (1000.0 * elapsed / args.steps)}
+            if args.workload == "rrdbnet" and world == 1:
+                # per kernel build, from a ONE-CHAIN run of the same job (SS4K_MODEL_ONE_CHAIN: with two launch chains in flight a launch's
+                # duration includes the time it shares the chip with the other chain's launch - nobody should have to divide by 1.9)
+                try:
+                    svc1, _ = build_service("rrdbnet", local, lr_shape=in_shape, flags=_capi.MODEL_ONE_CHAIN)
+                    for _ in range(2):
+                        svc1.upscale(frames, wait=False)
+                    rl1 = conv_roofline(svc1, frames, psteps=2, by_kernel=True)
+                    result["roofline"]["by_kernel"] = {"what": "one launch chain (SS4K_MODEL_ONE_CHAIN), every launch alone on the chip: algorithmic GFLOP / average launch "
+                                                               "duration (HIP events on the launch stream) against the dense fp16 MFMA peak",
+                                                       "frames_per_launch": args.batch, "conv_tflops": rl1["achieved"], "conv_frac_of_peak": rl1["frac"],
+                                                       "kernels": rl1.get("by_kernel", [])}
+                    del svc1
+                    torch.cuda.empty_cache()
+                except Exception as e:  # never lose the headline line to a secondary measurement
+                    result["roofline"]["by_kernel"] = {"error": str(e)}
         elif args.workload in ("fsrcnn", "fsrcnn_f16"):
             # FSRCNN: three stages, each against the unit that bounds it (fsrcnn_stage_rooflines); the line's roofline is the
             # stage that takes the longest
-            stages = fsrcnn_stage_rooflines(ctx, up, frames, out, half=args.workload == "fsrcnn_f16")
+            stages = fsrcnn_stage_rooflines(svc, frames, half=args.workload == "fsrcnn_f16")
             if stages:
                 name, dom = max(stages.items(), key=lambda kv: kv[1]["ms_per_step"])
                 result["roofline"] = {"bound": "mfma", "achieved": dom["achieved_tflops"], "peak": dom["peak_tflops"], "unit": "TFLOP/s",
@@ -411,31 +421,38 @@ def main():
         # the other single-GPU BASELINE configs and the 1-frame (image-server / latency) job, measured the
         # same way (short, outside the headline timing); conv-based ones carry their own roofline fraction
         also = {}
+
+        def timed(svc2, fr2, reps):
+            for _ in range(3):
+                svc2.upscale(fr2, wait=False)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(reps):
+                svc2.upscale(fr2, wait=False)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1
+
         for name, wl, nb, shape, reps in (("fsrcnn", "fsrcnn", args.batch, (720, 1280), 10),
                                           ("fsrcnn_f16", "fsrcnn_f16", args.batch, (720, 1280), 10),
                                           ("pipeline", "pipeline", args.batch, (720, 1280), 10),
                                           ("srvgg", "srvgg", args.batch, (720, 1280), 10),
-                                          ("rrdbnet_n1", "rrdbnet", 1, (720, 1280), 20),
-                                          ("rrdbnet_n1_chain", "rrdbnet", 1, (720, 1280), 20),
+                                          ("rrdbnet_n1", "rrdbnet", 1, (720, 1280), 40),
+                                          ("rrdbnet_n1_one_set", "rrdbnet", 1, (720, 1280), 20),
                                           ("rrdbnet_x4", "rrdbnet_x4", 1, (1080, 1920), 5)):
-            # rrdbnet_n1_chain: the RRDB body as one persistent launch with per-tile hand-offs (SS4K_MODEL_CHAIN, csrc/conv_chain.hip)
-            up2, keep2, fpf = (up, keep, flops_per_frame) if name == "rrdbnet_n1" else build_upscaler(
-                ctx, wl, device, lr_shape=shape, flags=_capi.MODEL_CHAIN if name == "rrdbnet_n1_chain" else 0)
+            # rrdbnet_n1: back-to-back one-frame jobs from ONE service (the image server's caller): consecutive jobs alternate over the
+            # service's two job sets (hip_upscaler.py); rrdbnet_n1_one_set: the same with overlap_jobs=False (every job on one set / stream)
+            if name == "rrdbnet_n1":
+                svc2, fpf = svc, flops_per_frame
+            else:
+                svc2, fpf = build_service(wl, local, lr_shape=shape, overlap_jobs=name != "rrdbnet_n1_one_set")
             fr2 = frames[:nb] if shape == in_shape else synthetic_frames(nb, shape, seed=77).to(device)
-            o2h, o2w = up2.out_shape(nb, *shape)
-            out2 = torch.empty((nb, o2h, o2w, 3), dtype=torch.uint8, device=device)
-            for _ in range(3):
-                up2(fr2, out2)
-            torch.cuda.synchronize(); t1 = time.perf_counter()
-            for _ in range(reps):
-                up2(fr2, out2)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            also[name] = {"workload": WORKLOADS[wl] + (", body as one chained launch (SS4K_MODEL_CHAIN)" if name.endswith("_chain") else ""),
-                          "frames_per_step": nb, "fps": reps * nb / dt,
-                          "net_tflops": fpf * reps * nb / dt / 1e12}
-            if not wl.startswith("fsrcnn"):
-                rl = conv_roofline(ctx, up2, fr2, out2, psteps=2)
+            dt = timed(svc2, fr2, reps)
+            also[name] = {"workload": WORKLOADS[wl] + (", back-to-back one-frame jobs from one service, alternating over its two job sets" if name == "rrdbnet_n1" else
+                                                       ", one-frame jobs on one job set (overlap_jobs=False)" if name == "rrdbnet_n1_one_set" else ""),
+                          "frames_per_step": nb, "fps": reps * nb / dt, "net_tflops": fpf * reps * nb / dt / 1e12}
+            if name == "rrdbnet_n1":
+                also[name]["job_sets"] = len(svc2._sets)
+            elif not wl.startswith("fsrcnn"):
+                rl = conv_roofline(svc2, fr2, psteps=2)
                 if rl is not None:
                     also[name]["conv_tflops"] = rl["achieved"]; also[name]["conv_frac_of_peak"] = rl["frac"]
                     also[name]["conv_launches_per_step"] = rl["launches_per_step"]
@@ -446,44 +463,46 @@ def main():
                     also[name]["frac_of_fp32_peak"] = also[name]["net_tflops"] / F32_VECTOR_PEAK_TFLOPS
                 else:
                     # the fp16 mode's uint8 frames against the fp32-accurate mode's on the same job
-                    up3, keep3, _ = build_upscaler(ctx, "fsrcnn", device, lr_shape=shape)
-                    out3 = torch.empty_like(out2)
-                    up3(fr2, out3); up2(fr2, out2); torch.cuda.synchronize()
+                    svc3, _ = build_service("fsrcnn", local, lr_shape=shape)
+                    out3, out2 = svc3.upscale(fr2), svc2.upscale(fr2)
+                    torch.cuda.synchronize()
                     d = out2.to(torch.int16) - out3.to(torch.int16)
                     mse = float((d.float() ** 2).mean())
                     also[name]["u8_vs_f32_mode"] = {"psnr_db": None if mse == 0 else 10 * math.log10(255.0 ** 2 / mse),
                                                     "max_lsb": int(d.abs().max()), "frac_differing": float((d != 0).float().mean())}
-                    del up3, keep3, out3
-                also[name]["stages"] = fsrcnn_stage_rooflines(ctx, up2, fr2, out2, half=wl == "fsrcnn_f16")
-            del out2, fr2
+                    del svc3, out3, out2
+                also[name]["stages"] = fsrcnn_stage_rooflines(svc2, fr2, half=wl == "fsrcnn_f16")
+            del fr2
             if name != "rrdbnet_n1":
-                del up2, keep2
+                del svc2
             torch.cuda.empty_cache()
-        # 1-frame jobs from TWO callers (two upscalers, two streams, jobs alternating): what an image server with two requests
-        # queued gets from this GPU - the overlap the frame lanes give a multi-frame job, done by the caller
+        # ... and the same one-frame jobs through a REAL worker process of the service (spawned child, job / result queues, CUDA-IPC
+        # tensors, deliver_lag = 1): what an integrator's image server gets from one GPU
         try:
-            up_b, keep_b, _ = build_upscaler(_capi.Context(local), "rrdbnet", device, lr_shape=in_shape)
-            fr1 = frames[:1]
-            o2h, o2w = up.out_shape(1, *in_shape)
-            outs2 = [torch.empty((1, o2h, o2w, 3), dtype=torch.uint8, device=device) for _ in range(2)]
-            sts = [torch.cuda.Stream(device), torch.cuda.Stream(device)]
-            pair = [up, up_b]
-            def two(reps):
-                for i in range(reps):
-                    with torch.cuda.stream(sts[i % 2]):
-                        pair[i % 2](fr1, outs2[i % 2])
-            torch.cuda.synchronize(); two(6); torch.cuda.synchronize()
-            t1 = time.perf_counter(); two(40); torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            also["rrdbnet_n1_two_callers"] = {"workload": WORKLOADS["rrdbnet"] + ", 1-frame jobs alternating over two upscalers on two streams",
-                                              "frames_per_step": 1, "fps": 40 / dt, "net_tflops": flops_per_frame * 40 / dt / 1e12}
-            del up_b, keep_b, outs2
-            torch.cuda.empty_cache()
+            from sharkshark4k_amd.upscale.upscaler_base import UpscalerQueueEntry
+            kw, _, _ = SERVICE_OF["rrdbnet"]
+            wsvc = HipUpscalerService(device=local, weights="synthetic", seed=0, dtype="f16", lr_shape=in_shape, **kw)
+            wsvc.start()
+            fr1 = frames[:1].clone()
+            n_jobs, depth = 60, 8
+            def pump(n):
+                sent = got = 0
+                while got < n:
+                    while sent < n and sent - got < depth:
+                        wsvc.push_job(UpscalerQueueEntry(frames=fr1, step=sent), timeout=600)
+                        sent += 1
+                    wsvc.get_result(timeout=600)
+                    got += 1
+            pump(6)
+            t1 = time.perf_counter(); pump(n_jobs); dt = time.perf_counter() - t1
+            wsvc.stop()
+            also["rrdbnet_n1_worker"] = {"workload": WORKLOADS["rrdbnet"] + f", one-frame jobs through a spawned service worker (queues + CUDA IPC, {depth} jobs in flight)",
+                                         "frames_per_step": 1, "fps": n_jobs / dt, "net_tflops": flops_per_frame * n_jobs / dt / 1e12}
         except Exception as e:  # never lose the headline line to a secondary measurement
-            also["rrdbnet_n1_two_callers"] = {"error": str(e)}
+            also["rrdbnet_n1_worker"] = {"error": f"{type(e).__name__}: {e}"}
         result["also"] = also
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cb, psnr = cpu_baseline(args.workload, ctx)
+        cb, psnr = cpu_baseline(args.workload, _capi.Context(local))
         result["cpu_baseline"] = cb
         result["psnr_db_vs_cpu_ref"] = psnr
     if world > 1:

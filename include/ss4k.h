@@ -30,8 +30,9 @@
 extern "C" {
 #endif
 
-#define SS4K_ABI_VERSION 2   /* 2: ss4k_model_desc.reserved[0] became the validated `flags` word (must be 0 or SS4K_MODEL_* bits);
-                                 ss4k_prof_read_kind and ss4k_model_check were added */
+#define SS4K_ABI_VERSION 3   /* 3: the register-stationary kernel and the cross-layer chain left the product library (dev library only): flag bits 8
+                                 (NO_RS), 64 (NO_CHAIN), 128 (CHAIN), 2048 (DENSE) and 16384 (CONV5_RS) are no longer accepted;
+                                 ss4k_prof_read_family was added.  2: ss4k_model_desc.reserved[0] became the validated `flags` word */
 
 enum { SS4K_OK = 0, SS4K_EINVAL = -22, SS4K_ENOMEM = -12, SS4K_EHIP = -5, SS4K_ENODEV = -19 };
 
@@ -76,48 +77,36 @@ typedef struct ss4k_model_desc {
 } ss4k_model_desc;
 
 enum {
+  /* --- what a deployment may want to choose ---------------------------------------------------------------------------------- */
   SS4K_MODEL_FS_EXACT = 1,      /* FSRCNN: exact-fp32 kernels for every stage instead of the fp16 hi/lo-split matrix-core
                                    stages (fp32-grade, ~1e-6 of the exact ones); also chosen automatically when the
                                    checkpoint's range does not fit the split (a weight >= 6e4: Model::build, csrc/models.cpp) */
-  SS4K_MODEL_ONE_CHAIN = 2,     /* an even job never runs as two concurrent launch chains (frame lanes) */
+  SS4K_MODEL_ONE_CHAIN = 2,     /* a multi-frame job never runs as two concurrent launch chains (frame lanes) */
   SS4K_MODEL_TWO_CHAINS = 4,    /* ... always does (default: measured per shape over the first calls) */
-  SS4K_MODEL_NO_RS = 8,         /* every conv layer on the LDS-weights kernel (conv_mfma.hip); default: conv5 of an RDB on the
-                                   register-stationary kernel (conv_rs.hip).  Changes the order of fp32 additions inside a
-                                   layer (one fp16 rounding per layer either way) */
-  SS4K_MODEL_TILE_ROWS_16 = 16, /* 32-cout body layers on 16-row tiles ... */
-  SS4K_MODEL_TILE_ROWS_20 = 32, /* ... or on 20-row tiles (default: by image height); bit-identical results */
-  SS4K_MODEL_NO_CHAIN = 64,     /* RRDBNet body as one launch per layer: this IS the default, the bit only states it */
-  SS4K_MODEL_CHAIN = 128,       /* opt-in: the RRDB body of every fp16 job as ONE persistent launch with per-tile hand-offs
-                                   (csrc/conv_chain.hip); bit-identical results.  The latency mode of a service that is the
-                                   GPU's only caller; its asynchronous failure mode is reported by ss4k_model_check */
-  SS4K_MODEL_NO_PAIR = 256,     /* BSVD: the full-resolution layer pairs (inc, outc) as two launches each instead of the fused
-                                   row-marching kernel (conv_pair.hip); bit-identical results */
   SS4K_MODEL_HR_F32 = 512,      /* fp16 SRVGG / fp16-mode FSRCNN on the service paths: keep the network's output tensor (x4 on 720p: 2880 x 5120 x 3
                                    per frame) in fp32; default: fp16 (half the bytes of the service's four passes over it; the uint8 frames
                                    differ by at most 1 LSB in a few per cent of the bytes - an fp16 model's own error is 30 dB above that) */
-  SS4K_MODEL_NO_DENSE = 1024,   /* RRDBNet: conv1..conv4 of every dense block always as four launches, never as two fused layer pairs
-                                   (csrc/conv_dense.hip: (conv1, conv2) and (conv3, conv4) stream their shared input planes once and
-                                   hand x1 / x3 over in LDS); bit-identical results.  Default: fused */
-  SS4K_MODEL_DENSE = 2048,      /* ... fused pairs pinned (today's default; a test or caller that must not follow a later change of
-                                   the default policy sets it) */
-  SS4K_MODEL_NO_WIDE = 4096,    /* fp16 layers with 64-cout groups and a plain epilogue (RRDBNet trunk / tail, SRVGG body, BSVD) on
-                                   conv_mfma.hip's <2,4,4> build - neither conv_dense.hip's single-layer build (bit-identical to it) nor
-                                   conv_w16.hip's (see SS4K_MODEL_NO_W16) */
   SS4K_MODEL_NO_UPS_PRESUM = 8192, /* RRDBNet fp16: conv_up1 / conv_up2 (3x3 convs on a nearest-x2 up-sampled tensor) in the direct form.
                                    Default: two of the three input rows an output row reads are the same low-resolution row, so their two
                                    MFMAs per tap column run as one with the weight fragments added in fp16 (6 instead of 9 MFMAs per
-                                   pixel).  The only routing bit that is NOT bit-identical: one more fp16 rounding of a weight sum */
-  SS4K_MODEL_CONV5_RS = 16384,  /* RRDBNet fp16: conv5 of every RDB on the register-stationary kernel (conv_rs.hip) for every job size.  Default:
-                                   conv_w16.hip with the residual through the matrix core, for every job size (4 frames of 720p + 1.6 %, one frame
-                                   + 3.9 %); with SS4K_MODEL_NO_W16 the round-3 rule: jobs with fewer than three rounds of 16 x 32 tiles per 256
-                                   workgroup slots (one 720p frame) on the wide kernel, larger ones on conv_rs.hip - then, and only then, a
-                                   frame's last bits depend on the size of the job it arrived in */
-  SS4K_MODEL_NO_W16 = 32768,    /* fp16 layers with 64-cout groups, a plain epilogue and an even number of 16-channel input planes (SRVGG body, RRDBNet
-                                   trunk / tail, BSVD) on the v_mfma_f32_32x32x16_f16 build of the tile (conv_dense.hip's wide kernel) instead of
-                                   conv_w16.hip's v_mfma_f32_16x16x32_f16 build (default since round 4: the chip runs these layers at its power cap
-                                   and holds a 10 % higher clock on that shape; SRVGG x4 720p + 12 %).  The two builds add the same products in a
+                                   pixel): one more fp16 rounding of a weight sum, NOT bit-identical to the direct form */
+  SS4K_MODEL_NO_W16 = 32768,    /* fp16 layers with 64-cout groups and an even number of 16-channel input planes (SRVGG body, RRDBNet conv5 / trunk /
+                                   tail, BSVD) on the v_mfma_f32_32x32x16_f16 build of the tile (conv_dense.hip's wide kernel) instead of
+                                   conv_w16.hip's v_mfma_f32_16x16x32_f16 build (default: the chip runs these layers at its power cap and holds
+                                   a 10 % higher clock on that shape; SRVGG x4 720p + 12 %).  The two builds add the same products in a
                                    different order: results differ in the last bits, the accuracy against the oracle is the same */
-  SS4K_MODEL_FLAGS_ALL = 65535
+  /* --- pins of a fallback route the library takes by itself for some shapes: BIT-IDENTICAL results, used by the parity tests -------- */
+  SS4K_MODEL_TILE_ROWS_16 = 16, /* 32-cout layers (conv_mfma.hip) on 16-row tiles ... */
+  SS4K_MODEL_TILE_ROWS_20 = 32, /* ... or on 20-row tiles (default: by image height) */
+  SS4K_MODEL_NO_PAIR = 256,     /* BSVD: the full-resolution layer pairs (inc, outc) as two launches each instead of the fused
+                                   row-marching kernel (conv_pair.hip) */
+  SS4K_MODEL_NO_DENSE = 1024,   /* RRDBNet: conv1..conv4 of every dense block as four launches, never as two fused layer pairs
+                                   (csrc/conv_dense.hip: (conv1, conv2) and (conv3, conv4) stream their shared input planes once and
+                                   hand x1 / x3 over in LDS) - what a job whose planes exceed 4 GB gets anyway */
+  SS4K_MODEL_NO_WIDE = 4096,    /* fp16 layers with 64-cout groups and a plain epilogue on conv_mfma.hip's <2,4,4> build - what a layer of a job
+                                   whose planes exceed 4 GB gets anyway - instead of conv_dense.hip's single-layer build (bit-identical to it);
+                                   implies NO_W16 */
+  SS4K_MODEL_FLAGS_ALL = 1 | 2 | 4 | 16 | 32 | 256 | 512 | 1024 | 4096 | 8192 | 32768
 };
 
 int ss4k_abi_version(void);
@@ -155,12 +144,10 @@ int ss4k_model_workspace_bytes(ss4k_model* m, int n, int h, int w, size_t* bytes
 int ss4k_model_forward(ss4k_model* m, const float* in_nchw_dev, float* out_nchw_dev, int n, int h,
                        int w, void* hip_stream);
 
-/* Asynchronous status of the model's earlier forwards.  Only the cross-layer chain kernel (SS4K_MODEL_CHAIN) has one: a work
- * unit that waited for its neighbours past a bound gives up (the launch always drains) and marks a sticky word that no later
- * launch resets.  Returns SS4K_OK, or SS4K_EHIP once per failure (the outputs since the last successful check are void).
- * wait != 0: first block until the model's last chain launch has finished, so the answer covers the forward just enqueued -
- * call it where the result is consumed.  wait == 0 never blocks; the next ss4k_model_forward performs the same check.
- * Models without a chain launch return SS4K_OK at once. */
+/* Asynchronous status of the model's earlier forwards.  No kernel of the product library has an asynchronous failure mode: always
+ * SS4K_OK, at once.  (The dev library's cross-layer chain kernel - include/ss4k_dev.h, SS4K_DEV_MODEL_CHAIN - marks a sticky word when a
+ * work unit gives up waiting for its neighbours; there this call returns SS4K_EHIP once per failure, after blocking until the model's
+ * last chain launch has finished when wait != 0.) */
 int ss4k_model_check(ss4k_model* m, int wait);
 
 /* ---- the service's frame-in/frame-out hot path ------------------------------------------- */
@@ -237,6 +224,11 @@ int ss4k_prof_read(ss4k_ctx* ctx, int64_t* launches, double* total_ms, double* f
 /* The same per kernel family: kind 0 = the 3x3 conv kernels (what ss4k_prof_read returns), 1 / 2 / 3 = FSRCNN's head (5x5 conv +
  * shrink), mapping (4 x conv3x3 12->12) and tail (expand + 9x9 transposed conv) stages, each bracketed as one unit. */
 int ss4k_prof_read_kind(ss4k_ctx* ctx, int kind, int64_t* launches, double* total_ms, double* flops);
+/* ... and per kernel BUILD of the conv launches (which tile / MFMA shape / epilogue form a launch was routed to), since the last reset:
+ * index 0 .. n-1 in name order, SS4K_EINVAL past the last one.  `name` receives a NUL-terminated description that starts with the kernel's
+ * C++ name as rocprofv3 prints it (e.g. "w16::conv3x3_w16_kernel<RL> (...)").  With two launch chains in flight the per-launch times overlap:
+ * read these from a one-chain run (SS4K_MODEL_ONE_CHAIN) when a kernel's own rate is wanted. */
+int ss4k_prof_read_family(ss4k_ctx* ctx, int index, char* name, size_t name_capacity, int64_t* launches, double* total_ms, double* flops);
 /* Conv sections: wall time, on the caller's stream, from the first conv launch of every network forward to the end
  * of its last one (launch boundaries included).  A job's frames may go through the conv layers as two CONCURRENT launch
  * chains (frame lanes): the per-launch times of ss4k_prof_read then overlap, and sum(FLOPs) / section time is the rate

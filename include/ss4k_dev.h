@@ -11,6 +11,14 @@
 extern "C" {
 #endif
 
+/* ss4k_model_desc.flags bits only libss4k_hip_dev.so accepts: kernels of rounds 2-4 that are on no product route any more. */
+enum {
+  SS4K_DEV_MODEL_CHAIN = 128,      /* RRDBNet fp16: the RRDB body of every job as ONE persistent launch with per-tile hand-offs (csrc/conv_chain.hip);
+                                      bit-identical to SS4K_MODEL_NO_DENSE | SS4K_MODEL_NO_WIDE.  Its asynchronous failure mode: ss4k_model_check */
+  SS4K_DEV_MODEL_CONV5_RS = 16384, /* RRDBNet fp16: conv5 of every RDB on the register-stationary kernel (csrc/conv_rs.hip) */
+  SS4K_DEV_MODEL_FLAGS_ALL = 128 | 16384
+};
+
 /* Times ONE 3x3 conv layer (cin0 [+ cin1 concat] -> cout) in isolation on random operands: average
  * microseconds per launch over `iters` launches.
  * flags: 0 = the production kernel for that shape;

@@ -27,7 +27,7 @@ SYMBOLS = [
     "ss4k_upscaler_reset", "ss4k_upscaler_out_shape", "ss4k_upscaler_last_enqueue_ms", "ss4k_model_workspace_bytes", "ss4k_upscale_frames", "ss4k_upscaler_enable_taps",
     "ss4k_upscaler_read_tap", "ss4k_op_u8nhwc_to_f32nchw", "ss4k_op_area_resize", "ss4k_op_bicubic_resize",
     "ss4k_op_bilinear_resize", "ss4k_op_depthwise_reflect", "ss4k_op_plane_stats", "ss4k_op_f32nchw_to_u8nhwc",
-    "ss4k_prof_enable", "ss4k_prof_reset", "ss4k_prof_read", "ss4k_prof_read_kind", "ss4k_prof_read_section_ms",
+    "ss4k_prof_enable", "ss4k_prof_reset", "ss4k_prof_read", "ss4k_prof_read_kind", "ss4k_prof_read_family", "ss4k_prof_read_section_ms",
 ]
 DEV_SYMBOLS = ["ss4k_bench_conv"]  # include/ss4k_dev.h: libss4k_hip_dev.so only (SS4K_LIB=.../libss4k_hip_dev.so)
 
@@ -40,8 +40,11 @@ class ModelDesc(C.Structure):
 
 
 # ss4k_model_desc.flags (include/ss4k.h)
-MODEL_FS_EXACT, MODEL_ONE_CHAIN, MODEL_TWO_CHAINS, MODEL_NO_RS, MODEL_TILE_ROWS_16, MODEL_TILE_ROWS_20 = 1, 2, 4, 8, 16, 32
-MODEL_NO_CHAIN, MODEL_CHAIN, MODEL_NO_PAIR, MODEL_HR_F32, MODEL_NO_DENSE, MODEL_DENSE, MODEL_NO_WIDE, MODEL_NO_UPS_PRESUM, MODEL_CONV5_RS, MODEL_NO_W16 = 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768
+MODEL_FS_EXACT, MODEL_ONE_CHAIN, MODEL_TWO_CHAINS, MODEL_TILE_ROWS_16, MODEL_TILE_ROWS_20 = 1, 2, 4, 16, 32
+MODEL_NO_PAIR, MODEL_HR_F32, MODEL_NO_DENSE, MODEL_NO_WIDE, MODEL_NO_UPS_PRESUM, MODEL_NO_W16 = 256, 512, 1024, 4096, 8192, 32768
+MODEL_FLAGS_ALL = 1 | 2 | 4 | 16 | 32 | 256 | 512 | 1024 | 4096 | 8192 | 32768
+# include/ss4k_dev.h: accepted by libss4k_hip_dev.so only (kernels of rounds 2-4 that are on no product route: tools/dev_tests/)
+DEV_MODEL_CHAIN, DEV_MODEL_CONV5_RS = 128, 16384
 
 
 class UpscaleCfg(C.Structure):
@@ -106,6 +109,8 @@ def load(path: str) -> C.CDLL:
     L.ss4k_prof_read.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if hasattr(L, "ss4k_prof_read_kind"):
         L.ss4k_prof_read_kind.argtypes = [vp, i, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    if hasattr(L, "ss4k_prof_read_family"):
+        L.ss4k_prof_read_family.argtypes = [vp, i, C.c_char_p, sz, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ss4k_prof_read_section_ms.argtypes = [vp, C.POINTER(C.c_double)]
     return L
 
@@ -162,6 +167,16 @@ class Context:
         n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
         _check(lib().ss4k_prof_read_kind(self._h, kind, C.byref(n), C.byref(ms), C.byref(fl)))
         return n.value, ms.value, fl.value
+
+    def prof_read_families(self):
+        """[(kernel build, launches, total ms, algorithmic FLOPs)] of the conv launches since the last reset."""
+        out, idx = [], 0
+        while True:
+            name, n, ms, fl = C.create_string_buffer(256), C.c_int64(), C.c_double(), C.c_double()
+            if lib().ss4k_prof_read_family(self._h, idx, name, 256, C.byref(n), C.byref(ms), C.byref(fl)) != 0:
+                return out
+            out.append((name.value.decode(), n.value, ms.value, fl.value))
+            idx += 1
 
     def prof_read_section_ms(self) -> float:
         """Wall time of the profiled forwards' conv sections (first conv launch to the end of the last, caller's stream)."""

@@ -14,8 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libss4k_hip.so")
 LIB_DEV = os.path.join(HERE, "libss4k_hip_dev.so")
-SOURCES = ["conv_mfma.hip", "conv_rs.hip", "conv_chain.hip", "conv_pair.hip", "conv_dense.hip", "conv_w16.hip", "conv_w16n.hip", "glue.hip", "fsrcnn.hip", "pack.cpp", "models.cpp", "api.cpp"]
-DEV_SOURCES = ["conv_s3.hip", "conv_d16.hip"]   # measurement-only experiments: libss4k_hip_dev.so alone
+SOURCES = ["conv_mfma.hip", "conv_pair.hip", "conv_dense.hip", "conv_w16.hip", "conv_w16n.hip", "glue.hip", "fsrcnn.hip", "pack.cpp", "models.cpp", "api.cpp"]
+# libss4k_hip_dev.so alone: measured experiments (conv_s3, conv_d16) and the kernels of rounds 2-4 that no product route uses any more
+# (conv_rs: register-stationary weights; conv_chain: the RRDB body as one persistent launch) - tools/dev_tests/ keeps them honest
+DEV_SOURCES = ["conv_s3.hip", "conv_d16.hip", "conv_rs.hip", "conv_chain.hip"]
 # conv_rs.hip: the per-tile body is thousands of fully unrolled MFMAs (weights live in named registers); hipcc's
 # default cap on '#pragma unroll' size would leave the chunk loop rolled and the weights in scratch
 EXTRA_FLAGS = {"conv_rs.hip": ["-mllvm", "-pragma-unroll-threshold=4000000"]}

@@ -470,6 +470,7 @@ static void prof_collect(ss4k_ctx* c) {
     const int k = e.kind >= 0 && e.kind < PROF_KINDS ? e.kind : 0;
     c->kind_ms[k] += ms; c->kind_flops[k] += e.flops; c->kind_launches[k] += 1;
     if (k == PROF_CONV) { c->prof_ms += ms; c->prof_flops += e.flops; c->prof_launches += 1; }
+    if (e.family) { auto& f = c->prof_families[e.family]; f.launches += 1; f.ms += ms; f.flops += e.flops; }
     c->prof_pool.push_back(e);
   }
   c->prof_events.clear();
@@ -484,7 +485,21 @@ static void prof_collect(ss4k_ctx* c) {
 int ss4k_prof_enable(ss4k_ctx* c, int en) { if (!c) return SS4K_EINVAL; c->prof = en != 0; return SS4K_OK; }
 int ss4k_prof_reset(ss4k_ctx* c) {
   return guard([&] { SS4K_REQUIRE(c, "NULL ctx"); prof_collect(c); c->prof_ms = 0; c->prof_section_ms = 0; c->prof_flops = 0; c->prof_launches = 0;
+    c->prof_families.clear();
     for (int k = 0; k < PROF_KINDS; ++k) { c->kind_ms[k] = 0; c->kind_flops[k] = 0; c->kind_launches[k] = 0; } });
+}
+int ss4k_prof_read_family(ss4k_ctx* c, int index, char* name, size_t name_capacity, int64_t* launches, double* ms, double* flops) {
+  return guard([&] {
+    SS4K_REQUIRE(c && index >= 0 && name && name_capacity > 0, "ss4k_prof_read_family: bad argument");
+    prof_collect(c);
+    SS4K_REQUIRE((size_t)index < c->prof_families.size(), "ss4k_prof_read_family: index past the last family");
+    auto it = c->prof_families.begin();
+    std::advance(it, index);
+    std::snprintf(name, name_capacity, "%s", it->first.c_str());
+    if (launches) *launches = it->second.launches;
+    if (ms) *ms = it->second.ms;
+    if (flops) *flops = it->second.flops;
+  });
 }
 int ss4k_prof_read(ss4k_ctx* c, int64_t* launches, double* ms, double* flops) {
   return guard([&] {

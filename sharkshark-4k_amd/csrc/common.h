@@ -12,6 +12,9 @@
 #include <vector>
 #include <stdexcept>
 #include "../../include/ss4k.h"
+#ifdef SS4K_DEV
+#include "../../include/ss4k_dev.h"
+#endif
 
 namespace ss4k {
 
@@ -59,7 +62,8 @@ struct DevBuf {
   template <typename T> T* as() const { return reinterpret_cast<T*>(ptr); }
 };
 
-struct ProfEvent { hipEvent_t a, b; double flops; int kind; };   // kind: PROF_* below
+struct ProfEvent { hipEvent_t a, b; double flops; int kind; const char* family; };   // kind: PROF_* below; family: the launcher's static name for the kernel build it chose (or null)
+struct ProfFamily { int64_t launches = 0; double ms = 0, flops = 0; };
 enum { PROF_CONV = 0, PROF_FS_HEAD = 1, PROF_FS_MAP = 2, PROF_FS_TAIL = 3, PROF_KINDS = 4 };
 
 }  // namespace ss4k
@@ -74,6 +78,8 @@ struct ss4k_ctx {
   std::vector<ss4k::ProfEvent> prof_events;
   std::vector<ss4k::ProfEvent> prof_pool;
   int64_t prof_launches = 0;
+  const char* prof_family = nullptr;   // set by the innermost launcher while a ProfScope is open: which kernel build the launch went to
+  std::map<std::string, ss4k::ProfFamily> prof_families;   // per kernel build since the last reset (ss4k_prof_read_family)
   std::set<const void*> lds_attr_set;  // kernels whose dynamic-LDS limit was raised on this device
   double prof_ms = 0, prof_flops = 0;
   double kind_ms[ss4k::PROF_KINDS] = {}, kind_flops[ss4k::PROF_KINDS] = {}; int64_t kind_launches[ss4k::PROF_KINDS] = {};
@@ -97,7 +103,7 @@ struct ss4k_ctx {
   double prof_section_ms = 0;
   ss4k::ProfEvent prof_get_events() {
     ss4k::ProfEvent pe{};
-    if (!prof_pool.empty()) { pe = prof_pool.back(); prof_pool.pop_back(); pe.flops = 0; pe.kind = 0; return pe; }
+    if (!prof_pool.empty()) { pe = prof_pool.back(); prof_pool.pop_back(); pe.flops = 0; pe.kind = 0; pe.family = nullptr; return pe; }
     if (hipEventCreate(&pe.a) != hipSuccess || hipEventCreate(&pe.b) != hipSuccess) throw ss4k::Error(SS4K_EHIP, "hipEventCreate failed");
     return pe;
   }
@@ -112,7 +118,7 @@ struct ss4k_ctx {
   void prof_end(ss4k::ProfEvent pe, hipStream_t st, double flops) {
     if (!pe.a) return;
     if (hipEventRecord(pe.b, st) != hipSuccess) throw ss4k::Error(SS4K_EHIP, "hipEventRecord failed");
-    pe.flops = flops; prof_events.push_back(pe);
+    pe.flops = flops; pe.family = prof_family; prof_family = nullptr; prof_events.push_back(pe);
   }
   const char* zero_page() {
     auto& b = scratch["zero_page"];

@@ -805,6 +805,9 @@ void launch_conv3x3_wide(ss4k_ctx* ctx, const ConvArgs& a0, hipStream_t st) {
   const bool rl = a.wide_rl && a.res1 && a.act == ACT_NONE && alpha_exact && a.nchunks0 == 4 && a.cout_pad == 64 && !a.ups2 &&
                   a.res1 + (size_t)a.r1_plane0 * a.r1_plane_bytes == a.in0 + (size_t)a.in0_plane0 * a.in0_plane_bytes &&
                   a.r1_plane_bytes == a.in0_plane_bytes;
+  ctx->prof_family = rl ? "wide::conv3x3_wide_kernel<RL> (64-cout tile, 32x32x16 MFMA, residual through the matrix core)"
+                     : (a.ups2 && a.ups_presum) ? "wide::conv3x3_wide_kernel<UPS> (64-cout tile, 32x32x16 MFMA, nearest-x2 input, pre-summed row taps)"
+                                                : "wide::conv3x3_wide_kernel (64-cout tile, 32x32x16 MFMA)";
   if (rl) go(&conv3x3_wide_kernel<false, true>);
   else if (a.ups2 && a.ups_presum) go(&conv3x3_wide_kernel<true>);
   else go(&conv3x3_wide_kernel<false>);
@@ -869,6 +872,9 @@ void launch_conv3x3_dense2(ss4k_ctx* ctx, const DenseArgs& a0, hipStream_t st) {
     return;
   }
 #endif
+  ctx->prof_family = a.nchunks0 + a.nchunks1 == 4 ? "dense::conv3x3_dense2_kernel<4> (fused pair conv1 + conv2 of an RDB, 32x32x16 MFMA)"
+                     : a.nchunks0 + a.nchunks1 == 8 ? "dense::conv3x3_dense2_kernel<8> (fused pair conv3 + conv4 of an RDB, 32x32x16 MFMA)"
+                                                    : "dense::conv3x3_dense2_kernel<0> (fused layer pair, 32x32x16 MFMA)";
   switch (a.nchunks0 + a.nchunks1) {
     case 4: go(&conv3x3_dense2_kernel<4>); break;
     case 8: go(&conv3x3_dense2_kernel<8>); break;

@@ -690,6 +690,10 @@ static void launch_t(ss4k_ctx* ctx, const ConvArgs& a0, int groups, hipStream_t 
   if (ctx->lds_attr_set.insert(fn).second)  // per context = per device
     SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int gx = std::min(ntiles, std::max(1, (int)(ctx->num_cu * per_cu / groups * (a.grid_share > 0.f ? a.grid_share : 1.f))));
+  ctx->prof_family = std::is_same<T, float>::value
+      ? (NB == 1 ? "conv3x3_kernel<float,1> (32-cout tile, exact fp32 MFMA 32x32x2)" : "conv3x3_kernel<float,2> (64-cout tile, exact fp32 MFMA 32x32x2)")
+      : (NB == 1 ? (MB == 5 ? "conv3x3_kernel<__half,1,5> (32-cout tile, 20 rows, 32x32x16 MFMA)" : "conv3x3_kernel<__half,1,4> (32-cout tile, 16 rows, 32x32x16 MFMA)")
+                 : "conv3x3_kernel<__half,2,4> (64-cout tile, 32x32x16 MFMA)");
   hipLaunchKernelGGL((conv3x3_kernel<T, NB, MB, NW, DBG, EK>), dim3(gx, groups), dim3(64 * NW), lds, st, a);
   SS4K_HIP(hipGetLastError());
 }
@@ -734,10 +738,13 @@ void launch_conv3x3(ss4k_ctx* ctx, const ConvArgs& a0, int dtype, hipStream_t st
   SS4K_REQUIRE((double)a.N * a.H * a.W < 2147483648.0, "conv3x3: a plane holds at most 2^31 pixels");
   ProfScope prof(ctx, st, PROF_CONV);
   // fp16 tile shapes <couts/32, rows per wave, waves>; see DESIGN.md 4.3 and profiles/NOTES_r01_r03.md 4.1 for how they were chosen
-  // fp16 layers of a supported shape with a plain epilogue: register-stationary weights on the 16x16x32 MFMA
+#ifdef SS4K_DEV
+  // dev library: fp16 layers of a supported shape with a plain epilogue on the register-stationary kernel (conv_rs.hip)
   if (a.wrs && dtype == SS4K_F16 && !a.dbg && a.epi == EPI_NHWC && !a.bsvd_resid && a.act != ACT_RELU6) {
     launch_conv3x3_rs(ctx, a, st);
-  } else if (nb == 1 && conv3x3_w16n_eligible(a, dtype)) {
+  } else
+#endif
+  if (nb == 1 && conv3x3_w16n_eligible(a, dtype)) {
     launch_conv3x3_w16n(ctx, a, st);   // <= 4 output channels, NCHW fp32 hand-off: one 16-cout block on the 16x16x32 MFMA (conv_w16n.hip)
   } else if (a.wide && nb == 2 && conv3x3_w16_eligible(a, dtype)) {
     launch_conv3x3_w16(ctx, a, st);    // the same tile on the 16x16x32 MFMA (conv_w16.hip; the layer has a w16 blob)

@@ -339,6 +339,7 @@ static void launch_t(ss4k_ctx* ctx, const PairArgs& a0, hipStream_t st) {
 #endif
   const void* fn = reinterpret_cast<const void*>(&conv3x3_pair_kernel<PA, EPI>);
   if (ctx->lds_attr_set.insert(fn).second) SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  ctx->prof_family = "pair::conv3x3_pair_kernel (two 32-channel full-resolution layers, row-marching, 32x32x16 MFMA: BSVD inc / outc)";
   hipLaunchKernelGGL((conv3x3_pair_kernel<PA, EPI>), dim3((unsigned)(a.N * a.bands * strips)), dim3(256), lds, st, a);
   SS4K_HIP(hipGetLastError());
 }

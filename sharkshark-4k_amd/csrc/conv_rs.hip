@@ -520,6 +520,7 @@ static void launch_t(ss4k_ctx* ctx, const ConvArgs& c, hipStream_t st) {
   if (ctx->lds_attr_set.insert(fn).second)
     SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int gx = std::min(ntiles, std::max(1, (int)(ctx->num_cu / groups * (c.grid_share > 0.f ? c.grid_share : 1.f))));
+  ctx->prof_family = "rs::conv3x3_rs_kernel (register-stationary weights, 16x16x32 MFMA)";
   hipLaunchKernelGGL((conv3x3_rs_kernel<NCH, ROWS, CB, CG, PR, RL, RES>), dim3(gx, groups), dim3(64 * NW), lds, st, a);
   SS4K_HIP(hipGetLastError());
 }

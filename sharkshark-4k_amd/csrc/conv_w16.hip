@@ -463,6 +463,8 @@ void launch_conv3x3_w16(ss4k_ctx* ctx, const ConvArgs& a0, hipStream_t st) {
   const void* fn = rl ? reinterpret_cast<const void*>(&conv3x3_w16_kernel<false, true>) : reinterpret_cast<const void*>(&conv3x3_w16_kernel<false, false>);
   if (ctx->lds_attr_set.insert(fn).second)
     SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+  ctx->prof_family = rl ? "w16::conv3x3_w16_kernel<RL> (64-cout tile, 16x16x32 MFMA, residual through the matrix core: conv5 of an RDB)"
+                        : "w16::conv3x3_w16_kernel (64-cout tile, 16x16x32 MFMA)";
   if (rl) hipLaunchKernelGGL((conv3x3_w16_kernel<false, true>), dim3(gx, groups), dim3(64 * NW), LDS_BYTES, st, a);
   else hipLaunchKernelGGL((conv3x3_w16_kernel<false, false>), dim3(gx, groups), dim3(64 * NW), LDS_BYTES, st, a);
   SS4K_HIP(hipGetLastError());

@@ -237,6 +237,7 @@ void launch_conv3x3_w16n(ss4k_ctx* ctx, const ConvArgs& a0, hipStream_t st) {
   const void* fn = reinterpret_cast<const void*>(&conv3x3_w16n_kernel);
   if (ctx->lds_attr_set.insert(fn).second)
     SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+  ctx->prof_family = "w16n::conv3x3_w16n_kernel (one 16-cout block, 16x16x32 MFMA, NCHW fp32 hand-off: a final 64 -> 3 layer)";
   hipLaunchKernelGGL(conv3x3_w16n_kernel, dim3(gx), dim3(64 * NW), LDS_BYTES, st, a);
   SS4K_HIP(hipGetLastError());
 }

@@ -2,7 +2,9 @@
 // the kernels in conv_mfma.hip / fsrcnn.hip.  Weights arrive as the reference's state_dict
 // flattened in key order (see sharkshark-4k_amd/weights.py) and are repacked once at creation.
 #include "models.h"
+#ifdef SS4K_DEV
 #include "chain_plan.h"
+#endif
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -100,8 +102,10 @@ static void upload(DevBuf& b, const void* src, size_t bytes) {
   SS4K_HIP(hipMemcpy(b.ptr, src, bytes, hipMemcpyHostToDevice));
 }
 
+#ifdef SS4K_DEV
 // bit of a layer shape in Model::rs_mask: 0-2 = 32 couts with 2/3/4 K-chunks (RDB conv1-3), 3 = conv4, 4 = 64->64, 5 = conv5
 static int rs_shape_bit(int nch, int cout_pad) { return cout_pad == 32 ? nch - 2 : (nch == 2 ? 4 : 5); }
+#endif
 
 int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool has_prelu_after, bool allow_rs, bool chainable) {
   s.dtype = desc.dtype; s.cout_real = cout; s.cin_total = cin_total;
@@ -113,6 +117,7 @@ int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool h
   upload(L.w, p.w.data(), p.w.size());
   upload(L.bias, p.bias.data(), p.bias.size() * 4);
   if (a) upload(L.prelu, p.prelu.data(), p.prelu.size() * 4);
+#ifdef SS4K_DEV   // conv_rs.hip (register-stationary weights) and conv_chain.hip (cross-layer chain): dev library only since round 5
   int nch, rows, cb, cg;
   if (allow_rs && use_rs && desc.dtype == SS4K_F16 && rs_config(s.nchunks0 + s.nchunks1, p.cout_pad, rs_wide, &nch, &rows, &cb, &cg) &&
       (rs_mask >> rs_shape_bit(nch, p.cout_pad)) & 1) {
@@ -121,6 +126,15 @@ int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool h
     weight_bytes += wr.size();
     L.rs_wide = rs_wide;
   }
+  if (chainable && chain_mode == 2 && desc.dtype == SS4K_F16 && p.nb == 2) {
+    PackSpec s1 = s; s1.force_nb1 = 1;
+    const PackedConv p1 = pack_conv3x3(s1, w, b, a);
+    upload(L.wch, p1.w.data(), p1.w.size());
+    weight_bytes += p1.w.size();
+  }
+#else
+  (void)allow_rs; (void)chainable;
+#endif
   if (use_w16 && use_wide && desc.dtype == SS4K_F16 && p.nb == 2 && p.cout_pad % 64 == 0 && (s.nchunks0 + s.nchunks1) % 2 == 0 && !s.ps2) {
     const std::vector<uint8_t> w6 = pack_conv3x3_w16(s, w, p.cout_pad);
     upload(L.w16, w6.data(), w6.size());
@@ -130,12 +144,6 @@ int Model::add_conv(ParamCursor& pc, int cout, int cin_total, PackSpec s, bool h
     const std::vector<uint8_t> w6 = pack_conv3x3_w16n(s, w);
     upload(L.w16, w6.data(), w6.size());
     weight_bytes += w6.size();
-  }
-  if (chainable && chain_mode == 2 && desc.dtype == SS4K_F16 && p.nb == 2) {
-    PackSpec s1 = s; s1.force_nb1 = 1;
-    const PackedConv p1 = pack_conv3x3(s1, w, b, a);
-    upload(L.wch, p1.w.data(), p1.w.size());
-    weight_bytes += p1.w.size();
   }
   L.has_prelu = a != nullptr;
   if (a) { L.prelu_le1 = true; for (int c = 0; c < cout; ++c) L.prelu_le1 = L.prelu_le1 && a[c] <= 1.f; }
@@ -203,26 +211,26 @@ void Model::build(const float* w, size_t n) {
   // can also be set from the environment of a deployed service: SS4K_LANES (0 = measured per shape, 1 = one
   // launch chain, 2 = two) and SS4K_FS_EXACT=1.  The measurement-only switches exist in the dev library alone.
   const int fl = desc.flags;
-  SS4K_REQUIRE((fl & ~SS4K_MODEL_FLAGS_ALL) == 0, "desc.flags: unknown SS4K_MODEL_* bit");
+#ifdef SS4K_DEV
+  SS4K_REQUIRE((fl & ~(SS4K_MODEL_FLAGS_ALL | SS4K_DEV_MODEL_FLAGS_ALL)) == 0, "desc.flags: unknown SS4K_MODEL_* / SS4K_DEV_MODEL_* bit");
+  SS4K_REQUIRE(!((fl & SS4K_DEV_MODEL_CHAIN) && (fl & SS4K_DEV_MODEL_CONV5_RS)), "desc.flags: the chain runs every layer on the 32-cout LDS-weights tile: CHAIN and CONV5_RS exclude each other");
+  if (fl & SS4K_DEV_MODEL_CHAIN) chain_mode = 2;
+  if (fl & SS4K_DEV_MODEL_CONV5_RS) { use_rs = true; conv5_mode = 1; }
+#else
+  SS4K_REQUIRE((fl & ~SS4K_MODEL_FLAGS_ALL) == 0, "desc.flags: unknown SS4K_MODEL_* bit (bits 8, 64, 128, 2048 and 16384 were retired with ABI 3)");
+#endif
   SS4K_REQUIRE(!((fl & SS4K_MODEL_ONE_CHAIN) && (fl & SS4K_MODEL_TWO_CHAINS)), "desc.flags: ONE_CHAIN and TWO_CHAINS exclude each other");
   SS4K_REQUIRE(!((fl & SS4K_MODEL_TILE_ROWS_16) && (fl & SS4K_MODEL_TILE_ROWS_20)), "desc.flags: TILE_ROWS_16 and TILE_ROWS_20 exclude each other");
   if (fl & SS4K_MODEL_FS_EXACT) fs_exact = true;
   if (fl & SS4K_MODEL_ONE_CHAIN) lanes_mode = 1;
   if (fl & SS4K_MODEL_TWO_CHAINS) lanes_mode = 2;
-  if (fl & SS4K_MODEL_NO_RS) use_rs = false;
   if (fl & SS4K_MODEL_TILE_ROWS_16) mb_override = 4;
   if (fl & SS4K_MODEL_TILE_ROWS_20) mb_override = 5;
-  SS4K_REQUIRE(!((fl & SS4K_MODEL_NO_CHAIN) && (fl & SS4K_MODEL_CHAIN)), "desc.flags: NO_CHAIN and CHAIN exclude each other");
-  if (fl & SS4K_MODEL_NO_CHAIN) chain_mode = 1;
-  if (fl & SS4K_MODEL_CHAIN) chain_mode = 2;
   if (fl & SS4K_MODEL_NO_PAIR) use_pair = false;
-  SS4K_REQUIRE(!((fl & SS4K_MODEL_NO_DENSE) && (fl & SS4K_MODEL_DENSE)), "desc.flags: NO_DENSE and DENSE exclude each other");
   if (fl & SS4K_MODEL_NO_DENSE) dense_mode = 1;
-  if (fl & SS4K_MODEL_DENSE) dense_mode = 2;
   if (fl & SS4K_MODEL_HR_F32) hr_f32 = true;
   if (fl & SS4K_MODEL_NO_WIDE) use_wide = false;
   if (fl & SS4K_MODEL_NO_UPS_PRESUM) ups_presum = false;
-  if (fl & SS4K_MODEL_CONV5_RS) conv5_mode = 1;
   if (fl & SS4K_MODEL_NO_W16) use_w16 = false;
   if (!(fl & (SS4K_MODEL_ONE_CHAIN | SS4K_MODEL_TWO_CHAINS)))
     if (const char* e = std::getenv("SS4K_LANES")) lanes_mode = std::max(0, std::min(2, std::atoi(e)));
@@ -230,14 +238,14 @@ void Model::build(const float* w, size_t n) {
 #ifdef SS4K_DEV
   if (const char* e = std::getenv("SS4K_NO_FLIP")) flip_walk = !(e[0] == '1');  // A/B switch for the tile-walk direction
   if (const char* e = std::getenv("SS4K_SUBBATCH")) sub_batch = std::atoi(e);   // A/B switch: frames per pass through the network
-  if (const char* e = std::getenv("SS4K_NO_RS")) use_rs = !(e[0] == '1');        // A/B switch: LDS-weights kernel for every layer
-  if (const char* e = std::getenv("SS4K_RS_MASK")) rs_mask = std::atoi(e);       // A/B switch: which layer shapes take conv_rs.hip
+  if (const char* e = std::getenv("SS4K_RS_MASK")) { rs_mask = std::atoi(e); use_rs = rs_mask != 0; }   // A/B switch: which layer shapes take conv_rs.hip
   if (const char* e = std::getenv("SS4K_RS_W8")) rs_wide = e[0] == '1';          // A/B switch: eight-wave variants of the 32-cout shapes
   if (const char* e = std::getenv("SS4K_MB")) mb_override = std::atoi(e);
   if (const char* e = std::getenv("SS4K_S3")) use_s3 = e[0] == '1';
   if (const char* e = std::getenv("SS4K_DENSE_MASK")) dense_mask = std::atoi(e);   // A/B switch: which layer pairs of an RDB run fused
   if (const char* e = std::getenv("SS4K_UPS_PRESUM")) ups_presum = e[0] == '1';   // A/B switch: pre-summed weights in the up-sampling convs
-  if (const char* e = std::getenv("SS4K_CONV5_MODE")) conv5_mode = std::atoi(e);    // A/B switch: 0 default, 1 always conv_rs.hip
+  if (const char* e = std::getenv("SS4K_CONV5_MODE")) { conv5_mode = std::atoi(e); use_rs = use_rs || conv5_mode == 1; }   // A/B switch: 0 default, 1 always conv_rs.hip
+  if (const char* e = std::getenv("SS4K_NO_RL")) no_rl = e[0] == '1';              // A/B switch: conv5's residual read from memory in the epilogue
   if (const char* e = std::getenv("SS4K_WIDE_RL")) wide_rl = e[0] == '1';          // A/B switch: conv5's residual through the matrix core on the wide kernel
   if (const char* e = std::getenv("SS4K_WIDE")) use_wide = e[0] == '1';            // A/B switch: 64-cout layers on conv3x3_wide_kernel
   if (const char* e = std::getenv("SS4K_W16")) use_w16 = e[0] == '1';              // A/B switch: ... on conv3x3_w16_kernel
@@ -356,27 +364,22 @@ void Model::conv(int li, const Tens& in0, const Tens* in1, int N, int H, int W, 
     SS4K_HIP(hipEventRecord(section.a, st));
     section_open = true;
   }
+#ifdef SS4K_DEV
   if (chain_rec) {
     a.flops = flops * N;
     chain_record(a, L);
     return;
   }
-#ifdef SS4K_DEV
   // experiment: a 64-cout body layer as two 32-cout groups on the per-launch path (what the chain does to conv5)
   static const bool split64 = std::getenv("SS4K_SPLIT64") && std::getenv("SS4K_SPLIT64")[0] == '1';
   if (split64 && L.wch.ptr && a.cout_pad == 64 && a.epi == EPI_NHWC) { a.wpk = L.wch.ptr; a.wrs = nullptr; a.cout_pad = -64; }
 #endif
-  // conv5 of an RDB (residual = the conv's own input).  Default since round 4: conv_w16.hip with the residual through the matrix core, for
-  // every job size - two workgroups per CU that co-reside with the fused dense-block launches of the other launch chain, where the
-  // register-stationary kernel's 160 KB ring and 460 registers monopolise a CU (4 frames of 720p + 1.6 %, 2 frames + 2.7 %, 1 frame + 3.9 %).
-  // A frame's bits therefore do not depend on the size of the job it arrived in.  Without the 16x16x32 build (SS4K_MODEL_NO_W16) the older
-  // rule applies: the register-stationary kernel runs one persistent workgroup per CU, so a job with fewer than three rounds of 16 x 32
-  // tiles for 256 slots (one 720p frame: 460 tiles = 1.8) takes the wide kernel with the residual through the matrix core, larger ones the
-  // register-stationary kernel - decided per JOB (N, H, W), never per launch, so that a job's bits do not depend on how it is cut into
-  // launch chains.  SS4K_MODEL_CONV5_RS pins the register-stationary kernel for every size.
-  if (a.wrs && conv5_mode != 1 && use_wide && a.res1 && a.act == ACT_NONE && a.nchunks0 == 4 && a.cout_pad == 64 && !a.ups2 &&
-      a.res1 + (size_t)a.r1_plane0 * a.r1_plane_bytes == a.in0 + (size_t)a.in0_plane0 * a.in0_plane_bytes &&
-      (a.w16 || (long long)N * ((H + 15) / 16) * ((W + 31) / 32) < 3LL * ctx->num_cu)) {
+  // conv5 of an RDB (residual = the conv's own input): on the 64-cout tile with the residual through the matrix core (conv_w16.hip; under
+  // SS4K_MODEL_NO_W16 conv_dense.hip's wide kernel), for EVERY job size - two workgroups per CU that co-reside with the fused dense-block
+  // launches of the other launch chain.  A frame's bits therefore never depend on the size of the job it arrived in.  (Rounds 2-4 also had a
+  // register-stationary kernel for this layer, conv_rs.hip: dev library only since round 5, SS4K_DEV_MODEL_CONV5_RS.)
+  if (use_wide && !no_rl && !(a.wrs && conv5_mode == 1) && a.res1 && a.act == ACT_NONE && a.nchunks0 == 4 && a.cout_pad == 64 && !a.ups2 &&
+      a.res1 + (size_t)a.r1_plane0 * a.r1_plane_bytes == a.in0 + (size_t)a.in0_plane0 * a.in0_plane_bytes) {
     a.wrs = nullptr; a.wide_rl = 1;
   }
   if (cur_lanes <= 1 || N != cur_n) {
@@ -503,7 +506,8 @@ bool Model::conv_dense(int li, const Tens& in0, const Tens* in1, int N, int H, i
   return true;
 }
 
-// ---- cross-layer chain (conv_chain.hip) ---------------------------------------------------------------------------------
+#ifdef SS4K_DEV
+// ---- cross-layer chain (conv_chain.hip; dev library only) -----------------------------------------------------------------
 void Model::chain_record(const ConvArgs& a, const ConvLayer& L) {
   SS4K_REQUIRE(desc.dtype == SS4K_F16 && a.epi == EPI_NHWC && !a.bsvd_resid && !a.ups2 && !a.prelu &&
                (a.act == ACT_NONE || a.act == ACT_LRELU) && (a.cout_pad == 32 || a.cout_pad == 64),
@@ -600,6 +604,8 @@ void Model::chain_run(int N, int H, int W, hipStream_t st) {
   }
 #endif
 }
+
+#endif  // SS4K_DEV
 
 // Asynchronous failures of the chain kernel (a unit gave up waiting: a co-running kernel starved it for seconds, or a defect).
 // wait: block until the last chain launch has finished, so that THIS forward's status is known before its output is used.
@@ -806,10 +812,12 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
     // off with launches (105-112 against 98 frames/s: their chains of launches fill each other's gaps, two chain kernels only
     // compete for the slots) - and a model cannot know how many callers the GPU has; since round 4 the fused dense-block launches
     // (conv_dense.hip) give the single caller more than the chain does.  DESIGN.md 4.5, profiles/NOTES_r01_r03.md 4.1d.
+#ifdef SS4K_DEV
     const bool use_chain = !plan_only && f16 && !dbg && nf == 64 && g == 32 && chain_mode == 2;
     if (use_chain) {
       chain_rec = true; chain_items.clear(); chain_layers.clear();
     }
+#endif
     for (int b = 0; b < desc.num_block; ++b) {
       const Tens a = cur;
       const Tens t1 = X[0], t2 = X[1];
@@ -832,6 +840,7 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
       }
       cur = dst;
     }
+#ifdef SS4K_DEV
     if (use_chain) {
       if (forked) {   // (a forced chain on an even batch: conv_first ran as two launch chains; the conv section stays open)
         SS4K_HIP(hipEventRecord(ctx->lane_done(), ctx->lane_stream()));
@@ -841,6 +850,7 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
       cur_lanes = 1;
       chain_run(n, H, W, st);
     }
+#endif
     { ConvOpts o; o.res1 = &F; o.out = X[0]; conv(li++, cur, nullptr, n, H, W, o, st); }  // feat + conv_body(body)
     Tens U1 = act(6, px * 4, nf), U2 = act(7, px * 16, nf), U3 = act(8, px * 16, nf);
     { ConvOpts o; o.ups2 = 1; o.act = ACT_LRELU; o.slope = 0.2f; o.out = U1; conv(li++, X[0], nullptr, n, 2 * H, 2 * W, o, st); }
@@ -944,6 +954,7 @@ double bench_conv_layer(ss4k_ctx* ctx, int dtype, int cin0, int cin1, int cout, 
   ss4k_model_desc d{}; d.kind = SS4K_RRDBNET; d.dtype = dtype; d.scale = 2; d.num_feat = 64; d.num_block = 1; d.num_grow_ch = 32;
   Model m; m.ctx = ctx; m.desc = d;
   m.use_rs = (flags & 4096) != 0;   // 4096: the register-stationary kernel (conv_rs.hip) where the shape is built
+  m.conv5_mode = m.use_rs ? 1 : 0;
   m.rs_mask = 63; m.rs_wide = (flags & 8192) != 0;
   const int cin = cin0 + cin1;
   std::vector<float> blob((size_t)cout * cin * 9 + cout);

@@ -87,18 +87,17 @@ struct Model {
   // cross-layer chain (conv_chain.hip): the RRDB body of small fp16 jobs as ONE persistent launch.  While chain_rec is set,
   // conv() records work items instead of launching; chain_run() resolves the dependencies and launches the chain.
   int dense_mode = 0;          // RRDBNet: (conv1, conv2) and (conv3, conv4) of every RDB as one fused launch each (conv_dense.hip): 0 = default (fused),
-                               // 1 = never (SS4K_MODEL_NO_DENSE), 2 = forced (SS4K_MODEL_DENSE; the same as the default today)
+                               // 1 = never (SS4K_MODEL_NO_DENSE)
   bool use_wide = true;        // 64-cout-group fp16 layers with a plain epilogue on conv_dense.hip's single-layer build (SS4K_MODEL_NO_WIDE: conv_mfma.hip's <2,4,4>)
   bool use_d16 = false;        // dev experiment (SS4K_D16=1, dev library): fused dense-block pairs on conv_d16.hip (v_mfma_f32_16x16x32_f16, 14-row tiles)
   const float* raw_w_prev = nullptr; PackSpec raw_s_prev{}; int raw_li_prev = -1;   // build(): the previous add_conv's source weights (pair packing)
   bool use_w16 = true;         // ... on conv_w16.hip (v_mfma_f32_16x16x32_f16) where the layer has an even number of K-chunks and no up-sampled input (SS4K_MODEL_NO_W16: never)
-  int conv5_mode = 0;          // RDB conv5: 0 = conv_w16.hip with the residual through the matrix core (without the w16 build: conv_rs.hip for jobs of at
-                               // least three rounds of tiles, the wide kernel below); 1 = conv_rs.hip for every size (SS4K_MODEL_CONV5_RS)
+  int conv5_mode = 0;          // RDB conv5: 0 = the 64-cout tile with the residual through the matrix core; 1 (dev library, SS4K_DEV_MODEL_CONV5_RS) = conv_rs.hip
   bool wide_rl = false;        // conv5 of an RDB on the wide kernel with its residual through the matrix core (when it is not routed to conv_rs.hip)
   bool ups_presum = true;      // RRDBNet's conv_up1 / conv_up2 on the wide kernel's pre-summed form (6 instead of 9 MFMAs per pixel; SS4K_MODEL_NO_UPS_PRESUM)
   int dense_mask = 3;          // ... which pairs: bit 0 = (conv1, conv2), bit 1 = (conv3, conv4)
   bool use_pair = true;        // BSVD: inc / outc layer pairs as one fused launch each (conv_pair.hip); SS4K_MODEL_NO_PAIR: two launches
-  int chain_mode = 1;          // 1: never (default, SS4K_MODEL_NO_CHAIN); 2: the RRDB body of every fp16 job (SS4K_MODEL_CHAIN)
+  int chain_mode = 1;          // 1: never; 2 (dev library, SS4K_DEV_MODEL_CHAIN): the RRDB body of every fp16 job as one persistent launch
   bool chain_rec = false;
   struct ChainLayerRec { int first_item, nitems; const char* out_lo; const char* out_hi; double flops; };
   std::vector<ChainItem> chain_items;
@@ -126,14 +125,12 @@ struct Model {
   int in_channels() const;
   int rs_mask = 32;        // layer shapes routed to conv_rs.hip (bit per shape, models.cpp rs_shape_bit); default: RDB conv5
   bool rs_wide = false;    // eight-wave variants of the 32-cout RS shapes (SS4K_RS_W8=1: A/B switch)
-  bool use_rs = true;      // route eligible fp16 layers to the register-stationary kernel (SS4K_NO_RS=1: A/B switch)
+  bool use_rs = false;     // dev library: pack conv_rs.hip weights for the shapes in rs_mask and route those layers to the register-stationary kernel
+  bool no_rl = false;      // dev library (SS4K_NO_RL=1): conv5's residual read from memory in the epilogue instead of through the matrix core
   ~Model() {
-    for (auto& l : layers) { l.w.release(); l.bias.release(); l.prelu.release(); l.wrs.release(); l.wch.release(); }
-    chain_tab.release(); chain_ctl.release();
+    // (device buffers are DevBuf members: freed with the object)
     if (chain_err_host) (void)hipHostFree(chain_err_host);
     if (chain_done) (void)hipEventDestroy(chain_done);
-    for (auto& a : acts) a.release();
-    fs_blob.release();
     for (auto* tab : {&lane_tune}) for (auto& t : *tab) for (auto& pr : t.second.ev) for (auto e : pr) if (e) (void)hipEventDestroy(e);
   }
 

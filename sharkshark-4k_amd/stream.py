@@ -11,6 +11,8 @@ Restates what the reference's ``TwitchUpscalerPostStreamer`` does around the ups
   are handed to the sink (the reference only warns on out-of-order steps, ``streamer.py:77-78``);
 * the sink gets ``'upscaler.upscale.per_frame_ms'`` and queue depths in the profiler
   (``pipeline.py:140-149``);
+* a worker process that has died is routed around at once: its steps go to the next living service (the node runs on G - 1), and a
+  step whose result can no longer come back because the worker it was queued in is gone is declared lost without waiting;
 * a result that never arrives (a worker died, or ``BaseService`` dropped it on a full result queue)
   must not stall a 24/7 stream: a step that keeps later results waiting for more than
   ``lost_after_s`` seconds, or behind more than ``max_reorder`` pending results, is declared lost,
@@ -46,6 +48,8 @@ class StreamDispatcher:
         self.lost_total = 0          # steps that were queued but whose result never came back
         self.late_total = 0          # results that arrived after their step had been declared lost (discarded)
         self._pending: Dict[int, UpscalerQueueEntry] = {}
+        self._owner: Dict[int, object] = {}   # queued step -> the service it went to (until its result is back or it is given up)
+        self.rerouted_total = 0      # steps that went to another service than step % G because that one's worker was dead
         self.max_reorder = max_reorder
         self.lost_after_s = lost_after_s
         self._stalled_since: Optional[float] = None
@@ -55,6 +59,24 @@ class StreamDispatcher:
     def dropped(self) -> List[int]:
         """Dropped steps the ordered emission has not passed yet (older ones are pruned)."""
         return sorted(self._dropped)
+
+    @staticmethod
+    def _alive(svc) -> bool:
+        """A service whose worker process was started and has exited is dead; doubles without a process are always alive."""
+        proc = getattr(svc, "proc", None)
+        if proc is None or proc.is_alive():
+            return True
+        return proc.exitcode is None and getattr(proc, "pid", None) is None   # (not started yet)
+
+    def _pick(self, step: int):
+        n = len(self.services)
+        for j in range(n):
+            svc = self.services[(step + j) % n]
+            if self._alive(svc):
+                if j:
+                    self.rerouted_total += 1
+                return svc
+        raise RuntimeError("StreamDispatcher: no living upscaler worker")
 
     # pipeline.py:61-108
     def submit_batch(self, frames, audio_segment=None, profiler: Optional[Profiler] = None) -> List[int]:
@@ -75,13 +97,14 @@ class StreamDispatcher:
             entry = UpscalerQueueEntry(frames=chunk, audio_segment=audio, step=step, profiler=profiler)
             profiler.set("recoder.output.frames.shape", str(tuple(chunk.shape)))
             profiler.end("recoder.output.entry")
-            svc = self.services[step % len(self.services)]
+            svc = self._pick(step)
             try:
                 if self.frame_skips:
                     svc.push_job_nowait(entry)
                 else:
                     svc.push_job(entry)
                 queued.append(step)
+                self._owner[step] = svc
             except queue.Full:
                 self._dropped.add(step)
                 self.dropped_total += 1
@@ -102,10 +125,16 @@ class StreamDispatcher:
                 now = time.monotonic()
                 if self._stalled_since is None:
                     self._stalled_since = now
-                if force or now - self._stalled_since > self.lost_after_s:
+                # a step queued in a worker that has died since (and whose results have been collected: poll() reads every
+                # queue first) cannot come back: no point in waiting lost_after_s for it
+                owner = self._owner.get(self.next_emit)
+                orphan = owner is not None and not self._alive(owner) and owner.result_queue.empty()
+                if force or orphan or now - self._stalled_since > self.lost_after_s:
                     nxt = min(self._pending)  # lost downstream: do not stall the stream (poll() keeps every pending step >= next_emit)
                     gone = [s for s in range(self.next_emit, nxt) if s not in self._dropped]
                     self.lost_total += len(gone)
+                    for g in gone:
+                        self._owner.pop(g, None)
                     self._dropped.difference_update(range(self.next_emit, nxt))
                     print(f"StreamDispatcher: step(s) {gone} never came back, skipped")
                     self.next_emit = nxt
@@ -139,6 +168,7 @@ class StreamDispatcher:
                         print(f"StreamDispatcher: result of step {e.step} arrived late (stream is at {self.next_emit}), discarded")
                         continue
                     self._pending[e.step] = e
+                    self._owner.pop(e.step, None)
                 except queue.Empty:
                     pass
             ready = self._emit_ready(force=len(self._pending) > self.max_reorder)
@@ -158,5 +188,5 @@ class StreamDispatcher:
 
     def report(self) -> dict:
         return {"frame_step": self.frame_step, "dropped": self.dropped_total, "lost": self.lost_total, "late": self.late_total,
-                "pending": len(self._pending),
+                "pending": len(self._pending), "rerouted": self.rerouted_total,
                 "upscaler.inputq": [s.job_queue.qsize() for s in self.services]}

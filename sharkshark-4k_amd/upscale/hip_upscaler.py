@@ -33,6 +33,7 @@ Cost: a second copy of the SR weights and activation workspace (RRDBNet x2 at 72
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Mapping, Optional
 
 import torch
@@ -119,50 +120,69 @@ class HipUpscalerService(BaseUpscalerService):
         return flat
 
     def proc_init(self):
-        from .. import _capi
-        from . import model as factory
         log("proc init")
+        self._open_device()
+        with self._node_group():
+            self._build_models()   # (weights resolved on rank 0 only, see _shared_flat)
+        self._init_job_sets()
+        log("model loaded")
+
+    def _open_device(self):
+        from .. import _capi
         self.ctx = _capi.Context(self.device)
         self.torch_device = self.ctx.device
+        self._local_device = self.ctx.device_index
+
+    @contextlib.contextmanager
+    def _node_group(self):
+        """Inside: this worker is rank ``node_rank`` of ``node_world`` (the group of ``self.group``, or one the process already sits
+        in - ``bench.py`` under ``torch.distributed.run``).  A group joined here is left on the way out, error or not, unless
+        ``group.keep``: once the weights are in place the workers of a node are independent processes."""
         import torch.distributed as dist
         had_group = dist.is_available() and dist.is_initialized()
-        self.node_rank, self.node_world = sharding.join_group(self.group, self.ctx.device_index)
+        self._flats = {}
+        self.node_rank, self.node_world = sharding.join_group(self.group, getattr(self, "_local_device", None))
         if self.node_world > 1:
             log(f"worker {self.node_rank} of {self.node_world} on {self.torch_device} ({dist.get_backend()})")
-        self._flats = {}
+        try:
+            yield
+        finally:
+            if not had_group and not (self.group and self.group.keep):
+                sharding.leave_group()
+
+    def _build_models(self):
+        from .. import _capi
+        from . import model as factory
         if self.weights == "synthetic":
             log("WARNING: weights='synthetic' - every network runs on generated weights, output frames are noise")
         def spec(name):
             return "synthetic" if self.weights == "synthetic" else (self.weights or {}).get(name)
-        try:
-            if self.upscaler_model == "fsrcnn":
-                desc = factory.fsrcnn_desc(self.scale, self.fsrcnn_dtype, self.model_flags)
-                flat = self._shared_flat("sr", desc, lambda: factory.fsrcnn_flat(self.scale, spec("sr"), self.seed, self.checkpoint_dir))
-            else:
-                name = self.model_name or factory.DEFAULT_REALESRGAN
-                desc = factory.esrgan_desc(name, self.dtype, self.model_flags)
-                flat = self._shared_flat("sr", desc, lambda: factory.esrgan_flat(
-                    name, self.denoise_rate, spec("sr"), self.seed, spec("sr_wdn") if self.weights != "synthetic" else None, self.checkpoint_dir))
-            self.model = _capi.Model(self.ctx, desc, flat)
-            self.denoise_model = None
-            # quirk kept from the reference: with 'realesrgan' the batched path never denoises even when
-            # denoising=True (fsrcnn_upscaler.py:109,168-233); the BSVD model is only used per-frame.
-            if self.denoising and self.single_mode:
-                ddesc = factory.denoise_desc(self.dtype)
-                dflat = self._shared_flat("denoise", ddesc, lambda: factory.denoise_flat(spec("denoise"), self.seed, checkpoint_dir=self.checkpoint_dir))
-                self.denoise_model = _capi.Model(self.ctx, ddesc, dflat)
-        finally:
-            if not had_group and not (self.group and self.group.keep):
-                sharding.leave_group()   # weights are in place: from here on the workers of a node are independent
+        if self.upscaler_model == "fsrcnn":
+            desc = factory.fsrcnn_desc(self.scale, self.fsrcnn_dtype, self.model_flags)
+            flat = self._shared_flat("sr", desc, lambda: factory.fsrcnn_flat(self.scale, spec("sr"), self.seed, self.checkpoint_dir))
+        else:
+            name = self.model_name or factory.DEFAULT_REALESRGAN
+            desc = factory.esrgan_desc(name, self.dtype, self.model_flags)
+            flat = self._shared_flat("sr", desc, lambda: factory.esrgan_flat(
+                name, self.denoise_rate, spec("sr"), self.seed, spec("sr_wdn") if self.weights != "synthetic" else None, self.checkpoint_dir))
+        self.model = _capi.Model(self.ctx, desc, flat)
+        self.denoise_model = None
+        # quirk kept from the reference: with 'realesrgan' the batched path never denoises even when
+        # denoising=True (fsrcnn_upscaler.py:109,168-233); the BSVD model is only used per-frame.
+        if self.denoising and self.single_mode:
+            ddesc = factory.denoise_desc(self.dtype)
+            dflat = self._shared_flat("denoise", ddesc, lambda: factory.denoise_flat(spec("denoise"), self.seed, checkpoint_dir=self.checkpoint_dir))
+            self.denoise_model = _capi.Model(self.ctx, ddesc, dflat)
+
+    def _init_job_sets(self):
         # job sets: [0] is what every job ran on before; [1] (second context / model / stream) is built on the first one-frame job
         self._sets = [{"ctx": self.ctx, "model": self.model, "denoise": self.denoise_model, "up": None, "key": None, "stream": None}]
         self._alt = 0
         self._pending = {}
         if not (self.overlap_jobs and not self.single_mode):
-            self._flats.pop("sr", None)      # (no second set will ever be built: drop the host copies)
+            self._flats.pop("sr", None)      # (no second set will ever be built: drop the host copy)
         self._flats.pop("denoise", None)     # (the batched path never denoises)
         self.deliver_lag = 1 if self._overlap_active() else 0
-        log("model loaded")
 
     def _overlap_active(self) -> bool:
         return bool(self.overlap_jobs) and not self.single_mode and "sr" in getattr(self, "_flats", {})
@@ -193,7 +213,8 @@ class HipUpscalerService(BaseUpscalerService):
     def proc_before_deliver(self, entry):
         # a result computed on a job set's own stream: the current stream - on which the result tensor is handed to the consumer
         # (on_queue, or the IPC event torch records when the tensor is pickled into the result queue) - waits for it here
-        rec = self._pending.pop(id(entry.frames), None) if getattr(entry, "frames", None) is not None else None
+        pending = getattr(self, "_pending", None)
+        rec = pending.pop(id(entry.frames), None) if pending and getattr(entry, "frames", None) is not None else None
         if rec is not None:
             torch.cuda.current_stream(self.torch_device).wait_event(rec[1])
 
@@ -201,13 +222,8 @@ class HipUpscalerService(BaseUpscalerService):
         pass
 
     def _run(self, k: int, frames: torch.Tensor) -> torch.Tensor:
-        from .. import _capi
         up = self._get_upscaler(k)
         out = up(frames)
-        if self.model_flags & _capi.MODEL_CHAIN:
-            # SS4K_MODEL_CHAIN's one asynchronous failure mode (a work unit timed out): the frames leave this worker right after
-            # this call, so the status of THIS job's launch is awaited here (include/ss4k.h: ss4k_model_check, wait = 1)
-            self._sets[k]["model"].check(wait=True)
         prof = getattr(self, "profiler", None)
         if prof is not None:
             # the reference's span keys (fsrcnn_upscaler.py:276-278,290-300): host time around the

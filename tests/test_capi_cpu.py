@@ -34,7 +34,7 @@ def test_header_symbols_exported(lib):
     assert sorted(_capi.SYMBOLS) == syms, "python binding list and header disagree"
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/ss4k.h but not exported"
-    assert lib.ss4k_abi_version() == 2
+    assert lib.ss4k_abi_version() == 3
 
 
 def test_dev_library_is_a_superset_and_product_has_no_bench_hooks(lib):
@@ -110,10 +110,16 @@ def test_model_flag_constants_match_header():
     text = open(os.path.join(ROOT, "include", "ss4k.h")).read()
     hdr = {m.group(1): int(m.group(2)) for m in re.finditer(r"\bSS4K_MODEL_([A-Z0-9_]+)\s*=\s*(\d+)", text)}
     want = {"FS_EXACT": _capi.MODEL_FS_EXACT, "ONE_CHAIN": _capi.MODEL_ONE_CHAIN, "TWO_CHAINS": _capi.MODEL_TWO_CHAINS,
-            "NO_RS": _capi.MODEL_NO_RS, "TILE_ROWS_16": _capi.MODEL_TILE_ROWS_16, "TILE_ROWS_20": _capi.MODEL_TILE_ROWS_20,
-            "NO_CHAIN": _capi.MODEL_NO_CHAIN, "CHAIN": _capi.MODEL_CHAIN, "NO_PAIR": _capi.MODEL_NO_PAIR, "HR_F32": _capi.MODEL_HR_F32,
-            "NO_DENSE": _capi.MODEL_NO_DENSE, "DENSE": _capi.MODEL_DENSE, "NO_WIDE": _capi.MODEL_NO_WIDE, "NO_UPS_PRESUM": _capi.MODEL_NO_UPS_PRESUM, "CONV5_RS": _capi.MODEL_CONV5_RS, "NO_W16": _capi.MODEL_NO_W16}
+            "TILE_ROWS_16": _capi.MODEL_TILE_ROWS_16, "TILE_ROWS_20": _capi.MODEL_TILE_ROWS_20, "NO_PAIR": _capi.MODEL_NO_PAIR, "HR_F32": _capi.MODEL_HR_F32,
+            "NO_DENSE": _capi.MODEL_NO_DENSE, "NO_WIDE": _capi.MODEL_NO_WIDE, "NO_UPS_PRESUM": _capi.MODEL_NO_UPS_PRESUM, "NO_W16": _capi.MODEL_NO_W16}
     for k, v in want.items():
         assert hdr[k] == v, k
-    assert hdr["FLAGS_ALL"] == sum(want.values())
-    assert _capi.ModelDesc.flags.offset == 12 * 4 and _capi.make_desc(_capi.RRDBNET, flags=_capi.MODEL_CHAIN).flags == 128
+    assert set(hdr) - {"FLAGS_ALL"} == set(want), "a header bit without a Python constant (or the other way round)"
+    all_expr = re.search(r"SS4K_MODEL_FLAGS_ALL\s*=\s*([0-9 |]+)", text).group(1)
+    assert eval(all_expr) == sum(want.values()) == _capi.MODEL_FLAGS_ALL
+    # the kernels that left the product library with ABI 3 keep their bit values in the dev header, outside the product's mask
+    dev = open(os.path.join(ROOT, "include", "ss4k_dev.h")).read()
+    dhdr = {m.group(1): int(m.group(2)) for m in re.finditer(r"\bSS4K_DEV_MODEL_([A-Z0-9_]+)\s*=\s*(\d+)", dev)}
+    assert dhdr["CHAIN"] == _capi.DEV_MODEL_CHAIN and dhdr["CONV5_RS"] == _capi.DEV_MODEL_CONV5_RS
+    assert (_capi.DEV_MODEL_CHAIN | _capi.DEV_MODEL_CONV5_RS) & _capi.MODEL_FLAGS_ALL == 0
+    assert _capi.ModelDesc.flags.offset == 12 * 4 and _capi.make_desc(_capi.RRDBNET, flags=_capi.MODEL_NO_W16).flags == 32768

@@ -17,7 +17,7 @@ from tests.helpers import psnr
 
 pytestmark = pytest.mark.gpu
 
-NO_DENSE, DENSE, ONE, TWO = _capi.MODEL_NO_DENSE, _capi.MODEL_DENSE, _capi.MODEL_ONE_CHAIN, _capi.MODEL_TWO_CHAINS
+NO_DENSE, DENSE, ONE, TWO = _capi.MODEL_NO_DENSE, 0, _capi.MODEL_ONE_CHAIN, _capi.MODEL_TWO_CHAINS   # DENSE: the default (fused pairs)
 
 
 PIN32 = _capi.MODEL_NO_W16   # this file tests conv_dense.hip (v_mfma_f32_32x32x16_f16: bit-identical to four launches of conv_mfma.hip); the default
@@ -51,7 +51,7 @@ def test_dense_pair_720p_23_blocks_bit_identical_and_repeatable(ctx):
     """The headline network at full size: 4 frames of 720p through 23 blocks (138 fused launches per lane), two launch chains."""
     flat = W.flatten(W.rrdbnet_table(0, scale=2), W.rrdbnet_keys(23))
     x = torch.rand(4, 3, 720, 1280, generator=torch.Generator().manual_seed(5)).cuda()
-    PIN = _capi.MODEL_CONV5_RS   # one conv5 kernel for every job size: the 1-frame job below must reproduce the 4-frame job's frame
+    PIN = 0   # (conv5 runs on one kernel for every job size: the 1-frame job below must reproduce the 4-frame job's frame)
     want = _model(ctx, flat, 2, 23, NO_DENSE | PIN)(x).clone()
     m = _model(ctx, flat, 2, 23, DENSE | PIN)
     for i in range(4):

@@ -22,3 +22,21 @@ def test_dev_library_d16_suite():
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
     assert " passed" in r.stdout
+
+
+def _run_dev_suite(files, extra_env=None, timeout=1500):
+    from sharkshark4k_amd import build as B
+    assert os.path.exists(B.LIB_DEV), "libss4k_hip_dev.so was not built (__graft_entry__.build())"
+    env = dict(os.environ, SS4K_LIB=B.LIB_DEV, **(extra_env or {}))
+    r = subprocess.run([sys.executable, "-m", "pytest", *[os.path.join(ROOT, "tools", "dev_tests", f) for f in files], "-x", "-q",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
+    assert " passed" in r.stdout
+
+
+def test_dev_library_conv_rs_suite():
+    _run_dev_suite(["test_conv_rs.py", "test_wide_rrdbnet.py"])
+
+
+def test_dev_library_chain_suite():
+    _run_dev_suite(["test_chain.py", "test_chain_plan_cpu.py"])

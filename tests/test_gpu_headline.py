@@ -128,20 +128,13 @@ def test_config2_rrdbnet_x2_720p_fp16_service_vs_oracle(ctx):
         record_measured(f"config2_rrdbnet_x2_720p_fp16_service_{tag}", psnr_db=psnr(g_r.float(), want.float(), peak=255.0), max_lsb=int(d_r.max()),
                         bytes_differ=float((d_r > 0).float().mean()), bytes_2lsb=int((d_r >= 2).sum()))
         del sr_r
-    # frames are independent: a 4-frame job gives every frame the result of a 1-frame job - bit for bit on the default route (every layer
-    # runs on the same kernel whatever the job size) and with conv5 pinned to the register-stationary kernel (SS4K_MODEL_CONV5_RS); on the
-    # round-3 routing (SS4K_MODEL_NO_W16: conv5 of one-frame jobs on another kernel than conv5 of four-frame jobs) within 1 LSB
+    # frames are independent: a 4-frame job gives every frame the result of a 1-frame job, bit for bit - every layer runs on the same
+    # kernel whatever the job size, on the default route and on the 32x32x16 build of the 64-cout tile (SS4K_MODEL_NO_W16)
     four = torch.cat([frames, torch.from_numpy(smooth_u8(124, (3, 720, 1280, 3)))]).cuda()
     assert torch.equal(up(four)[0].cpu(), got[0])
-    for fl, exact in ((_capi.MODEL_CONV5_RS, True), (_capi.MODEL_NO_W16, False)):
-        sr_p = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, flags=fl), W.flatten(table, W.rrdbnet_keys(23)))
-        up_p = _capi.Upscaler(ctx, sr_p, (720, 1280), None, True, False, None, 1.0)
-        a4, a1 = up_p(four)[0].cpu(), up_p(frames.cuda())[0].cpu()
-        if exact:
-            assert torch.equal(a4, a1)
-        else:   # measured: 1 LSB in 6.2 % of the bytes (against the fp32 oracle the fp16 path itself differs in 11.6 %)
-            d4 = (a4.int() - a1.int()).abs()
-            assert int(d4.max()) <= 1 and float((d4 > 0).float().mean()) < 0.09, (int(d4.max()), float((d4 > 0).float().mean()))
+    sr_p = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, flags=_capi.MODEL_NO_W16), W.flatten(table, W.rrdbnet_keys(23)))
+    up_p = _capi.Upscaler(ctx, sr_p, (720, 1280), None, True, False, None, 1.0)
+    assert torch.equal(up_p(four)[0].cpu(), up_p(frames.cuda())[0].cpu())
 
 
 # ------------------------------------------------------------------------------ (c) configs[3]: BSVD + RRDBNet, per-frame path

@@ -1,0 +1,124 @@
+"""GPU: the node launcher (``node.UpscalerNode``) and the one-frame-job overlap with REAL ``HipUpscalerService`` workers.
+
+A one-GPU box cannot show G > 1 GPUs, so:
+* world 1 over ``nccl`` (RCCL) through the launcher with ``force_group``: the worker creates its communicator, rank 0 = itself loads,
+  the 67 MB RRDBNet blob takes the device round trip through ``dist.broadcast``, the group is left, frames come back;
+* two workers on ``cuda:0`` (the launcher picks ``gloo`` for workers that share a GPU: RCCL refuses duplicate devices): rank 0 loads, rank 1
+  gets the blob, jobs alternate, results are bit-identical to an in-process upscaler built from the same table;
+* one of the two is killed: the stream goes on over the survivor, ``report()`` says so, a replacement joins.
+"""
+import time
+
+import pytest
+import torch
+
+import sharkshark4k_amd  # noqa: F401
+from sharkshark4k_amd import _capi
+from sharkshark4k_amd import weights as W
+from sharkshark4k_amd.node import UpscalerNode
+from sharkshark4k_amd.upscale.hip_upscaler import HipUpscalerService
+from tests.helpers import smooth_u8
+
+pytestmark = pytest.mark.gpu
+LR = (72, 104)
+KW = dict(upscaler_model="realesrgan", model_name="RealESRGAN_x2plus", denoising=False, weights="synthetic", seed=3, lr_shape=LR, dtype="f16")
+
+
+@pytest.fixture(scope="module")
+def want(ctx):
+    """What every worker must return: the same network / service path built in-process from the same generated table."""
+    sr = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2), W.flatten(W.rrdbnet_table(3, scale=2), W.rrdbnet_keys(23)))
+    up = _capi.Upscaler(ctx, sr, LR, None, True, False, None, 1.0)
+    frames = torch.from_numpy(smooth_u8(77, (12, LR[0], LR[1], 3)))
+    one = torch.cat([up(frames[i:i + 1].cuda()).cpu() for i in range(12)])
+    four = torch.cat([up(frames[i:i + 4].cuda()).cpu() for i in range(0, 12, 4)])
+    assert torch.equal(one, four)   # a frame's bytes do not depend on the job it arrived in
+    return frames, one
+
+
+def test_node_world1_nccl_through_the_launcher(want):
+    frames, ref = want
+    node = UpscalerNode(devices=[0], force_group=True, fps=24, frame_skips=False, **KW)
+    assert node.services[0].group.force and node.services[0].group.backend is None   # -> nccl in the worker
+    with node:
+        steps = node.submit_batch(frames.cuda())                       # 3 jobs of 4 frames
+        out = node.drain(steps, timeout=300)
+        assert [e.step for e in out] == [0, 1, 2]
+        got = torch.cat([e.frames.cpu() for e in out])
+        assert torch.equal(got, ref)
+    assert node.alive() == [False]
+
+
+def test_node_two_workers_one_gpu_rank0_loads_jobs_alternate(want):
+    frames, ref = want
+    node = UpscalerNode(devices=[0, 0], fps=1, frame_skips=False, **KW)   # fps 1 -> one-frame jobs (the image server's job size)
+    assert node.backend == "gloo"
+    with node:
+        steps = node.submit_batch(frames.cuda())
+        out = node.drain(steps, timeout=300)
+        assert [e.step for e in out] == list(range(12))
+        assert torch.equal(torch.cat([e.frames.cpu() for e in out]), ref)   # rank 1 runs rank 0's weights, bit for bit
+        rep = node.report()
+        assert rep["lost"] == 0 and rep["rerouted"] == 0 and rep["alive"] == [True, True]
+        # worker 1 dies (a job it cannot parse; exit_on_error is off, so only that child goes)
+        node.services[1].job_queue.put("not a job")
+        deadline = time.monotonic() + 60
+        while node.services[1].proc.is_alive() and time.monotonic() < deadline:
+            time.sleep(0.05)
+        assert node.alive() == [True, False]
+        steps = node.submit_batch(frames[:6].cuda())
+        out = node.drain(steps, timeout=300)
+        assert [e.step for e in out] == steps == list(range(12, 18))
+        assert torch.equal(torch.cat([e.frames.cpu() for e in out]), ref[:6])
+        rep = node.report()
+        assert rep["rerouted"] == 3 and rep["lost"] == 0 and rep["alive"] == [True, False]
+        assert node.replace_dead(timeout=300) == [1]
+        steps = node.submit_batch(frames[6:].cuda())
+        out = node.drain(steps, timeout=300)
+        assert torch.equal(torch.cat([e.frames.cpu() for e in out]), ref[6:]) and node.report()["alive"] == [True, True]
+
+
+def test_one_frame_jobs_alternate_over_two_job_sets_bit_identical(want):
+    """The worker's one-frame overlap, driven in-process: consecutive one-frame jobs run on two (context, model, stream) sets; a
+    multi-frame job in between runs on set 0; every frame equals the single-set result; ``wait=False`` hands results over un-ordered
+    (the worker loop orders them one job later, ``proc_before_deliver``), ``wait=True`` orders them on the current stream."""
+    frames, ref = want
+    svc = HipUpscalerService(device=0, **KW)
+    svc.proc_init()
+    assert svc.deliver_lag == 1 and len(svc._sets) == 1
+    dev = frames.cuda()
+    outs = [svc.upscale(dev[i:i + 1]) for i in range(5)]                 # ordered on the current stream: .cpu() below is safe
+    assert len(svc._sets) == 2 and svc._sets[0]["stream"] is not None and svc._sets[1]["stream"] is not None
+    assert torch.equal(torch.cat(outs).cpu(), ref[:5])
+    mixed = [svc.upscale(dev[0:1], wait=False), svc.upscale(dev[4:8], wait=False), svc.upscale(dev[1:2], wait=False), svc.upscale(dev[2:3], wait=False)]
+    torch.cuda.synchronize()
+    assert torch.equal(mixed[0].cpu(), ref[0:1]) and torch.equal(mixed[1].cpu(), ref[4:8])
+    assert torch.equal(mixed[2].cpu(), ref[1:2]) and torch.equal(mixed[3].cpu(), ref[2:3])
+    # switched off: one set, the current stream, as before
+    svc1 = HipUpscalerService(device=0, overlap_jobs=False, **KW)
+    svc1.proc_init()
+    assert svc1.deliver_lag == 0
+    assert torch.equal(torch.cat([svc1.upscale(dev[i:i + 1]) for i in range(3)]).cpu(), ref[:3]) and len(svc1._sets) == 1
+
+
+def test_worker_loop_delivers_in_order_with_the_overlap(want):
+    """The real worker process with deliver_lag = 1: twelve one-frame jobs pushed back to back, results in order and bit-identical; a
+    lone job (nothing follows it) still comes back at once."""
+    frames, ref = want
+    from sharkshark4k_amd.upscale.upscaler_base import UpscalerQueueEntry
+    from sharkshark4k_amd.util import Profiler
+    svc = HipUpscalerService(device=0, **KW)
+    svc.start()
+    try:
+        dev = frames.cuda()
+        svc.push_job(UpscalerQueueEntry(frames=dev[0:1].clone(), step=100, profiler=Profiler()), timeout=300)
+        lone = svc.get_result(timeout=300)
+        assert lone.step == 100 and torch.equal(lone.frames.cpu(), ref[0:1])
+        for i in range(12):
+            svc.push_job(UpscalerQueueEntry(frames=dev[i:i + 1].clone(), step=i, profiler=Profiler()), timeout=60)
+        got = [svc.get_result(timeout=300) for _ in range(12)]
+        assert [g.step for g in got] == list(range(12))
+        assert torch.equal(torch.cat([g.frames.cpu() for g in got]), ref)
+        assert "fsrcnn.model" in got[3].profiler.data and "upscaler.upscale" in got[3].profiler.data
+    finally:
+        svc.stop()

@@ -16,7 +16,7 @@ from oracle import nets as onets
 from tests.helpers import psnr
 
 pytestmark = pytest.mark.gpu
-NO_W16, ONE, TWO, NO_RS = _capi.MODEL_NO_W16, _capi.MODEL_ONE_CHAIN, _capi.MODEL_TWO_CHAINS, _capi.MODEL_NO_RS
+NO_W16, ONE, TWO = _capi.MODEL_NO_W16, _capi.MODEL_ONE_CHAIN, _capi.MODEL_TWO_CHAINS
 
 
 def _close(got, ref, want, what, db_forms, slack=0.5):
@@ -48,16 +48,14 @@ def test_w16_srvgg_vs_wide_and_oracle(ctx, nf, shape, up, lanes):
 
 @pytest.mark.parametrize("scale,shape,base", [(2, (1, 3, 144, 208), ONE), (2, (2, 3, 92, 200), TWO), (4, (1, 3, 37, 70), ONE), (1, (1, 3, 128, 256), ONE)])
 def test_w16_rrdbnet_vs_wide_and_oracle(ctx, scale, shape, base):
-    """RRDBNet: trunk conv (+ feat residual), the high-resolution convs, and - with the register-stationary kernel off - conv5 of every
-    RDB (192 -> 64: twelve K-chunks from two tensors, x 0.2 + x, and the RRDB's second residual written in place)."""
+    """RRDBNet: trunk conv (+ feat residual read from memory), the high-resolution convs, and conv5 of every RDB (192 -> 64: twelve K-chunks
+    from two tensors, x 0.2 + x through the matrix core - the RL builds of the two kernels - and the RRDB's second residual written in place)."""
     t = W.rrdbnet_table(17, scale=scale, num_block=2)
     flat = W.flatten(t, W.rrdbnet_keys(2))
     x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[2] * 7 + shape[3]))
     with torch.no_grad():
         want = onets.rrdbnet(x, t, scale, 2)
-    # conv5: pinned to the register-stationary kernel; on the LDS-weights kernels with its residual read from memory; and the default route
-    # of a small job - residual through the matrix core (the RL builds of the two kernels)
-    for extra in (_capi.MODEL_CONV5_RS, NO_RS, 0):
+    for extra in (0, _capi.MODEL_NO_DENSE):
         outs = [_capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=2, flags=base | extra | fl), flat)(x.cuda()).cpu()
                 for fl in (NO_W16, 0)]
         _close(outs[1], outs[0], want, f"rrdbnet x{scale} {shape} flags {extra}", 60.0)

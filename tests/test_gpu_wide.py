@@ -14,25 +14,8 @@ from sharkshark4k_amd import weights as W
 pytestmark = pytest.mark.gpu
 WIDE = _capi.MODEL_NO_W16   # the wide kernel is the route of these layers when conv_w16.hip (the default since round 4, not bit-identical) is off;
                             # set on BOTH sides: it also keeps conv_last off conv_w16n.hip
-NO_WIDE, NO_RS, NO_DENSE, ONE, TWO = _capi.MODEL_NO_WIDE, _capi.MODEL_NO_RS, _capi.MODEL_NO_DENSE, _capi.MODEL_ONE_CHAIN, _capi.MODEL_TWO_CHAINS
+NO_WIDE, NO_DENSE, ONE, TWO = _capi.MODEL_NO_WIDE, _capi.MODEL_NO_DENSE, _capi.MODEL_ONE_CHAIN, _capi.MODEL_TWO_CHAINS
 DIRECT_UPS = _capi.MODEL_NO_UPS_PRESUM   # the pre-summed up-sampling convs are the one route that is not bit-identical: pinned off here
-
-
-@pytest.mark.parametrize("scale,shape,base", [(2, (1, 3, 144, 208), ONE), (2, (2, 3, 92, 200), TWO), (4, (1, 3, 37, 70), ONE),
-                                              (1, (1, 3, 128, 256), ONE), (4, (3, 3, 9, 33), ONE), (2, (2, 3, 34, 62), NO_DENSE | TWO)])
-def test_wide_bit_identical_rrdbnet(ctx, scale, shape, base):
-    """Trunk / tail layers (incl. both up-sampling convs) and - with conv5 routed off the register-stationary kernel - conv5 of every
-    RDB: residual x 0.2 + x, and (x ... ) x 0.2 + block input written in place over it."""
-    t = W.rrdbnet_table(17, scale=scale, num_block=2)
-    flat = W.flatten(t, W.rrdbnet_keys(2))
-    x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[2] * 7 + shape[3])).cuda()
-    # (conv5 pinned to the register-stationary kernel, or routed off it with its residual read from memory: the two forms that exist on both sides)
-    for extra in (DIRECT_UPS | _capi.MODEL_CONV5_RS, DIRECT_UPS | NO_RS):
-        want = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=2, flags=base | extra | NO_WIDE | WIDE), flat)(x).clone()
-        m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=2, flags=base | extra | WIDE), flat)
-        for _ in range(2):
-            got = m(x)
-            assert torch.isfinite(got).all() and torch.equal(got, want), f"{shape} flags {base | extra}: max |d| {float((got - want).abs().max()):.3g}"
 
 
 @pytest.mark.parametrize("nf,shape,up", [(64, (2, 3, 72, 130), 4), (64, (1, 3, 33, 47), 2), (128, (1, 3, 40, 64), 2)])
@@ -80,11 +63,13 @@ def test_ups_presum_vs_direct_and_oracle(ctx, scale, shape):
 
 
 @pytest.mark.parametrize("shape", [(1, 3, 144, 208), (2, 3, 66, 94)])
-def test_conv5_small_job_route_vs_pinned_and_oracle(ctx, shape):
-    """Round-3 routing (SS4K_MODEL_NO_W16): jobs with fewer than three rounds of tiles run conv5 of every RDB on the wide kernel with its
-    residual through the matrix core ((conv + x / alpha) * alpha) instead of the register-stationary kernel (SS4K_MODEL_CONV5_RS): another
-    order of fp32 additions, the same accuracy against the oracle; every RDB (one residual, and two with the block's input written in place).
-    (Default routing: conv_w16.hip's build of the same form for every job size - tests/test_gpu_w16.py.)"""
+def test_conv5_matrix_core_residual_vs_memory_residual_and_oracle(ctx, shape):
+    """conv5 of every RDB on the wide kernel carries its residual through the matrix core ((conv + x / alpha) * alpha, one more MFMA per
+    accumulator with a (1 / alpha) I fragment); conv_mfma.hip's <2,4,4> build (SS4K_MODEL_NO_WIDE - what a job with planes beyond 4 GB gets)
+    reads it from memory in the epilogue: another order of fp32 additions, the same accuracy against the oracle; every RDB (one residual, and
+    two with the block's input written in place).  (Default routing: conv_w16.hip's build of the same form - tests/test_gpu_w16.py.  The
+    trunk / tail layers of an RRDBNet on the two kernels, bit for bit: tools/dev_tests/test_wide_rrdbnet.py, which can switch the
+    matrix-core residual off.)"""
     from oracle import nets as onets
     from tests.helpers import psnr
     t = W.rrdbnet_table(33, scale=2, num_block=3)
@@ -92,9 +77,9 @@ def test_conv5_small_job_route_vs_pinned_and_oracle(ctx, shape):
     x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[3]))
     with torch.no_grad():
         want = onets.rrdbnet(x, t, 2, 3)
-    small = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=3, flags=WIDE), flat)(x.cuda()).cpu()
-    pinned = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=3, flags=_capi.MODEL_CONV5_RS), flat)(x.cuda()).cpu()
+    rl = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=3, flags=WIDE | DIRECT_UPS), flat)(x.cuda()).cpu()
+    mem = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=3, flags=WIDE | NO_WIDE | DIRECT_UPS), flat)(x.cuda()).cpu()
     peak = float(want.abs().max())
-    p_routes, p_small, p_pinned = psnr(small / peak, pinned / peak), psnr(small / peak, want / peak), psnr(pinned / peak, want / peak)
-    print(f"{shape}: routes {p_routes:.1f} dB apart; vs oracle: wide + matrix-core residual {p_small:.2f} dB, register-stationary {p_pinned:.2f} dB")
-    assert not torch.equal(small, pinned) and p_routes > 70.0 and abs(p_small - p_pinned) < 0.5
+    p_routes, p_rl, p_mem = psnr(rl / peak, mem / peak), psnr(rl / peak, want / peak), psnr(mem / peak, want / peak)
+    print(f"{shape}: routes {p_routes:.1f} dB apart; vs oracle: matrix-core residual {p_rl:.2f} dB, residual from memory {p_mem:.2f} dB")
+    assert not torch.equal(rl, mem) and p_routes > 70.0 and abs(p_rl - p_mem) < 0.5

@@ -1,6 +1,6 @@
-// CPU harness of sharkshark-4k_amd/csrc/chain_plan.h (tests/test_chain_plan_cpu.py compiles and runs it): the dependency plan
+// CPU harness of sharkshark-4k_amd/csrc/chain_plan.h (tools/dev_tests/test_chain_plan_cpu.py compiles and runs it): the dependency plan
 // of three RDBs laid out the way Model::forward lays them out (trunk buffers rotating a -> t1 -> t2 -> a, growth planes reused).
-#include "../sharkshark-4k_amd/csrc/chain_plan.h"
+#include "../../sharkshark-4k_amd/csrc/chain_plan.h"
 #include <cstdio>
 #include <cstdlib>
 using namespace ss4k;

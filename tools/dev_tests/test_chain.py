@@ -2,7 +2,7 @@
 per-tile hand-offs between the layers - against the one-launch-per-layer path.
 
 The chain runs every layer on the LDS-weights kernel's 32-cout tile body, so its results must be BIT-IDENTICAL to the
-per-launch path with SS4K_MODEL_NO_RS (same MFMA order per output, same epilogue arithmetic); against the default
+per-launch path with conv5's residual read from memory (SS4K_NO_RL=1; same MFMA order per output, same epilogue arithmetic); against the default
 per-launch route (conv5 on the register-stationary kernel) only the order of fp32 additions inside a layer differs.
 Every hand-off is exercised on reused buffers (the growth planes are rewritten every RDB, the trunk buffers rotate), so a
 stale read or a too-early write anywhere in the 345-layer chain changes the output."""
@@ -18,13 +18,21 @@ from tests.helpers import psnr, smooth_u8
 
 pytestmark = pytest.mark.gpu
 
-NO_CHAIN, CHAIN, NO_RS = _capi.MODEL_NO_CHAIN, _capi.MODEL_CHAIN, _capi.MODEL_NO_RS
+# dev library only since round 5 (include/ss4k_dev.h).  NO_RS is a pseudo-flag of this file: "conv5's residual read from memory in the
+# epilogue" (what the chain's tile body does) = the dev library's SS4K_NO_RL=1, read when a model is built
+NO_CHAIN, CHAIN, NO_RS = 0, _capi.DEV_MODEL_CHAIN, 1 << 30
 
 
 def _model(ctx, flat, scale, nb, flags):
     # every layer outside the chain (and conv5 of the reference path) on the 32x32x16 kernels the chain's tile body is bit-identical to:
     # conv_w16.hip (the default route of 64-cout layers since round 4) adds in another order
-    return _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=nb, flags=flags | _capi.MODEL_NO_W16), flat)
+    import os
+    if flags & NO_RS:
+        os.environ["SS4K_NO_RL"] = "1"
+    try:
+        return _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=scale, num_block=nb, flags=(flags & ~NO_RS) | _capi.MODEL_NO_W16), flat)
+    finally:
+        os.environ.pop("SS4K_NO_RL", None)
 
 
 @pytest.mark.parametrize("scale,shape,rows", [(2, (1, 3, 144, 208), 0), (2, (2, 3, 92, 200), 16), (2, (3, 3, 80, 72), 20),
@@ -102,7 +110,7 @@ def test_chain_two_contexts_on_two_streams_do_not_deadlock(ctx):
 
 def test_service_model_flags_route_to_the_chain(ctx):
     """The drop-in service passes model_flags through to the library: a one-frame realesrgan job with
-    model_flags=MODEL_CHAIN gives the uint8 frames of the default route within 1 LSB (conv5's summation order differs)."""
+    model_flags=DEV_MODEL_CHAIN gives the uint8 frames of the default route within 1 LSB (conv5's summation order differs)."""
     from sharkshark4k_amd.upscale.hip_upscaler import HipUpscalerService
     tab = W.rrdbnet_table(13, scale=2)
     frames = torch.from_numpy(smooth_u8(7, (1, 72, 104, 3))).cuda()

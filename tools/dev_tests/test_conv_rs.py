@@ -2,8 +2,8 @@
 LDS-weights kernel (csrc/conv_mfma.hip) and the CPU oracle, layer shape by layer shape.
 
 Both kernels read and write the same fp16 "planes" tensors and accumulate in fp32, so their results differ only by
-the order of the fp32 additions (then one fp16 rounding per layer).  ``SS4K_MODEL_NO_RS`` in the model description routes every
-layer to the LDS-weights kernel (A/B switch of Model::build).
+the order of the fp32 additions (then one fp16 rounding per layer).  Dev library only since round 5: ``SS4K_RS_MASK=63`` +
+``SS4K_CONV5_MODE=1`` (read when a model is built) route every layer shape the kernel is built for to it; without them no layer takes it.
 """
 import os
 
@@ -21,9 +21,12 @@ pytestmark = pytest.mark.gpu
 
 
 def _build(ctx, desc, flat, no_rs):
-    # SS4K_MODEL_NO_RS (include/ss4k.h): every layer on the LDS-weights kernel
-    desc.flags = (desc.flags | _capi.MODEL_NO_RS) if no_rs else (desc.flags & ~_capi.MODEL_NO_RS)
-    return _capi.Model(ctx, desc, flat)
+    if not no_rs:
+        os.environ.update(SS4K_RS_MASK="63", SS4K_CONV5_MODE="1")
+    try:
+        return _capi.Model(ctx, desc, flat)
+    finally:
+        os.environ.pop("SS4K_RS_MASK", None); os.environ.pop("SS4K_CONV5_MODE", None)
 
 
 @pytest.mark.parametrize("scale,shape", [(2, (1, 3, 64, 96)), (2, (3, 3, 86, 150)), (4, (2, 3, 37, 70)), (1, (1, 3, 128, 256))])
@@ -67,7 +70,7 @@ def test_rs_kernel_is_deterministic_and_batch_invariant(ctx):
     """The tile walk, ring slots and counted waits must never change a pixel: the same frame gives bit-identical
     results alone, inside a batch, and on repeated calls (a landed-too-late DMA would show up here)."""
     tab = W.rrdbnet_table(3, scale=2, num_block=2)
-    m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=2), W.flatten(tab, W.rrdbnet_keys(2)))
+    m = _build(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=2), W.flatten(tab, W.rrdbnet_keys(2)), no_rs=False)
     x = torch.rand(4, 3, 360, 640).cuda()
     y = m(x)
     for _ in range(5):
@@ -81,7 +84,7 @@ def test_rs_kernel_full_size_repeatability(ctx):
     (351 launches, ~7 tiles per workgroup, tile-boundary stores in flight) must give bit-identical frames on
     every one of 12 runs."""
     tab = W.rrdbnet_table(0, scale=2)
-    m = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2), W.flatten(tab, W.rrdbnet_keys(23)))
+    m = _build(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2), W.flatten(tab, W.rrdbnet_keys(23)), no_rs=False)
     x = torch.from_numpy(smooth_u8(31, (4, 720, 1280, 3))).permute(0, 3, 1, 2).float().div(255.0).cuda()
     ref = m(x)
     assert torch.isfinite(ref).all()

@@ -28,7 +28,7 @@ for i in range(cases):
     if rng.random() < 0.3: gw = int(rng.choice([30, 31, 32, 33, 34, 63, 64, 65, 96]))
     lanes = _capi.MODEL_TWO_CHAINS if (n % 2 == 0 and rng.random() < 0.5) else _capi.MODEL_ONE_CHAIN
     x = torch.rand(n, 3, gh * r, gw * r, generator=torch.Generator().manual_seed(i)).cuda()
-    pin = _capi.MODEL_NO_W16 | _capi.MODEL_CONV5_RS | _capi.MODEL_NO_UPS_PRESUM   # (the pre-summed up-sampling convs are not bit-identical either)
+    pin = _capi.MODEL_NO_W16 | _capi.DEV_MODEL_CONV5_RS | _capi.MODEL_NO_UPS_PRESUM   # (the pre-summed up-sampling convs are not bit-identical either)
     want = model(scale, lanes | pin | _capi.MODEL_NO_DENSE | _capi.MODEL_NO_WIDE)(x).clone()
     got = model(scale, lanes | pin)(x).clone()
     dflt = model(scale, lanes)(x)

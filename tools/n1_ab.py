@@ -9,7 +9,7 @@ from sharkshark4k_amd import _capi, weights as W
 
 nf = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-variants = sys.argv[3].split(",") if len(sys.argv) > 3 else ["0", str(_capi.MODEL_NO_RS)]
+variants = sys.argv[3].split(",") if len(sys.argv) > 3 else ["0", str(0)]
 def setenv(v):
     for k in [k for k in os.environ if k.startswith("SS4K_CHAIN_")]:
         del os.environ[k]
