@@ -34,6 +34,7 @@ Cost: a second copy of the SR weights and activation workspace (RRDBNet x2 at 72
 from __future__ import annotations
 
 import contextlib
+import sys
 from typing import Mapping, Optional
 
 import torch
@@ -46,6 +47,8 @@ LR_LEVELS = [(360, 640), (540, 960), (630, 1120), (720, 1280), (900, 1600), (108
 
 
 def log(*args, **kwargs):
+    # stderr: a process that prints a result on stdout (bench.py's one JSON line) may run a service in-process
+    kwargs.setdefault("file", sys.stderr)
     print(f"HipUpscalerService: {' '.join(str(a) for a in args)}", **kwargs)
 
 
