@@ -25,11 +25,15 @@ blob reaches the other workers through one ``sharding.broadcast_weights`` each; 
 independent.  The reference builds one service on ``device=0`` (``src/sharkshark/pipeline.py:20,41-50``); SURVEY.md 8(e).
 
 One-frame jobs (``overlap_jobs=True``, batched path only - the image server's caller, ``image_pipeline.py:54-64,280-287``): consecutive
-one-frame jobs alternate over TWO job sets (context + model + upscaler + stream), so that job i + 1's launches fill the launch
-boundaries and partly filled tile rounds of job i - what frame lanes do inside a multi-frame job.  Frames are bit-identical to the
+one-frame jobs alternate over ``overlap_sets`` (3) job sets (context + model + upscaler + stream), so that job i + 1's launches fill the
+launch boundaries and partly filled tile rounds of job i - what frame lanes do inside a multi-frame job.  Frames are bit-identical to the
 single-set path (same kernels, same weights).  The worker hands result i over after job i + 1 has been enqueued
 (``BaseService.deliver_lag``); ``upscale()`` called directly stays synchronous with the current stream unless ``wait=False``.
-Cost: a second copy of the SR weights and activation workspace (RRDBNet x2 at 720p: 67 MB + 177 MB), built on the first one-frame job.
+Measured on one box (RRDBNet x2, 720p, ``profiles/r05_n1_probe_sets.txt``): one set 108.8 frames/s, two 122.8, three 125.6, four 124.9 -
+against 127.5 for four-frame jobs; two- and four-frame jobs gain nothing from alternating (125.5 / 125.7 against 125.0 / 127.5), so they
+stay on set 0.  Cost per extra set: a copy of the SR weights and activation workspace (RRDBNet x2 at 720p: 67 MB + 177 MB), built on the
+first one-frame job.  HIP serves a process's streams from a few hardware queues: the sets' streams are checked once to really run side by
+side (``_check_streams``).
 """
 from __future__ import annotations
 
@@ -60,7 +64,7 @@ class HipUpscalerService(BaseUpscalerService):
                  # knobs the reference hard-codes
                  scale=4, model_name=None, dtype="f16", weights=None, checkpoint_dir: Optional[str] = None,
                  lr_shape=None, single_mode=None, seed=0, model_flags=0, fsrcnn_dtype="f32",
-                 group: Optional[sharding.GroupSpec] = None, overlap_jobs=True):
+                 group: Optional[sharding.GroupSpec] = None, overlap_jobs=True, overlap_sets=3, overlap_max_frames=1):
         if jit_mode not in (None, "hip"):
             raise Exception(f"jit_mode={jit_mode!r}: this build has one backend, 'hip'")
         if upscaler_model not in ("fsrcnn", "realesrgan"):
@@ -89,6 +93,8 @@ class HipUpscalerService(BaseUpscalerService):
         self.model_flags = int(model_flags)  # SS4K_MODEL_* routing switches for the SR model (include/ss4k.h)
         self.group = group
         self.overlap_jobs = bool(overlap_jobs)
+        self.overlap_sets = max(2, int(overlap_sets))            # job sets that consecutive small jobs alternate over
+        self.overlap_max_frames = int(overlap_max_frames)        # jobs of up to this many frames alternate (bigger ones overlap with themselves: frame lanes)
         super().__init__()
 
     # worker side -----------------------------------------------------------------------------
@@ -182,6 +188,7 @@ class HipUpscalerService(BaseUpscalerService):
         self._sets = [{"ctx": self.ctx, "model": self.model, "denoise": self.denoise_model, "up": None, "key": None, "stream": None}]
         self._alt = 0
         self._pending = {}
+        self._streams_checked = False
         if not (self.overlap_jobs and not self.single_mode):
             self._flats.pop("sr", None)      # (no second set will ever be built: drop the host copy)
         self._flats.pop("denoise", None)     # (the batched path never denoises)
@@ -201,6 +208,43 @@ class HipUpscalerService(BaseUpscalerService):
         if js["stream"] is None and self._overlap_active():
             js["stream"] = torch.cuda.Stream(self.torch_device)
         return js
+
+    def _check_streams(self, frames: torch.Tensor, tries: int = 6) -> None:
+        """One-off, at the first small job: do the job sets' streams really run side by side?  HIP serves a process's streams from a few
+        hardware queues (four by default); two streams that share one are executed in order, whatever the program says - seen on a process
+        that had created many streams before (profiles/r05_n1_probe_streams.txt: 107 instead of 122 frames/s, silently).  So: time two jobs
+        on sets 0 and 1 with both on stream 0, then on their own streams; if the second form is not faster, give the later set another stream
+        and try again.  Blocks the host for a few jobs' time, once per service."""
+        self._streams_checked = True
+        frames = frames[:1]   # (one-frame jobs gain 12-15 % from running side by side: a clear signal; multi-frame jobs gain nothing, measured)
+        dev, cur = self.torch_device, torch.cuda.current_stream(self.torch_device)
+        sets = [self._job_set(k) for k in range(self.overlap_sets)]
+        ups = [self._get_upscaler(k) for k in range(self.overlap_sets)]
+        def timed(streams):
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            for st in set(streams):
+                st.wait_stream(cur)
+            for up, st in zip(ups, streams):
+                with torch.cuda.stream(st):
+                    up(frames)
+            for st in set(streams):
+                cur.wait_stream(st)
+            e1.record(cur)
+            e1.synchronize()
+            return e0.elapsed_time(e1)
+        timed([js["stream"] for js in sets])   # (first calls size workspaces and raise LDS limits)
+        serial = min(timed([sets[0]["stream"]] * len(sets)) for _ in range(2))
+        for k in range(1, len(sets)):
+            for attempt in range(tries):
+                both = min(timed([sets[0]["stream"]] * k + [sets[k]["stream"]] + [sets[0]["stream"]] * (len(sets) - k - 1)) for _ in range(2))
+                if both < 0.96 * serial:
+                    break
+                log(f"job set {k}: its stream does not run beside set 0's ({both:.2f} ms against {serial:.2f} ms in order) - taking another stream")
+                sets[k]["stream"] = torch.cuda.Stream(dev)
+            else:
+                log(f"job set {k}: no stream found that overlaps with set 0's after {tries} tries; jobs will run in order")
 
     def _get_upscaler(self, k: int = 0):
         from .. import _capi
@@ -250,8 +294,10 @@ class HipUpscalerService(BaseUpscalerService):
         if not self._overlap_active():
             return self._run(0, frames)
         k = 0
-        if frames.shape[0] == 1:   # consecutive one-frame jobs alternate; a multi-frame job overlaps with itself (frame lanes) on set 0
-            k, self._alt = self._alt, self._alt ^ 1
+        if frames.shape[0] <= self.overlap_max_frames:   # consecutive one-frame jobs alternate; a multi-frame job overlaps with itself (frame lanes) on set 0
+            if not self._streams_checked:
+                self._check_streams(frames)
+            k, self._alt = self._alt, (self._alt + 1) % self.overlap_sets
         cur = torch.cuda.current_stream(self.torch_device)
         side = self._job_set(k)["stream"]
         side.wait_stream(cur)   # the frames (an IPC tensor's ready event, a .to(device) copy) are ordered on the current stream

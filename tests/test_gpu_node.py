@@ -79,7 +79,7 @@ def test_node_two_workers_one_gpu_rank0_loads_jobs_alternate(want):
 
 
 def test_one_frame_jobs_alternate_over_two_job_sets_bit_identical(want):
-    """The worker's one-frame overlap, driven in-process: consecutive one-frame jobs run on two (context, model, stream) sets; a
+    """The worker's one-frame overlap, driven in-process: consecutive one-frame jobs run on three (context, model, stream) sets; a
     multi-frame job in between runs on set 0; every frame equals the single-set result; ``wait=False`` hands results over un-ordered
     (the worker loop orders them one job later, ``proc_before_deliver``), ``wait=True`` orders them on the current stream."""
     frames, ref = want
@@ -88,7 +88,7 @@ def test_one_frame_jobs_alternate_over_two_job_sets_bit_identical(want):
     assert svc.deliver_lag == 1 and len(svc._sets) == 1
     dev = frames.cuda()
     outs = [svc.upscale(dev[i:i + 1]) for i in range(5)]                 # ordered on the current stream: .cpu() below is safe
-    assert len(svc._sets) == 2 and svc._sets[0]["stream"] is not None and svc._sets[1]["stream"] is not None
+    assert len(svc._sets) == 3 and all(js["stream"] is not None for js in svc._sets)
     assert torch.equal(torch.cat(outs).cpu(), ref[:5])
     mixed = [svc.upscale(dev[0:1], wait=False), svc.upscale(dev[4:8], wait=False), svc.upscale(dev[1:2], wait=False), svc.upscale(dev[2:3], wait=False)]
     torch.cuda.synchronize()
