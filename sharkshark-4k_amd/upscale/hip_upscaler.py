@@ -27,8 +27,8 @@ independent.  The reference builds one service on ``device=0`` (``src/sharkshark
 One-frame jobs (``overlap_jobs=True``, batched path only - the image server's caller, ``image_pipeline.py:54-64,280-287``): consecutive
 one-frame jobs alternate over ``overlap_sets`` (3) job sets (context + model + upscaler + stream), so that job i + 1's launches fill the
 launch boundaries and partly filled tile rounds of job i - what frame lanes do inside a multi-frame job.  Frames are bit-identical to the
-single-set path (same kernels, same weights).  The worker hands result i over after job i + 1 has been enqueued
-(``BaseService.deliver_lag``); ``upscale()`` called directly stays synchronous with the current stream unless ``wait=False``.
+single-set path (same kernels, same weights).  The worker hands result i over after the next ``overlap_sets - 1`` jobs have been enqueued, or
+at once when the queue runs dry (``BaseService.deliver_lag``); ``upscale()`` called directly stays synchronous with the current stream unless ``wait=False``.
 Measured on one box (RRDBNet x2, 720p, ``profiles/r05_n1_probe_sets.txt``): one set 108.8 frames/s, two 122.8, three 125.6, four 124.9 -
 against 127.5 for four-frame jobs; two- and four-frame jobs gain nothing from alternating (125.5 / 125.7 against 125.0 / 127.5), so they
 stay on set 0.  Cost per extra set: a copy of the SR weights and activation workspace (RRDBNet x2 at 720p: 67 MB + 177 MB), built on the
@@ -192,7 +192,9 @@ class HipUpscalerService(BaseUpscalerService):
         if not (self.overlap_jobs and not self.single_mode):
             self._flats.pop("sr", None)      # (no second set will ever be built: drop the host copy)
         self._flats.pop("denoise", None)     # (the batched path never denoises)
-        self.deliver_lag = 1 if self._overlap_active() else 0
+        # the worker hands result i over once jobs i + 1 .. i + sets - 1 have been enqueued: the wait for result i goes onto the current stream,
+        # which every later job's stream waits for before it starts - delivered any earlier, result i would hold back job i + sets - 1
+        self.deliver_lag = self.overlap_sets - 1 if self._overlap_active() else 0
 
     def _overlap_active(self) -> bool:
         return bool(self.overlap_jobs) and not self.single_mode and "sr" in getattr(self, "_flats", {})

@@ -85,7 +85,7 @@ def test_one_frame_jobs_alternate_over_two_job_sets_bit_identical(want):
     frames, ref = want
     svc = HipUpscalerService(device=0, **KW)
     svc.proc_init()
-    assert svc.deliver_lag == 1 and len(svc._sets) == 1
+    assert svc.deliver_lag == 2 and len(svc._sets) == 1
     dev = frames.cuda()
     outs = [svc.upscale(dev[i:i + 1]) for i in range(5)]                 # ordered on the current stream: .cpu() below is safe
     assert len(svc._sets) == 3 and all(js["stream"] is not None for js in svc._sets)
@@ -102,7 +102,7 @@ def test_one_frame_jobs_alternate_over_two_job_sets_bit_identical(want):
 
 
 def test_worker_loop_delivers_in_order_with_the_overlap(want):
-    """The real worker process with deliver_lag = 1: twelve one-frame jobs pushed back to back, results in order and bit-identical; a
+    """The real worker process with deliver_lag = 2: twelve one-frame jobs pushed back to back, results in order and bit-identical; a
     lone job (nothing follows it) still comes back at once."""
     frames, ref = want
     from sharkshark4k_amd.upscale.upscaler_base import UpscalerQueueEntry
