@@ -45,10 +45,29 @@ constexpr int XT_DMA = (XT_SLOTS + 63) / 64;        // 23 wave-level DMA instruc
 constexpr int DMA_PER_WAVE = (XT_DMA + NW - 1) / NW;  // 6
 constexpr int WU = 6 * 1024, NSLOT = 5;             // weight unit, ring slots
 constexpr int NDMA = 11;                            // DMA slots per wave and chunk: 6 tile pieces, 3 for weight units 0 and 1, 2 for unit 2
-constexpr int W_OFF = 2 * XT_BYTES, B_OFF = W_OFF + NSLOT * WU;
-constexpr size_t LDS_BYTES = B_OFF + 64 * 4;
+constexpr int W_OFF = 2 * XT_BYTES, B_OFF = W_OFF + NSLOT * WU, R_OFF = B_OFF + 64 * 4;   // R_OFF: every thread's ring-table entry
+constexpr size_t LDS_BYTES = R_OFF + 64 * NW * 4;
 static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 static_assert((TH + 3) * ROWX <= XT_BYTES, "x_k's plane image fits a tile buffer");
+
+// Which pixel of the one-pixel ring of x_k around the tile a lane of the ring group computes: [wave][lane & 31] = j | i << 8 | live << 16 in
+// x_k coordinates (j, i) = tile-image pixel (j + 1, i + 1); top row j = 0 and bottom row j = 17 (i = 0..33), left column i = 0 and right
+// column i = 33 (j = 1..16): 100 pixels on 4 x 32 lanes, an idle lane repeats a live lane's pixel (same LDS address: a broadcast).
+// Chosen for ds_read_b128's real lane groups ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}) by tools/costing/ring_table.py: a column's
+// pixels share two bank slots, so zero conflicts is out of reach with this image - 45 extra LDS cycles over the 9 taps x 8 groups
+// against 126 for round 4's formula (two column pixels + nine row pixels per 16-lane HALF).  Placement only: any table that covers the
+// ring gives the same bits.
+__constant__ uint32_t RING_TAB[128] = {
+// tools/costing/ring_table.py: 45 extra LDS cycles over the 9 taps x 8 lane groups (round 4's formula: 126)
+  0x10000, 0x10f00, 0x11000, 0x11500, 0x10300, 0x10400, 0x10600, 0x10a00, 0x11d00, 0x11e00, 0x10005, 0x12106, 0x11600, 0x11900, 0x12100, 0x10003,
+  0x12107, 0x1000a, 0x1000c, 0x10511, 0x12108, 0x10009, 0x10111, 0x10611, 0x11311, 0x11611, 0x11d11, 0x00000, 0x10911, 0x10a11, 0x10b11, 0x11111,
+  0x10700, 0x10c00, 0x10d00, 0x11b00, 0x10500, 0x10900, 0x11200, 0x12104, 0x10006, 0x1000b, 0x10311, 0x00500, 0x12103, 0x1210a, 0x1210c, 0x1000f,
+  0x00500, 0x00500, 0x00500, 0x00500, 0x1210f, 0x10010, 0x10411, 0x10e11, 0x10f11, 0x11011, 0x11a11, 0x11e11, 0x00500, 0x00500, 0x00500, 0x00500,
+  0x10200, 0x11a00, 0x12102, 0x12105, 0x11100, 0x11800, 0x11c00, 0x11f00, 0x10002, 0x10007, 0x1210b, 0x1000d, 0x1000e, 0x10211, 0x10711, 0x10d11,
+  0x11211, 0x11411, 0x11511, 0x11711, 0x11b11, 0x11f11, 0x12011, 0x00200, 0x00200, 0x00200, 0x00200, 0x00200, 0x11811, 0x12111, 0x01100, 0x01100,
+  0x10800, 0x10b00, 0x11300, 0x11400, 0x10100, 0x10e00, 0x11700, 0x10008, 0x12109, 0x10011, 0x11c11, 0x00100, 0x12000, 0x10001, 0x12101, 0x10004,
+  0x00100, 0x00100, 0x00100, 0x00100, 0x1210d, 0x1210e, 0x12110, 0x10811, 0x10c11, 0x11911, 0x00800, 0x00800, 0x00100, 0x00100, 0x00100, 0x00100,
+};
 
 // LeakyReLU with a slope in [0, 1] as max(t, slope t) - the value conv_mfma.hip's epilogue computes with fmaxf - of the 16 values of an
 // accumulator: the products two at a time (v_pk_mul_f32), the maximum as ONE v_max_f32 each (asm: fmaxf, and v_med3(t, slope t, +inf)
@@ -113,22 +132,14 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_dense2_kernel(const DenseA
   int rd_base[3];
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx) rd_base[dx] = img_off(wave * MB + 1, lr + 1 + dx);
-  // The ring of x_k around the tile, in x_k coordinates (j, i) = buffer (j + 1, i + 1): top row j = 0 and bottom row j = 17 (i = 0..33),
-  // left column i = 0 and right column i = 33 (j = 1..16).  Ring group w: every 16-lane half u = 2w + (lane >> 4) & 1 takes two pixels of
-  // each column (consecutive rows: different banks) and nine consecutive pixels of the two rows; 3 of 16 lanes idle.
-  auto ring_pixel = [&]() -> int {   // j | i << 8 | valid << 16 (recomputed where needed: cheaper than a register through the MFMA loops)
-    int lre = lr;
-    asm volatile("" : "+v"(lre));
-    const int u = 2 * wave + (lre >> 4), t = lre & 15;
-    int j = 0, i = 0; bool ok = true;
-    if (t < 4) { j = 1 + 2 * u + (t & 1); i = (t & 2) ? TW + 1 : 0; }
-    else {
-      const int p = 9 * u + (t - 4);
-      ok = t < 13 && p < 2 * (TW + 2);
-      j = p < TW + 2 ? 0 : TH + 1; i = p < TW + 2 ? p : p - (TW + 2);
-    }
-    if (!ok) { j = 0; i = 0; }
-    return j | (i << 8) | ((ok ? 1 : 0) << 16);
+  // The ring of x_k around the tile: this lane's pixel from RING_TAB, parked in LDS (one slot per thread) and re-read where it is needed -
+  // cheaper than a register through the MFMA loops.  (The slot is read by its own thread only: no barrier.)
+  uint32_t* ring_slot = reinterpret_cast<uint32_t*>(smem + R_OFF) + tid;
+  *ring_slot = RING_TAB[wave * 32 + lr];
+  auto ring_pixel = [&]() -> int {   // j | i << 8 | live << 16
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(lds0 + R_OFF + tid * 4)) : "memory");
+    return (int)v;
   };
   int rd_h[3];   // x_k (j, i) reads buffer (j + dy, i + dx)
 #pragma unroll

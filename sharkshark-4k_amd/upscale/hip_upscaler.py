@@ -37,6 +37,7 @@ side (``_check_streams``).
 """
 from __future__ import annotations
 
+import collections
 import contextlib
 import sys
 from typing import Mapping, Optional
@@ -188,6 +189,7 @@ class HipUpscalerService(BaseUpscalerService):
         self._sets = [{"ctx": self.ctx, "model": self.model, "denoise": self.denoise_model, "up": None, "key": None, "stream": None}]
         self._alt = 0
         self._pending = {}
+        self._inflight = collections.deque()   # (end-of-job event, input frames) of jobs on a job set's stream: see _retire
         self._streams_checked = False
         if not (self.overlap_jobs and not self.single_mode):
             self._flats.pop("sr", None)      # (no second set will ever be built: drop the host copy)
@@ -259,7 +261,16 @@ class HipUpscalerService(BaseUpscalerService):
             js["key"] = key
         return js["up"]
 
+    def _retire(self) -> None:
+        """Let go of the input frames of jobs whose device work has finished.  A job's input is usually a tensor received over CUDA IPC; when
+        its last reference dies torch closes the IPC mapping at once - not in stream order - and a job running on a job set's own
+        (non-blocking) stream may still be reading it.  So the service keeps the reference until the job's end event has fired."""
+        q = getattr(self, "_inflight", None)
+        while q and q[0][0].query():
+            q.popleft()
+
     def proc_before_deliver(self, entry):
+        self._retire()
         # a result computed on a job set's own stream: the current stream - on which the result tensor is handed to the consumer
         # (on_queue, or the IPC event torch records when the tensor is pickled into the result queue) - waits for it here
         pending = getattr(self, "_pending", None)
@@ -307,6 +318,8 @@ class HipUpscalerService(BaseUpscalerService):
         with torch.cuda.stream(side):
             out = self._run(k, frames)
         done = side.record_event()
+        self._retire()
+        self._inflight.append((done, frames))
         out.record_stream(cur)
         if getattr(self, "_in_worker", False):
             self._pending[id(out)] = (out, done)   # proc_before_deliver makes the current stream wait, one job later
