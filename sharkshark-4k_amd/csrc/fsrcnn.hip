@@ -982,8 +982,12 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
 //   * PReLU on packed fp16.
 // 16-byte chunk q of a ring row sits at a chunk with its low two bits XOR-ed by higher bits of q (mh_chunk): a wave's 16-byte reads at a
 // 64-byte lane stride spread over all banks.
-constexpr int MH_COLS = 64, MH_HALO = 4, MH_CI = MH_COLS - 2 * MH_HALO, MH_REC = MH_COLS + 2;
-constexpr int MH_ROWB = MH_REC * 32, MH_STAGEB = 4 * MH_ROWB, MH_LDS = 4 * MH_STAGEB;
+// NU units of 64 columns per workgroup strip (a wave computes NU x 32 pixel pairs per row: NU independent accumulators, reads and
+// epilogues between two barriers; 8 halo columns per 64 NU instead of per 64)
+constexpr int MH_HALO = 4;
+template <int NU> struct MhGeo {
+  static constexpr int COLS = 64 * NU, CI = COLS - 2 * MH_HALO, REC = COLS + 2, ROWB = REC * 32, STAGEB = 4 * ROWB, LDS = 4 * STAGEB;
+};
 __device__ __forceinline__ int mh_chunk(int q) {
 #ifdef SS4K_MH_SWZ_OLD
   return (q ^ ((q >> 4) & 3)) * 16;
@@ -993,9 +997,10 @@ __device__ __forceinline__ int mh_chunk(int q) {
 #endif
 }
 
-template <bool STAMP>
-__global__ __launch_bounds__(256, 4) void k_fs_maps4_h(const uint2* __restrict__ in, uint2* __restrict__ out, const FsMapW W,
-                                                       int planes, int h, int w, int bands, unsigned long long* dbg) {
+template <bool STAMP, int NU>
+__global__ __launch_bounds__(256, 4 / NU) void k_fs_maps4_h(const uint2* __restrict__ in, uint2* __restrict__ out, const FsMapW W,
+                                                            int planes, int h, int w, int bands, unsigned long long* dbg) {
+  constexpr int MH_COLS = MhGeo<NU>::COLS, MH_CI = MhGeo<NU>::CI, MH_ROWB = MhGeo<NU>::ROWB, MH_STAGEB = MhGeo<NU>::STAGEB, MH_LDS = MhGeo<NU>::LDS;
   extern __shared__ __attribute__((aligned(16))) char mh_ring[];
   // dev build, STAMP: cycles of this wave per phase (s_memtime): [0] loader, [1] operand reads + MFMAs, [2] epilogue + stores, [3] barrier
   unsigned long long ph[4] = {0, 0, 0, 0}, tlast = 0, rt0 = 0, ct0 = 0;
@@ -1049,11 +1054,11 @@ __global__ __launch_bounds__(256, 4) void k_fs_maps4_h(const uint2* __restrict__
   int rd[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) rd[c] = st * MH_STAGEB + mh_chunk(2 * (2 * n + c) + hh);
-  // this lane's output pixel: ring column 2n + hh, its record's two chunks in the next layer's ring
+  // this lane's output pixel of unit un: ring column 2n + hh + 64 un, its record's two chunks in the next layer's ring (a unit is 128
+  // chunks = 2 KB further: mh_chunk permutes chunks inside blocks of 64 only)
   const int oc = 2 * n + hh, X = x0 - MH_HALO + oc;
   const int wr0 = (st + 1) * MH_STAGEB + mh_chunk(2 * (oc + 1)), wr1 = (st + 1) * MH_STAGEB + mh_chunk(2 * (oc + 1) + 1);
   const bool edge = x0 - MH_HALO < 0 || x0 - MH_HALO + MH_COLS > w;   // wave-uniform: this strip has columns outside the image
-  const bool col_in = X >= 0 && X < w;
 
   const size_t plane_px = (size_t)h * w, total = (size_t)planes * plane_px;
   const uint2* src = in + (size_t)plane * plane_px;
@@ -1061,28 +1066,30 @@ __global__ __launch_bounds__(256, 4) void k_fs_maps4_h(const uint2* __restrict__
   // input loader: thread tid < 192 moves channel group lg = tid / 64 (8 bytes) of ring column lc = tid % 64; threads 192..255 write
   // the constant-1 slots of the row
   const int lg = tid >> 6, lc = tid & 63, lx = x0 - MH_HALO + lc;
-  const bool lcol_in = lx >= 0 && lx < w;
   const int ld_off = mh_chunk(2 * (lc + 1) + (lg >> 1)) + 8 * (lg & 1);
   // Every load is UNCONDITIONAL (address clamped into the image, the value replaced when it is stored): a load under a branch makes
   // hipcc wait with vmcnt(0), which also waits for the rows requested after it and turns the four-row prefetch into none
-  const size_t lsrc = (size_t)min(lg, 2) * total + (size_t)min(max(lx, 0), w - 1);
-  auto load_row = [&](int r) -> uint2 {   // relative row r = image row ylo - 4 + r
-    return src[lsrc + (size_t)min(max(ylo - 4 + r, 0), h - 1) * w];
+  const size_t lplane = (size_t)min(lg, 2) * total;
+  auto load_row = [&](int r, int un) -> uint2 {   // relative row r = image row ylo - 4 + r, column lc + 64 un of the strip
+    return src[lplane + (size_t)min(max(lx + 64 * un, 0), w - 1) + (size_t)min(max(ylo - 4 + r, 0), h - 1) * w];
   };
-  auto store_row = [&](int r, uint2 v) {   // into slot r & 3
-    const int y = ylo - 4 + r;
-    const bool in_img = lcol_in && y >= 0 && y < h;
+  auto store_row = [&](int r, int un, uint2 v) {   // into slot r & 3
+    const int y = ylo - 4 + r, xx = lx + 64 * un;
+    const bool in_img = xx >= 0 && xx < w && y >= 0 && y < h;
     uint2 o;   // (component-wise selects: selecting between whole values makes hipcc select between their addresses in scratch)
     o.x = in_img ? (lg == 3 ? 0x00003c00u : v.x) : 0u;
     o.y = (in_img && lg != 3) ? v.y : 0u;
-    *reinterpret_cast<uint2*>(mh_ring + (r & 3) * MH_ROWB + ld_off) = o;
+    *reinterpret_cast<uint2*>(mh_ring + (r & 3) * MH_ROWB + ld_off + un * 2048) = o;
   };
   __syncthreads();   // rings are zero
-  store_row(0, load_row(0)); store_row(1, load_row(1));
-  // four input rows in flight: a step is shorter than a trip to HBM, so row t + 2 was requested four steps before it is stored
-  uint2 nxt[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) nxt[(i + 2) & 3] = load_row(i + 2);
+  for (int un = 0; un < NU; ++un) { store_row(0, un, load_row(0, un)); store_row(1, un, load_row(1, un)); }
+  // four input rows in flight: a step is shorter than a trip to HBM, so row t + 2 was requested four steps before it is stored
+  uint2 nxt[NU][4];
+#pragma unroll
+  for (int un = 0; un < NU; ++un)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nxt[un][(i + 2) & 3] = load_row(i + 2, un);
   __syncthreads();
   const f32x16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int nsteps = (yhi - ylo) + 4 + 6;   // layer 3 reaches relative row (yhi - ylo) + 3 at step that + 6
@@ -1096,44 +1103,65 @@ __global__ __launch_bounds__(256, 4) void k_fs_maps4_h(const uint2* __restrict__
       if (t >= nsteps) break;   // uniform over the workgroup
       // input row t + 2 goes into layer 0's ring (slot (t + 2) & 3) while rows t - 1 .. t + 1 are being read; row t + 6 is requested
       stamp(-1);
-      store_row(t + 2, nxt[(u + 2) & 3]);
-      nxt[(u + 2) & 3] = load_row(t + 6);
+#pragma unroll
+      for (int un = 0; un < NU; ++un) {
+        store_row(t + 2, un, nxt[un][(u + 2) & 3]);
+        nxt[un][(u + 2) & 3] = load_row(t + 6, un);
+      }
       stamp(0);
       const int r = t - 2 * st;   // this layer's output row (wave-uniform)
       if (r >= 0 && r <= rlast) {
         const int y = ylo - 4 + r;
         const bool row_in = y >= 0 && y < h;
-        uint32_t E[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        uint32_t E[NU][8];
+#pragma unroll
+        for (int un = 0; un < NU; ++un)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) E[un][j] = 0u;
         if (row_in) {   // wave-uniform
-          f32x16v acc = zero16;
-          // the four pixel operands of a kernel row are read together, then its four MFMAs issue; the next row's reads overlap them
-          // (left to itself hipcc re-uses one register quad: read, wait, MFMA, twelve times over)
+          f32x16v acc[NU];
+#pragma unroll
+          for (int un = 0; un < NU; ++un) acc[un] = zero16;
+          // the four pixel operands of a kernel row (of every unit) are read together, then its MFMAs issue; the next row's reads overlap
+          // them (left to itself hipcc re-uses one register quad: read, wait, MFMA, twelve times over)
 #pragma unroll
           for (int dy = 0; dy < 3; ++dy) {
-            uint4 b[4];
+            uint4 b[NU][4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const uint4*>(mh_ring + rd[c] + ((u + 3 + dy) & 3) * MH_ROWB);
+            for (int un = 0; un < NU; ++un)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) b[un][c] = *reinterpret_cast<const uint4*>(mh_ring + rd[c] + un * 2048 + ((u + 3 + dy) & 3) * MH_ROWB);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A[dy][c]), __builtin_bit_cast(f16x8v, b[c]), acc, 0, 0, 0);
+#pragma unroll
+              for (int un = 0; un < NU; ++un)
+                acc[un] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A[dy][c]), __builtin_bit_cast(f16x8v, b[un][c]), acc[un], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
           stamp(1);
 #pragma unroll
-          for (int j = 0; j < 6; ++j) E[j] = prelu_h2(half2_rne(acc[2 * j], acc[2 * j + 1]), slp[j]);
-          E[6] = 0x00003c00u;
-          if (edge && !col_in) {   // a column outside the image is zero padding for the next layer
+          for (int un = 0; un < NU; ++un) {
 #pragma unroll
-            for (int j = 0; j < 7; ++j) E[j] = 0u;
+            for (int j = 0; j < 6; ++j) E[un][j] = prelu_h2(half2_rne(acc[un][2 * j], acc[un][2 * j + 1]), slp[j]);
+            E[un][6] = 0x00003c00u;
+            const int Xu = X + 64 * un;
+            if (edge && !(Xu >= 0 && Xu < w)) {   // a column outside the image is zero padding for the next layer
+#pragma unroll
+              for (int j = 0; j < 7; ++j) E[un][j] = 0u;
+            }
           }
         }
-        if (st < 3) {
-          *reinterpret_cast<uint4*>(mh_ring + wr0 + ((u + 2) & 3) * MH_ROWB) = make_uint4(E[0], E[1], E[2], E[3]);
-          *reinterpret_cast<uint4*>(mh_ring + wr1 + ((u + 2) & 3) * MH_ROWB) = make_uint4(E[4], E[5], E[6], E[7]);
-        } else if (row_in && y >= ylo && y < yhi && oc >= MH_HALO && oc < MH_HALO + MH_CI && X < w) {
-          uint2* o = dst + (size_t)y * w + X;
-          o[0] = make_uint2(E[0], E[1]); o[total] = make_uint2(E[2], E[3]); o[2 * total] = make_uint2(E[4], E[5]);
+#pragma unroll
+        for (int un = 0; un < NU; ++un) {
+          const int ocu = oc + 64 * un, Xu = X + 64 * un;
+          if (st < 3) {
+            *reinterpret_cast<uint4*>(mh_ring + wr0 + un * 2048 + ((u + 2) & 3) * MH_ROWB) = make_uint4(E[un][0], E[un][1], E[un][2], E[un][3]);
+            *reinterpret_cast<uint4*>(mh_ring + wr1 + un * 2048 + ((u + 2) & 3) * MH_ROWB) = make_uint4(E[un][4], E[un][5], E[un][6], E[un][7]);
+          } else if (row_in && y >= ylo && y < yhi && ocu >= MH_HALO && ocu < MH_HALO + MH_CI && Xu < w) {
+            uint2* o = dst + (size_t)y * w + Xu;
+            o[0] = make_uint2(E[un][0], E[un][1]); o[total] = make_uint2(E[un][2], E[un][3]); o[2 * total] = make_uint2(E[un][4], E[un][5]);
+          }
         }
       }
       stamp(2);
@@ -1199,8 +1227,18 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
     // re-does 8 halo rows plus 6 steps of pipeline fill
     const int mbands = std::max(1, std::min((h + 31) / 32, 3 * ctx->num_cu / std::max(1, planes * mstrips)));
     if (half) {
+      // strips of 64 NU columns (56 / 120 interior).  NU = 2 (round 5, VERDICT r4 item 8: two independent units of work per wave between
+      // barriers, half the barriers and halo columns per pixel - at two workgroups per CU instead of four, 66.5 KB of rings each) is
+      // bit-identical and 8.7 % SLOWER on the stage (0.375 against 0.345 ms per 12 planes of 720p, profiles/r05_fs_nu_ab.txt): four
+      // resident workgroups per CU interleave better than one wave does with itself.  Kept as a dev-library switch (SS4K_MH_NU=2).
+      int mh_nu = 1;
+#ifdef SS4K_DEV
+      if (const char* e = std::getenv("SS4K_MH_NU")) mh_nu = std::atoi(e);
+#endif
+      const int NUr = (mh_nu != 2 || w <= MhGeo<1>::CI) ? 1 : 2;
+      const int MH_CI = NUr == 2 ? MhGeo<2>::CI : MhGeo<1>::CI, MH_LDS = NUr == 2 ? MhGeo<2>::LDS : MhGeo<1>::LDS;
       const int hs = (w + MH_CI - 1) / MH_CI;
-      int hb = std::max(1, std::min((h + 31) / 32, 4 * ctx->num_cu / std::max(1, planes * hs)));   // one round at four per CU
+      int hb = std::max(1, std::min((h + 31) / 32, (4 / NUr) * ctx->num_cu / std::max(1, planes * hs)));   // one round at four (two) per CU
 #ifdef SS4K_DEV
       if (const char* e = std::getenv("SS4K_MH_BANDS")) hb = std::max(1, std::atoi(e));
 #endif
@@ -1210,9 +1248,10 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
         static unsigned long long* dbuf = nullptr;
         if (!dbuf) SS4K_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), 1024 * 4 * 8 * 8));
         SS4K_HIP(hipMemsetAsync(dbuf, 0, 1024 * 4 * 8 * 8, st));
-        const void* fs = reinterpret_cast<const void*>(&k_fs_maps4_h<true>);
+        auto kst = NUr == 2 ? &k_fs_maps4_h<true, 2> : &k_fs_maps4_h<true, 1>;
+        const void* fs = reinterpret_cast<const void*>(kst);
         if (ctx->lds_attr_set.insert(fs).second) SS4K_HIP(hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, MH_LDS));
-        hipLaunchKernelGGL(k_fs_maps4_h<true>, dim3((unsigned)(planes * hb * hs)), block, MH_LDS, st, reinterpret_cast<const uint2*>(cur),
+        hipLaunchKernelGGL(kst, dim3((unsigned)(planes * hb * hs)), block, MH_LDS, st, reinterpret_cast<const uint2*>(cur),
                            reinterpret_cast<uint2*>(nxt), mw, planes, h, w, hb, dbuf);
         SS4K_HIP(hipStreamSynchronize(st));
         std::vector<unsigned long long> hbuf(1024 * 4 * 8);
@@ -1231,9 +1270,10 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
       } else
 #endif
       {
-        const void* fn = reinterpret_cast<const void*>(&k_fs_maps4_h<false>);
+        auto kfn = NUr == 2 ? &k_fs_maps4_h<false, 2> : &k_fs_maps4_h<false, 1>;
+        const void* fn = reinterpret_cast<const void*>(kfn);
         if (ctx->lds_attr_set.insert(fn).second) SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MH_LDS));
-        hipLaunchKernelGGL(k_fs_maps4_h<false>, dim3((unsigned)(planes * hb * hs)), block, MH_LDS, st, reinterpret_cast<const uint2*>(cur),
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(planes * hb * hs)), block, MH_LDS, st, reinterpret_cast<const uint2*>(cur),
                            reinterpret_cast<uint2*>(nxt), mw, planes, h, w, hb, nullptr);
       }
     } else {
