@@ -297,6 +297,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the short secondary-workload measurements")
+    ap.add_argument("--no-by-kernel", action="store_true", help="skip the one-chain per-kernel pass of the roofline record (a second model: keeps a profiler trace to the headline job)")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks as child processes even for --gpus 1 (exercises the parent / child relay; with "
                          "SS4K_FORCE_GROUP=1 the single rank also creates its RCCL group and broadcasts the weights through it)")
@@ -392,7 +393,7 @@ def main():
                                   "concurrent_launches": rl["concurrent_launches"],
                                   "launches_per_frame_chain": LAUNCHES_PER_FRAME,
                                   "kernel_time_share_of_step": rl["conv_ms_per_step"] / (1000.0 * elapsed / args.steps)}
-            if args.workload == "rrdbnet" and world == 1:
+            if args.workload == "rrdbnet" and world == 1 and not args.no_by_kernel:
                 # per kernel build, from a ONE-CHAIN run of the same job (SS4K_MODEL_ONE_CHAIN: with two launch chains in flight a launch's
                 # duration includes the time it shares the chip with the other chain's launch - nobody should have to divide by 1.9)
                 try:

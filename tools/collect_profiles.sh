@@ -7,7 +7,7 @@ TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG; mkdir -p $O
-B="python3 bench.py --no-cpu-baseline --no-also"
+B="python3 bench.py --no-cpu-baseline --no-also --no-by-kernel"
 # 1. headline: per-kernel stats + the bench line printed under the profiler + how many conv launches are in flight
 #    (frame lanes: two concurrent launch chains; the choice is measured by the library over its first calls)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/st -- $B --steps 8 --warmup 6 > $O/bench_under_rocprof.log 2>&1
@@ -15,6 +15,14 @@ cp $(find $O/st -name "*kernel_stats.csv" | head -1) $O/${TAG}_rrdbnet_x2_720p_b
 grep '^{' $O/bench_under_rocprof.log | tail -1 > $O/${TAG}_bench_line_under_rocprof.json
 python3 tools/trace_overlap.py $O/st 0.5 > $O/${TAG}_rrdbnet_lanes_overlap.txt
 rm -rf $O/st
+# 1b. the same job as ONE launch chain (SS4K_LANES=1, read when a model is built): every launch alone on the chip, so that a kernel's
+#     average duration is its own (with two chains it includes the time it shares the chip with the other chain's launch)
+export SS4K_LANES=1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/st1 -- $B --steps 8 --warmup 6 > $O/bench_one_chain_under_rocprof.log 2>&1
+cp $(find $O/st1 -name "*kernel_stats.csv" | head -1) $O/${TAG}_rrdbnet_x2_720p_batch4_one_chain_kernel_stats.csv
+grep '^{' $O/bench_one_chain_under_rocprof.log | tail -1 > $O/${TAG}_bench_line_one_chain_under_rocprof.json
+rm -rf $O/st1
+unset SS4K_LANES
 # the counter passes serialise kernels: two chains are forced (SS4K_LANES=2) so that every launch carries 2 frames
 export SS4K_LANES=2
 # 2. headline: fabric traffic of the conv launches (separate passes)
@@ -41,11 +49,8 @@ unset SS4K_LANES
 # 3c. working set against the Infinity Cache, WITH frame lanes: 4 frames at once (default) against two passes of 2 frames
 #     (dev library switch SS4K_SUBBATCH=2; each pass still runs as two launch chains of one frame)
 SS4K_LIB=$PWD/sharkshark-4k_amd/libss4k_hip_dev.so python3 tools/env_ab.py "SS4K_LANES=2,SS4K_SUBBATCH=0;SS4K_LANES=2,SS4K_SUBBATCH=2" 4 3 > $O/${TAG}_subbatch_ab_with_lanes.txt 2>&1
-# 3d. 1-frame jobs: one launch per layer against the chain kernel (SS4K_MODEL_CHAIN = 128), and the chain's stall statistics
-python3 tools/n1_ab.py 1 3 0,128 2>&1 | grep "^round" > $O/${TAG}_n1_chain_ab.txt
-SS4K_LIB=$PWD/sharkshark-4k_amd/libss4k_hip_dev.so python3 tools/n1_ab.py 1 1 144:SS4K_CHAIN_ABL=8 2>&1 | grep "chain\]" | tail -1 >> $O/${TAG}_n1_chain_ab.txt
 # 4. the other workloads: per-kernel stats
-for wl in fsrcnn pipeline srvgg rrdbnet_x4; do
+for wl in fsrcnn fsrcnn_f16 pipeline srvgg rrdbnet_x4; do
   extra=""; [ $wl = rrdbnet_x4 ] && extra="--batch 1"
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/st -- python3 bench.py --workload $wl --steps 8 --warmup 6 --no-cpu-baseline --no-also --no-roofline $extra > $O/bench_$wl.log 2>&1
   cp $(find $O/st -name "*kernel_stats.csv" | head -1) $O/${TAG}_${wl}_kernel_stats.csv
