@@ -21,10 +21,7 @@ for shape in ((12, 1, 720, 1280), (3, 1, 150, 333)):
 fs32 = factory.build_model_fsrcnn(ctx, factor=2, weights=W.fsrcnn_table(seed=2))
 for shape in ((12, 1, 720, 1280), (3, 1, 97, 130)):
     jobs.append((f"fsrcnn fp32-grade (split MFMA head) {shape}", fs32, torch.rand(*shape, generator=g).cuda()))
-rr = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=4, flags=_capi.DEV_MODEL_CHAIN),
-                 W.flatten(W.rrdbnet_table(5, scale=2, num_block=4), W.rrdbnet_keys(4)))
-jobs.append(("rrdbnet chain (1, 3, 360, 500)", rr, torch.rand(1, 3, 360, 500, generator=g).cuda()))
-# round 4: the default route (fused pairs + wide kernel + register-stationary conv5), two launch chains and one, ragged and full size
+# the default route (fused pairs with the ring table, 16x16x32 tile for conv5 / trunk / conv_hr), two launch chains and one, ragged and full size
 rd = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, num_block=6), W.flatten(W.rrdbnet_table(6, scale=2, num_block=6), W.rrdbnet_keys(6)))
 for shape in ((4, 3, 720, 1280), (1, 3, 720, 1280), (3, 3, 250, 330), (2, 3, 70, 66)):
     jobs.append((f"rrdbnet fused pairs {shape}", rd, torch.rand(*shape, generator=g).cuda()))
