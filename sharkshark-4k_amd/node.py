@@ -129,11 +129,15 @@ class UpscalerNode:
         for svc in self.services:
             if svc.proc.is_alive():
                 try:
-                    codes.append(svc.stop())
+                    svc.stop()
                 except Exception:  # noqa: BLE001 - a worker that dies between the check and the command is already stopped
-                    codes.append(svc.proc.exitcode)
-            else:
-                codes.append(svc.proc.exitcode)
+                    pass
+                if svc.proc.is_alive():
+                    # it did not take the exit command (e.g. still inside a collective whose peer died during start-up): end exactly
+                    # this child - the process object this node started
+                    svc.proc.kill()
+                    svc.proc.join(timeout=15)
+            codes.append(svc.proc.exitcode)
         return codes
 
     def __enter__(self):
