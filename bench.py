@@ -307,6 +307,12 @@ def main():
         # no launcher: this process becomes the parent of N fresh ranks and never touches a GPU itself
         sys.exit(spawn_ranks(args.gpus, [a for a in sys.argv[1:] if a != "--spawn"]))
 
+    # stdout carries ONE JSON line: everything else this process, its libraries or its child processes (the service worker of the `also` leg)
+    # might print to file descriptor 1 goes to stderr; the line itself is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank, world_env, local = sharding.init_distributed()
     assert world_env == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch one rank per GPU"
     assert torch.cuda.is_available(), f"rank {rank}: bench.py needs a GPU (no CPU fallback exists)"
@@ -509,7 +515,8 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

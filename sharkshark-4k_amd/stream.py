@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import math
 import queue
+import sys
 import time
 from typing import Callable, Dict, List, Optional, Sequence
 
@@ -108,7 +109,7 @@ class StreamDispatcher:
             except queue.Full:
                 self._dropped.add(step)
                 self.dropped_total += 1
-                print("StreamDispatcher: upscaler queue full, job skipped")
+                print("StreamDispatcher: upscaler queue full, job skipped", file=sys.stderr)
         return queued
 
     def _emit_ready(self, force: bool = False):
@@ -136,7 +137,7 @@ class StreamDispatcher:
                     for g in gone:
                         self._owner.pop(g, None)
                     self._dropped.difference_update(range(self.next_emit, nxt))
-                    print(f"StreamDispatcher: step(s) {gone} never came back, skipped")
+                    print(f"StreamDispatcher: step(s) {gone} never came back, skipped", file=sys.stderr)
                     self.next_emit = nxt
                     self._stalled_since = None
                 else:
@@ -165,7 +166,7 @@ class StreamDispatcher:
                         # its step was already passed (declared lost after lost_after_s, or skipped): emitting it now would
                         # put a stale frame behind newer ones and rewind next_emit, so it is counted and dropped
                         self.late_total += 1
-                        print(f"StreamDispatcher: result of step {e.step} arrived late (stream is at {self.next_emit}), discarded")
+                        print(f"StreamDispatcher: result of step {e.step} arrived late (stream is at {self.next_emit}), discarded", file=sys.stderr)
                         continue
                     self._pending[e.step] = e
                     self._owner.pop(e.step, None)

@@ -28,6 +28,7 @@ import abc
 import collections
 import os
 import queue
+import sys
 import signal
 import time
 import traceback
@@ -47,7 +48,7 @@ class ProcessDeadException(Exception):
 
 def _interrupt_process_group(ex: BaseException) -> None:
     traceback.print_exc()
-    print(ex)
+    print(ex, file=sys.stderr)
     os.killpg(os.getpgid(os.getpid()), signal.SIGINT)
 
 
@@ -105,7 +106,7 @@ class BaseService(abc.ABC):
         try:
             self.result_queue.put_nowait(entry)
         except queue.Full:
-            print(f"{type(self).__name__}: result queue is full, result of this job dropped (consumer too slow?)")
+            print(f"{type(self).__name__}: result queue is full, result of this job dropped (consumer too slow?)", file=sys.stderr)
 
     def proc_main(self) -> None:
         try:
@@ -133,7 +134,7 @@ class BaseService(abc.ABC):
                 raise
             _interrupt_process_group(ex)
             return
-        print(f"{type(self).__name__}: worker leaves on request")
+        print(f"{type(self).__name__}: worker leaves on request", file=sys.stderr)
         os.kill(os.getpid(), signal.SIGTERM)  # daemon threads of the runtime must not keep it alive
 
     # ---------------------------------------------------------------- client side
