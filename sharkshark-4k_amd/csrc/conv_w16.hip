@@ -1,7 +1,7 @@
 // conv3x3_w16_kernel: ONE 3x3 layer with 64 output channels per workgroup - conv_dense.hip's single-layer kernel (same tile, same LDS
 // budget, same DMA pipeline, two workgroups per CU) on v_mfma_f32_16x16x32_f16 instead of v_mfma_f32_32x32x16_f16.
 //
-// Why.  The part runs these layers at its 1400 W cap (profiles/r04_headline_power_clock.txt: 1.82 of 2.4 GHz through the whole timed
+// Why.  The part runs these layers at its 1400 W cap (profiles/earlier/r04/r04_headline_power_clock.txt: 1.82 of 2.4 GHz through the whole timed
 // loop), and at equal cycles per FLOP the 16x16x32 shape costs less energy: 1.12-1.14 x the FLOP/s under the cap with operands
 // re-read from LDS at this loop's reuse ratios (tools/micro/mfma_shapes.hip).  conv_rs.hip has used the shape since round 2, paying for
 // its K = 32 with 64-byte-per-pixel halo stages (one tap x TWO planes per MFMA) and one workgroup per CU.  Here K = 32 is

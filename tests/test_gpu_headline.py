@@ -171,7 +171,7 @@ def test_config3_bsvd_rrdbnet_fp32_vs_oracle_small(ctx, rate, out_shape, in_hw):
             assert_close(up.read_tap(which), w, what=f"configs[3] fp32 job {job} tap {key}")
 
 
-# measured (profiles/r03_parity_measured.json) + 1 LSB / - 2 dB
+# measured (profiles/r05_parity_measured.json) + 1 LSB / - 2 dB
 C3_PSNR_DB, C3_MAX_LSB = 55.9, 2   # measured 57.93 dB, 1 LSB (both jobs)
 
 
@@ -270,7 +270,7 @@ def test_job_whose_plane_exceeds_4gb_is_routed_as_a_whole(ctx):
     torch.cuda.empty_cache()
 
 
-C4_PSNR_DB, C4_MAX_LSB = 55.5, 2   # measured 57.55 dB, 1 LSB (profiles/r03_parity_measured.json)
+C4_PSNR_DB, C4_MAX_LSB = 55.5, 2   # measured 57.55 dB, 1 LSB (profiles/r05_parity_measured.json)
 
 
 # ------------------------------------------------------------------------------ (f) fp16 storage at realistic activation ranges

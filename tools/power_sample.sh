@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX: sample sclk and socket power with rocm-smi while a workload runs (is the part at its power cap? at what clock?).
-# usage: bash tools/power_sample.sh headline            -> profiles/r04_headline_power_clock.txt style output on stdout
+# usage: bash tools/power_sample.sh headline            -> profiles/earlier/r04/r04_headline_power_clock.txt style output on stdout
 #        bash tools/power_sample.sh srvgg <model flags> -> the SRVGG x4 720p network in a loop (tools/power_loop.py), e.g. 0 and 32768 (NO_W16)
 set -u
 cd "$GRAFT_REPO_ROOT"
