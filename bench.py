@@ -313,7 +313,13 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    rank, world_env, local = sharding.init_distributed()
+    # SS4K_BENCH_REHEARSE_ON_ONE_GPU=1 (tests only): the N ranks of a multi-GPU run all use cuda:0 and meet over gloo (RCCL refuses two
+    # ranks on one device) - rehearses every line of the N > 1 path (group, rank-0 load, broadcast, barrier, max over ranks) on a one-GPU
+    # box; the line's config says so and such a number is never a result
+    rehearse = os.environ.get("SS4K_BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    rank, world_env, local = sharding.init_distributed("gloo" if rehearse else None)
+    if rehearse:
+        local = 0
     assert world_env == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch one rank per GPU"
     assert torch.cuda.is_available(), f"rank {rank}: bench.py needs a GPU (no CPU fallback exists)"
     assert local < torch.cuda.device_count(), f"rank {rank}: no GPU {local} on this node ({torch.cuda.device_count()} visible)"
@@ -331,7 +337,8 @@ def main():
 
     # a step = one job through the service's frame-in/frame-out call; results are ordered on the job set's stream (wait=False, what the
     # worker loop does) and the timed region ends with a device-wide synchronise
-    elapsed = run_timed(lambda: svc.upscale(frames, wait=False), args.steps, args.warmup, world, torch.cuda.synchronize, device)
+    elapsed = run_timed(lambda: svc.upscale(frames, wait=False), args.steps, args.warmup, world, torch.cuda.synchronize,
+                        torch.device("cpu") if rehearse else device)
     total_frames = args.batch * args.steps * world
     fps = total_frames / elapsed
 
@@ -344,7 +351,8 @@ def main():
         "config": {"workload": WORKLOADS[args.workload], "frames_per_step_per_gpu": args.batch,
                    "in": [in_shape[0], in_shape[1], 3], "out": [oh, ow, 3], "io": "uint8 NHWC resident in HBM",
                    "path": "HipUpscalerService.upscale -> ss4k_upscale_frames (every rank is a service worker: proc_init joins the group, rank 0 loads, RCCL broadcast)",
-                   "parallelism": (f"frame-sharded x{world}, weights broadcast once from rank 0 (RCCL)" if torch.distributed.is_initialized()
+                   "parallelism": (f"REHEARSAL: {world} ranks sharing cuda:0 over gloo (SS4K_BENCH_REHEARSE_ON_ONE_GPU) - not a result" if rehearse else
+                                   f"frame-sharded x{world}, weights broadcast once from rank 0 (RCCL)" if torch.distributed.is_initialized()
                                    else "one GPU, no process group (frames shard one-per-GPU at N > 1; the only collective is the weight broadcast)"),
                    "fps_per_gpu": fps / world, "net_tflops_per_gpu": flops_per_frame * fps / world / 1e12},
     }

@@ -49,3 +49,18 @@ def test_bench_spawned_rank_with_rccl_group():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 24.0 and "RCCL" in line["config"]["parallelism"], line
+
+
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher and SS4K_BENCH_REHEARSE_ON_ONE_GPU=1: the parent starts two ranks, both use cuda:0 and meet
+    over gloo.  Every line of the N > 1 path runs: the group, rank 0 generating the weights, the broadcast into rank 1's service worker,
+    the barrier-bracketed timed region, the max over ranks, rank 0's one JSON line relayed by the parent."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], cwd=ROOT, env=_env(SS4K_BENCH_REHEARSE_ON_ONE_GPU="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                                     # stdout is the one JSON line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "REHEARSAL" in line["config"]["parallelism"], line
+    assert line["value"] > 24.0 and abs(line["value"] - 2 * line["config"]["fps_per_gpu"]) < 1e-6   # whole-job value = all ranks' frames / max time
+    assert "roofline" in line and "also" not in line and "cpu_baseline" not in line                  # N > 1: the headline record only
