@@ -305,7 +305,11 @@ class HipUpscalerService(BaseUpscalerService):
             raise Exception(frames.shape)
         assert frames.shape[-1] == 3
         if not self._overlap_active():
-            return self._run(0, frames)
+            out = self._run(0, frames)
+            if frames.is_cuda and hasattr(self, "_inflight"):   # (same hold on the input as below: see _retire)
+                self._retire()
+                self._inflight.append((torch.cuda.current_stream(self.torch_device).record_event(), frames))
+            return out
         k = 0
         if frames.shape[0] <= self.overlap_max_frames:   # consecutive one-frame jobs alternate; a multi-frame job overlaps with itself (frame lanes) on set 0
             if not self._streams_checked:
