@@ -10,6 +10,8 @@
 //   W1D: F(2,3) along x, direct along y.  One wave per SIMD, a wave owns 32 couts x 4 rows x 32 column pairs, 4 positions x 4 rows = 256
 //        accumulator registers.  Per K-chunk and wave: 12 ds_read_b128 of U, per input row (6) 4 ds_read_b128 + 16 v_pk ops of transform,
 //        48 MFMA 32x32x16.  1.5 x fewer matrix ops; 0.75 LDS reads + 2 packed VALU ops per MFMA.
+//   W1D2: the same with TWO waves per SIMD: a wave owns 32 couts x 2 rows x 32 column pairs (4 positions x 2 rows = 128 accumulator registers),
+//        two workgroups per CU; per K-chunk and wave 12 reads of U + 4 input rows x (4 reads + 16 v_pk ops), 24 MFMAs (1.17 reads per MFMA).
 // Both: LDS-DMA of the next chunk's halo tile + U through the MFMA stream (L2-resident window), one barrier per chunk, and every NCH chunks
 // the inverse transform + LeakyReLU + fp16 pack + non-temporal stores of the tile.
 // Reported: direct-equivalent TFLOP/s = output pixels x 64 couts x 2 x 9 x Cin / time (what conv_roofline / ss4k_bench_conv report for the
@@ -31,39 +33,41 @@ __device__ __forceinline__ void dma16(const void* g, unsigned lds) {
 __device__ __forceinline__ f16x8 ldsv(const char* p) { return *reinterpret_cast<const f16x8*>(p); }
 
 constexpr int LDS_STAGE = 64 * 1024;   // one stage = a chunk's halo tile + its U (W2D: 10.9 + 32 KB, W1D: 21 + 24.6 KB); two stages
+constexpr int LDS_STAGE2 = 38 * 1024;  // W1D2 (two workgroups per CU): 4 + 2 rows x 66 columns = 12.7 KB + U 24.6 KB
 
-// MODE 0 = W2D, 1 = W1D.  NCH = K-chunks per tile (4: a 64 -> 64 layer, 12: conv5 of an RDB)
+// MODE 0 = W2D, 1 = W1D, 2 = W1D2.  NCH = K-chunks per tile (4: a 64 -> 64 layer, 12: conv5 of an RDB)
 template <int MODE, int NCH>
-__global__ __launch_bounds__(256, 1) void k(const uint4* __restrict__ seed, const char* __restrict__ buf, char* __restrict__ outp, int tiles) {
+__global__ __launch_bounds__(256, MODE == 2 ? 2 : 1) void k(const uint4* __restrict__ seed, const char* __restrict__ buf, char* __restrict__ outp, int tiles) {
   extern __shared__ char smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int i = threadIdx.x; i < 2 * LDS_STAGE / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = seed[i & 4095];
+  constexpr int STAGE = MODE == 2 ? LDS_STAGE2 : LDS_STAGE, ROWS = MODE == 2 ? 2 : 4, NACC = MODE == 2 ? 8 : 16;
+  for (int i = threadIdx.x; i < 2 * STAGE / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = seed[i & 4095];
   __syncthreads();
-  f32x16 acc[16];
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  for (int i = 0; i < NACC; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
   size_t pos = ((size_t)blockIdx.x * 4 + wave) * 1024;
   const size_t stride = (size_t)gridDim.x * 4 * 1024, span = (size_t)(2u << 20);
   char* myout = outp + ((size_t)blockIdx.x * 256 + threadIdx.x) * 512;
-  constexpr int NDMA = MODE == 0 ? 11 : 12;   // LDS-DMA wave-instructions (1 KB each) per wave and chunk: (halo tile + U) / 4 waves
+  constexpr int NDMA = MODE == 0 ? 11 : MODE == 1 ? 12 : 10;   // LDS-DMA wave-instructions (1 KB each) per wave and chunk: (halo tile + U) / 4 waves
   int c = 0;
   for (int t = 0; t < tiles; ++t) {
     for (int kc = 0; kc < NCH; ++kc, ++c) {
-      const unsigned stage = lds0 + (c & 1) * LDS_STAGE;
-      const char* rd = smem + ((c & 1) ^ 1) * LDS_STAGE;
-      const char* rdU = rd + 24 * 1024 + (wave & 1) * 16384 + lane * 16;   // this wave's cout half of U
+      const unsigned stage = lds0 + (c & 1) * STAGE;
+      const char* rd = smem + ((c & 1) ^ 1) * STAGE;
+      const char* rdU = rd + (MODE == 2 ? 13 : 24) * 1024 + (wave & 1) * (MODE == 2 ? 12288 : 16384) + lane * 16;   // this wave's cout half of U
       const char* rdD = rd + (wave >> 1) * 4096 + lane * 16;                 // this wave's tiles / rows
       int nd = 0;
       auto dma = [&]() {
         if (nd < NDMA) {
           __builtin_amdgcn_sched_barrier(0);
-          dma16(buf + (pos & (span - 1)) + lane * 16, stage + ((wave * NDMA + nd) * 1024) % LDS_STAGE);
+          dma16(buf + (pos & (span - 1)) + lane * 16, stage + ((wave * NDMA + nd) * 1024) % STAGE);
           pos += stride; ++nd;
           __builtin_amdgcn_sched_barrier(0);
         }
       };
-      if (MODE == 0) {
+      if constexpr (MODE == 0) {
         // input transform in registers: the lane's tile (4x4 pixels) x 8 channels -> 16 positions x 8 channels (B operand of position p)
         f16x8 d[16];
 #pragma unroll
@@ -95,17 +99,17 @@ __global__ __launch_bounds__(256, 1) void k(const uint4* __restrict__ seed, cons
 #pragma unroll
         for (int i = 0; i < 12; ++i) u[i] = ldsv(rdU + i * 1024);
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {   // input rows of the wave's 4 output rows
+        for (int r = 0; r < ROWS + 2; ++r) {   // input rows of the wave's output rows
           const f16x8 d0 = ldsv(rdD + (r * 4 + 0) * 1024), d1 = ldsv(rdD + (r * 4 + 1) * 1024), d2 = ldsv(rdD + (r * 4 + 2) * 1024),
                       d3 = ldsv(rdD + (r * 4 + 3) * 1024);
           f16x8 v[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
 #pragma unroll
           for (int dy = 0; dy < 3; ++dy) {
             const int orow = r - dy;
-            if (orow < 0 || orow > 3) continue;
+            if (orow < 0 || orow >= ROWS) continue;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-              acc[p * 4 + orow] = __builtin_amdgcn_mfma_f32_32x32x16_f16(u[p * 3 + dy], v[p], acc[p * 4 + orow], 0, 0, 0);
+              acc[p * ROWS + orow] = __builtin_amdgcn_mfma_f32_32x32x16_f16(u[p * 3 + dy], v[p], acc[p * ROWS + orow], 0, 0, 0);
               if (p == 1 || p == 3) dma();
             }
           }
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void k(const uint4* __restrict__ seed, cons
       __syncthreads();
     }
     // epilogue of the tile: inverse transform, LeakyReLU, fp16, non-temporal stores
-    if (MODE == 0) {
+    if constexpr (MODE == 0) {
       // out (2x2) = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]: 16 positions -> 4 outputs per (cout, tile)
       f32x16 o[4];
 #pragma unroll
@@ -139,12 +143,12 @@ __global__ __launch_bounds__(256, 1) void k(const uint4* __restrict__ seed, cons
       }
     } else {
 #pragma unroll
-      for (int row = 0; row < 4; ++row) {
+      for (int row = 0; row < ROWS; ++row) {
         f32x16 o0, o1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          o0[e] = acc[0 * 4 + row][e] + acc[1 * 4 + row][e] + acc[2 * 4 + row][e];
-          o1[e] = acc[1 * 4 + row][e] - acc[2 * 4 + row][e] - acc[3 * 4 + row][e];
+          o0[e] = acc[0 * ROWS + row][e] + acc[1 * ROWS + row][e] + acc[2 * ROWS + row][e];
+          o1[e] = acc[1 * ROWS + row][e] - acc[2 * ROWS + row][e] - acc[3 * ROWS + row][e];
         }
         uint4 st[4]; __half* hh = reinterpret_cast<__half*>(st);
 #pragma unroll
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256, 1) void k(const uint4* __restrict__ seed, cons
       }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    for (int i = 0; i < NACC; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
   }
 }
 
@@ -168,9 +172,10 @@ __global__ void k_fill(uint32_t* p, size_t n) {
 
 template <int MODE, int NCH> void run(const uint4* seed, const char* buf, char* out, const char* what, double seconds) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const int grid = 256, tiles = MODE == 0 ? 3000 / NCH * 4 : 1000 / NCH * 4;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_STAGE);
-  auto launch = [&]() { hipLaunchKernelGGL((k<MODE, NCH>), dim3(grid), dim3(256), 2 * LDS_STAGE, 0, seed, buf, out, tiles); };
+  const int grid = MODE == 2 ? 512 : 256, tiles = MODE == 0 ? 3000 / NCH * 4 : 1000 / NCH * 4;
+  const int lds = 2 * (MODE == 2 ? LDS_STAGE2 : LDS_STAGE);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  auto launch = [&]() { hipLaunchKernelGGL((k<MODE, NCH>), dim3(grid), dim3(256), lds, 0, seed, buf, out, tiles); };
   launch(); hipDeviceSynchronize();
   // run for `seconds` so that the chip settles at its power-capped clock, time the last launches
   int n = 0; float ms = 0, total = 0;
@@ -182,9 +187,9 @@ template <int MODE, int NCH> void run(const uint4* seed, const char* buf, char* 
   }
   ms /= 4;
   // per wave and tile: W2D 32 couts x 32 tiles x 4 px; W1D 32 couts x 4 rows x 64 px
-  const double px_cout = (MODE == 0 ? 32.0 * 128 : 32.0 * 256) * 4 /*waves*/ * grid * tiles;
+  const double px_cout = (MODE == 0 ? 32.0 * 128 : MODE == 1 ? 32.0 * 256 : 32.0 * 128) * 4 /*waves*/ * grid * tiles;
   const double direct_flops = px_cout * 2 * 9 * 16.0 * NCH;
-  const double mfma_flops = (MODE == 0 ? 16.0 : 48.0) * NCH * 32768.0 * 4 * grid * tiles;
+  const double mfma_flops = (MODE == 0 ? 16.0 : MODE == 1 ? 48.0 : 24.0) * NCH * 32768.0 * 4 * grid * tiles;
   printf("%-78s %7.0f direct-equivalent TFLOP/s  (matrix pipe: %5.0f TFLOP/s issued, %.2f ms per launch)\n", what, direct_flops / ms / 1e9, mfma_flops / ms / 1e9, ms);
   fflush(stdout);
 }
@@ -196,12 +201,14 @@ int main(int argc, char** argv) {
   for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (s & 0x83FF83FFu) | 0x38003800u; }
   uint4* seed; hipMalloc(&seed, h.size() * 4); hipMemcpy(seed, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   char* big; const size_t BIG = 64ull << 20; hipMalloc(&big, BIG); hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, reinterpret_cast<uint32_t*>(big), BIG / 4); hipDeviceSynchronize();
-  char* out; hipMalloc(&out, 256ull * 256 * 512);
+  char* out; hipMalloc(&out, 512ull * 256 * 512);
   for (int rep = 0; rep < 2; ++rep) {
     run<0, 4>(seed, big, out, "W2D F(2x2,3x3), 64 -> 64 (4 K-chunks per tile), register input transform", seconds);
     run<0, 12>(seed, big, out, "W2D F(2x2,3x3), 192 -> 64 (12 K-chunks per tile: conv5)", seconds);
     run<1, 4>(seed, big, out, "W1D F(2,3) along x, 64 -> 64 (4 K-chunks per tile)", seconds);
     run<1, 12>(seed, big, out, "W1D F(2,3) along x, 192 -> 64 (12 K-chunks per tile: conv5)", seconds);
+    run<2, 4>(seed, big, out, "W1D2 F(2,3) along x, two waves per SIMD, 64 -> 64", seconds);
+    run<2, 12>(seed, big, out, "W1D2 F(2,3) along x, two waves per SIMD, 192 -> 64 (conv5)", seconds);
   }
   return 0;
 }
