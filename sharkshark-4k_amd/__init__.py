@@ -5,4 +5,18 @@ Python host code (this package) mirrors the reference's service interface
 library (``csrc/`` -> ``libss4k_hip.so``, declared in ``include/ss4k.h``) for all arithmetic.
 There is no CPU fallback: constructing a context without the library or a GPU raises.
 """
+import os as _os
+
+# Kernel arguments in device memory (a HIP runtime setting, read when the runtime initialises - i.e. at the process's first HIP call, which
+# comes after this import): a network forward is 213-351 launches with ~ 300-byte argument blocks, and fetching them from host memory costs
+# launch latency that the launch chains expose.  Headline job, one box, three interleaved processes each: 123.9 -> 125.0 frames/s (+ 0.9 %,
+# profiles/r05_kernarg_ab.txt).  setdefault: an integrator's own setting wins; service workers inherit it through the environment.
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# Eight hardware queues per process instead of HIP's four.  A service worker uses up to five streams that should run side by side (the
+# current stream, three job-set streams, the context's frame-lane stream); streams that share a hardware queue run in order, whatever the
+# program says (profiles/NOTES_r05.md 3).  Same A/B form: headline 124.9-125.6 either way; the SRVGG job of a process that had used many
+# streams lost its second launch chain in two of three runs at four queues (402 against 423 frames/s) and never at eight
+# (profiles/r05_hwq_ab.txt).  The job sets still check their streams once (hip_upscaler._check_streams).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 __version__ = "0.1.0"
