@@ -215,40 +215,47 @@ class HipUpscalerService(BaseUpscalerService):
 
     def _check_streams(self, frames: torch.Tensor, tries: int = 6) -> None:
         """One-off, at the first small job: do the job sets' streams really run side by side?  HIP serves a process's streams from a few
-        hardware queues (four by default); two streams that share one are executed in order, whatever the program says - seen on a process
-        that had created many streams before (profiles/r05_n1_probe_streams.txt: 107 instead of 122 frames/s, silently).  So: time two jobs
-        on sets 0 and 1 with both on stream 0, then on their own streams; if the second form is not faster, give the later set another stream
-        and try again.  Blocks the host for a few jobs' time, once per service."""
+        hardware queues; two streams that share one are executed in order, whatever the program says - seen on a process that had created
+        many streams before (profiles/r05_n1_probe_streams.txt: 107 instead of 122 frames/s, silently).  So, for every pair of sets: time a
+        one-frame job of each with both on one stream, then on their own streams; if the second form is not faster, the later set takes
+        another stream and is checked again.  Blocks the host for a few dozen jobs' time, once per service."""
         self._streams_checked = True
         frames = frames[:1]   # (one-frame jobs gain 12-15 % from running side by side: a clear signal; multi-frame jobs gain nothing, measured)
         dev, cur = self.torch_device, torch.cuda.current_stream(self.torch_device)
         sets = [self._job_set(k) for k in range(self.overlap_sets)]
         ups = [self._get_upscaler(k) for k in range(self.overlap_sets)]
-        def timed(streams):
+
+        def run(which, streams):   # one job on each set of `which`, set which[i] on streams[i]: milliseconds on the current stream
             torch.cuda.synchronize(dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(cur)
             for st in set(streams):
                 st.wait_stream(cur)
-            for up, st in zip(ups, streams):
+            for idx, st in zip(which, streams):
                 with torch.cuda.stream(st):
-                    up(frames)
+                    ups[idx](frames)
             for st in set(streams):
                 cur.wait_stream(st)
             e1.record(cur)
             e1.synchronize()
             return e0.elapsed_time(e1)
-        timed([js["stream"] for js in sets])   # (first calls size workspaces and raise LDS limits)
-        serial = min(timed([sets[0]["stream"]] * len(sets)) for _ in range(2))
+
+        run(range(len(sets)), [js["stream"] for js in sets])   # (first calls size workspaces and raise LDS limits)
         for k in range(1, len(sets)):
-            for attempt in range(tries):
-                both = min(timed([sets[0]["stream"]] * k + [sets[k]["stream"]] + [sets[0]["stream"]] * (len(sets) - k - 1)) for _ in range(2))
-                if both < 0.96 * serial:
+            for _ in range(tries):
+                bad = None
+                for j in range(k):   # against EVERY earlier set: sets 1 and 2 must not share a queue either
+                    serial = min(run((j, k), [sets[j]["stream"]] * 2) for _ in range(2))
+                    both = min(run((j, k), [sets[j]["stream"], sets[k]["stream"]]) for _ in range(2))
+                    if not both < 0.96 * serial:
+                        bad = (j, both, serial)
+                        break
+                if bad is None:
                     break
-                log(f"job set {k}: its stream does not run beside set 0's ({both:.2f} ms against {serial:.2f} ms in order) - taking another stream")
+                log(f"job set {k}: its stream does not run beside set {bad[0]}'s ({bad[1]:.2f} ms against {bad[2]:.2f} ms in order) - taking another stream")
                 sets[k]["stream"] = torch.cuda.Stream(dev)
             else:
-                log(f"job set {k}: no stream found that overlaps with set 0's after {tries} tries; jobs will run in order")
+                log(f"job set {k}: no stream found that overlaps with the earlier sets' after {tries} tries; its jobs will run in order with one of them")
 
     def _get_upscaler(self, k: int = 0):
         from .. import _capi
