@@ -621,11 +621,12 @@ void Model::check_async_error(bool wait) {
 // Two chains win when a launch is short next to its fixed costs (launch boundary, prologue, the partly filled last round
 // of tiles): up to 4 frames of 720p per job here; they lose nothing-to-1 % on bigger jobs, and they rely on the two HIP
 // streams being served concurrently by the hardware queues.  So, unless forced by SS4K_LANES, the choice is MEASURED per
-// (n, h, w): calls 0-1 run two chains, calls 2-3 one, the second call of each pair is timed with events on the
-// caller's stream (no host synchronisation: the events are polled on later calls), and the faster mode is kept.
-// One step of a two-way measured choice for a job shape: returns the mode this call runs in - 2 ("the new way": two launch
-// chains / the chain kernel) on calls 0-1, 1 ("the plain way") on calls 2-3, the second call of each pair timed with events on
-// the caller's stream (no host synchronisation: the events are polled on later calls), then the faster one for good.
+// (n, h, w) over the shape's first six forwards, ALTERNATING: calls 0, 2, 4 run two chains, calls 1, 3, 5 one; calls 2-5 are
+// timed with events on the caller's stream (no host synchronisation: the events are polled on later calls) and the better
+// of each mode's two samples is compared.  Alternating matters: a service built a second ago starts on an idle chip whose
+// clock is still ramping, and "two chains first, one chain after" charged the ramp to the two chains (round 5: one bench leg
+// in a dozen then ran its whole job on one chain, 106-112 instead of 115-118 frames/s).
+// Returns the mode this call runs in: 2 = two launch chains, 1 = one.
 int Model::tune_step(std::map<std::tuple<int, int, int>, LaneTune>& tab, int n, int h, int w, hipStream_t st) {
   const auto key = std::make_tuple(n, h, w);
   auto it = tab.find(key);
@@ -636,24 +637,26 @@ int Model::tune_step(std::map<std::tuple<int, int, int>, LaneTune>& tab, int n, 
   LaneTune* t = &it->second;
   if (t->decided) return t->decided;
   const int k = t->calls++;
-  if (k < 4) {
-    if (k & 1) {   // second call of the pair: timed
-      auto& ev = t->ev[k >> 1];
+  if (k < 6) {
+    if (k >= 2) {   // timed
+      auto& ev = t->ev[k - 2];
       SS4K_HIP(hipEventCreate(&ev[0])); SS4K_HIP(hipEventCreate(&ev[1]));
       SS4K_HIP(hipEventRecord(ev[0], st));
       tune_timed = ev[1];
     }
-    return k < 2 ? 2 : 1;
+    return (k & 1) ? 1 : 2;
   }
-  if (hipEventQuery(t->ev[0][1]) == hipSuccess && hipEventQuery(t->ev[1][1]) == hipSuccess) {
-    float ms2 = 0, ms1 = 0;
+  bool done = true;
+  for (auto& pr : t->ev) done = done && hipEventQuery(pr[1]) == hipSuccess;
+  if (done) {
     // (a timed forward that threw left its end event unrecorded: no measurement, stay with the plain way)
-    const bool ok = hipEventElapsedTime(&ms2, t->ev[0][0], t->ev[0][1]) == hipSuccess &&
-                    hipEventElapsedTime(&ms1, t->ev[1][0], t->ev[1][1]) == hipSuccess && ms1 > 0.f && ms2 > 0.f;
+    float ms[4] = {0, 0, 0, 0};
+    bool ok = true;
+    for (int i = 0; i < 4; ++i) ok = ok && hipEventElapsedTime(&ms[i], t->ev[i][0], t->ev[i][1]) == hipSuccess && ms[i] > 0.f;
     if (!ok) (void)hipGetLastError();
-    // two chains unless one chain was CLEARLY faster: where both were measured carefully (RRDBNet / SRVGG / BSVD, 2-8 frames) two chains win by
-    // 4-10 % or lose by at most 1 %, so a single noisy sample should cost the latter, not the former (round 5: one bench leg in a dozen ran its
-    // whole job on one chain after a disturbed sample: 106 instead of 115 frames/s)
+    const float ms2 = std::min(ms[0], ms[2]), ms1 = std::min(ms[1], ms[3]);   // calls 2, 4: two chains; 3, 5: one
+    // two chains unless one chain was CLEARLY faster: where both were measured carefully (RRDBNet / SRVGG / BSVD, 2-8 frames) two chains win
+    // by 4-10 % or lose by at most 1 %, so a noisy pair of samples should cost the latter, not the former
     t->decided = !ok ? 1 : (ms1 < 0.97f * ms2 ? 1 : 2);
     t->ms[0] = ms2; t->ms[1] = ms1;
     for (auto& pr : t->ev) for (auto& e : pr) { (void)hipEventDestroy(e); e = nullptr; }

@@ -73,7 +73,7 @@ struct Model {
   float lane_grid_share = 1.f; // grid of a lane's launch as a share of the chip's workgroup slots (measured: 1.0 is best)
   int cur_lanes = 1, cur_n = 0;
   bool forked = false;
-  struct LaneTune { int calls = 0, decided = 0; hipEvent_t ev[2][2] = {}; float ms[2] = {}; };
+  struct LaneTune { int calls = 0, decided = 0; hipEvent_t ev[4][2] = {}; float ms[2] = {}; };
   // per (n, h, w); an image server fed arbitrary sizes must not grow this without bound: past LANE_TUNE_MAX shapes a new
   // shape runs one chain and is not measured
   static constexpr size_t LANE_TUNE_MAX = 64;
