@@ -328,7 +328,7 @@ def test_frame_lanes_bit_identical(ctx, monkeypatch, kind, n):
         else:
             monkeypatch.setenv("SS4K_LANES", mode)
         m = build()
-        ys = [m(x).clone() for _ in range(7)]   # the measured choice switches modes over its first calls
+        ys = [m(x).clone() for _ in range(9)]   # the measured choice alternates modes over its first six calls, then settles
         torch.cuda.synchronize()
         for y in ys[1:]:
             assert torch.equal(ys[0], y), f"{kind}: lanes mode {mode}: output changed between calls"
