@@ -472,7 +472,11 @@ def main():
             if name == "rrdbnet_n1":
                 also[name]["job_sets"] = len(svc2._sets)
             elif not wl.startswith("fsrcnn"):
+                # (one-frame legs: on ONE job set - with consecutive jobs alternating over the sets a context's conv sections share the chip with
+                # the other sets' jobs, and the per-context rate is not the chip's)
+                keep_overlap, svc2.overlap_jobs = svc2.overlap_jobs, svc2.overlap_jobs and nb > svc2.overlap_max_frames
                 rl = conv_roofline(svc2, fr2, psteps=2)
+                svc2.overlap_jobs = keep_overlap
                 if rl is not None:
                     also[name]["conv_tflops"] = rl["achieved"]; also[name]["conv_frac_of_peak"] = rl["frac"]
                     also[name]["conv_launches_per_step"] = rl["launches_per_step"]
