@@ -224,7 +224,13 @@ class HipUpscalerService(BaseUpscalerService):
         if key not in self._small:
             if len(self._small) > 256:   # an image server fed arbitrary sizes must not grow this without bound
                 self._small.clear()
-            self._small[key] = self.model.workspace_bytes(*key) <= self.SMALL_JOB_WORKSPACE
+            n, h, w = key
+            if self.lr_hr_resize and (h > self.lr_shape[0] or w > self.lr_shape[1]):
+                h, w = self.lr_shape   # (the network sees the area-resized frame: fsrcnn_upscaler.py:174-176)
+            try:
+                self._small[key] = self.model.workspace_bytes(n, h, w) <= self.SMALL_JOB_WORKSPACE
+            except Exception:  # noqa: BLE001 - a shape the network rejects: the job itself reports it
+                self._small[key] = False
         return self._small[key]
 
     def _check_streams(self, frames: torch.Tensor, tries: int = 6) -> None:
