@@ -31,7 +31,7 @@ single-set path (same kernels, same weights).  The worker hands result i over af
 at once when the queue runs dry (``BaseService.deliver_lag``); ``upscale()`` called directly stays synchronous with the current stream unless ``wait=False``.
 Measured on one box (RRDBNet x2, 720p, ``profiles/r05_n1_probe_sets.txt``): one set 108.8 frames/s, two 122.8, three 125.6, four 124.9 -
 against 127.5 for four-frame jobs; two- and four-frame jobs gain nothing from alternating (125.5 / 125.7 against 125.0 / 127.5), so they
-stay on set 0.  Cost per extra set: a copy of the SR weights and activation workspace (RRDBNet x2 at 720p: 67 MB + 177 MB), built on the
+stay on set 0.  Cost per extra set: a copy of the SR weights and activation workspace (RRDBNet x2 at 720p: 67 MB + 1.25 GB), built on the
 first one-frame job.  HIP serves a process's streams from a few hardware queues: the sets' streams are checked once to really run side by
 side (``_check_streams``).
 """
@@ -214,10 +214,11 @@ class HipUpscalerService(BaseUpscalerService):
             js["stream"] = torch.cuda.Stream(self.torch_device)
         return js
 
-    #: a job alternates over the job sets only if the network's activation workspace for it is at most this (RRDBNet x2 on a 720p frame: 177 MB,
-    #: on a 1080p frame 400 MB; RRDBNet x4 on 1080p: 11 GB - 4050 tiles per launch fill the chip eight times over, the next job has nothing
-    #: to cover (measured: 14.1 frames/s either way) and two more sets would be 22 GB for nothing)
-    SMALL_JOB_WORKSPACE = 1 << 30
+    #: a job alternates over the job sets only if the network's activation workspace for it is at most this (RRDBNet x2 on a 720p frame: 1.25 GB -
+    #: 0.19 GB of body tensors at 360 x 640 and 1.06 GB of tail tensors at 720p / 1440p -, on a 1080p frame 2.8 GB; RRDBNet x4 on 1080p: 11 GB:
+    #: 4050 tiles per launch fill the chip eight times over, the next job has nothing to cover (measured: 14.1 frames/s either way) and two more
+    #: sets would be 22 GB for nothing)
+    SMALL_JOB_WORKSPACE = 4 << 30
 
     def _small_job(self, frames: torch.Tensor) -> bool:
         key = tuple(frames.shape[:3])
