@@ -621,11 +621,12 @@ void Model::check_async_error(bool wait) {
 // Two chains win when a launch is short next to its fixed costs (launch boundary, prologue, the partly filled last round
 // of tiles): up to 4 frames of 720p per job here; they lose nothing-to-1 % on bigger jobs, and they rely on the two HIP
 // streams being served concurrently by the hardware queues.  So, unless forced by SS4K_LANES, the choice is MEASURED per
-// (n, h, w) over the shape's first six forwards, ALTERNATING: calls 0, 2, 4 run two chains, calls 1, 3, 5 one; calls 2-5 are
-// timed with events on the caller's stream (no host synchronisation: the events are polled on later calls) and the better
-// of each mode's two samples is compared.  Alternating matters: a service built a second ago starts on an idle chip whose
-// clock is still ramping, and "two chains first, one chain after" charged the ramp to the two chains (round 5: one bench leg
-// in a dozen then ran its whole job on one chain, 106-112 instead of 115-118 frames/s).
+// (n, h, w) over the shape's first six forwards: calls 0 / 1 warm up two chains / one, calls 2-5 run two, one, one, two (A B B A)
+// and are timed with events on the caller's stream (no host synchronisation: the events are polled on later calls); the MEANS
+// of each mode's two samples are compared.  The order matters: a service built a second ago starts on an idle chip whose
+// clock is still ramping, and a drift that is linear over the four timed calls cancels in A B B A, where "two chains first,
+// one chain after" (rounds 3-4) and plain alternation both charge it to the two chains (round 5: one bench leg in a dozen ran
+// its whole job on one chain, 106-112 instead of 115-120 frames/s).
 // Returns the mode this call runs in: 2 = two launch chains, 1 = one.
 int Model::tune_step(std::map<std::tuple<int, int, int>, LaneTune>& tab, int n, int h, int w, hipStream_t st) {
   const auto key = std::make_tuple(n, h, w);
@@ -644,7 +645,8 @@ int Model::tune_step(std::map<std::tuple<int, int, int>, LaneTune>& tab, int n, 
       SS4K_HIP(hipEventRecord(ev[0], st));
       tune_timed = ev[1];
     }
-    return (k & 1) ? 1 : 2;
+    static const int order[6] = {2, 1, 2, 1, 1, 2};
+    return order[k];
   }
   bool done = true;
   for (auto& pr : t->ev) done = done && hipEventQuery(pr[1]) == hipSuccess;
@@ -654,9 +656,9 @@ int Model::tune_step(std::map<std::tuple<int, int, int>, LaneTune>& tab, int n, 
     bool ok = true;
     for (int i = 0; i < 4; ++i) ok = ok && hipEventElapsedTime(&ms[i], t->ev[i][0], t->ev[i][1]) == hipSuccess && ms[i] > 0.f;
     if (!ok) (void)hipGetLastError();
-    const float ms2 = std::min(ms[0], ms[2]), ms1 = std::min(ms[1], ms[3]);   // calls 2, 4: two chains; 3, 5: one
+    const float ms2 = 0.5f * (ms[0] + ms[3]), ms1 = 0.5f * (ms[1] + ms[2]);   // calls 2, 5: two chains; 3, 4: one
     // two chains unless one chain was CLEARLY faster: where both were measured carefully (RRDBNet / SRVGG / BSVD, 2-8 frames) two chains win
-    // by 4-10 % or lose by at most 1 %, so a noisy pair of samples should cost the latter, not the former
+    // by 4-10 % or lose by at most 1 %, so noisy samples should cost the latter, not the former
     t->decided = !ok ? 1 : (ms1 < 0.97f * ms2 ? 1 : 2);
     t->ms[0] = ms2; t->ms[1] = ms1;
     for (auto& pr : t->ev) for (auto& e : pr) { (void)hipEventDestroy(e); e = nullptr; }

@@ -309,7 +309,7 @@ def test_rrdbnet_fp16_full_gain_weights(ctx, nb):
 def test_frame_lanes_bit_identical(ctx, monkeypatch, kind, n):
     """An fp16 batch of two or more frames may go through the conv layers as two concurrent launch chains (csrc/models.h,
     frame lanes); an odd batch splits unevenly (3 = 1 + 2, 5 = 2 + 3), so the two chains run different grid sizes.
-    One chain (SS4K_LANES=1), two chains (=2) and the measured choice (unset: calls 0-5 alternate two chains / one, then the
+    One chain (SS4K_LANES=1), two chains (=2) and the measured choice (unset: calls 0-5 run two / one / two / one / one / two chains, then the
     faster) must give bit-identical tensors, call after call, for every conv network."""
     def build():
         if kind == "rrdbnet":
