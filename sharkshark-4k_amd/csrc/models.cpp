@@ -661,6 +661,10 @@ int Model::tune_step(std::map<std::tuple<int, int, int>, LaneTune>& tab, int n, 
     // by 4-10 % or lose by at most 1 %, so noisy samples should cost the latter, not the former
     t->decided = !ok ? 1 : (ms1 < 0.97f * ms2 ? 1 : 2);
     t->ms[0] = ms2; t->ms[1] = ms1;
+#ifdef SS4K_DEV
+    static const bool tune_log = std::getenv("SS4K_LANE_TUNE_LOG") != nullptr;
+    if (tune_log) std::fprintf(stderr, "[lanes] kind %d job %d x %d x %d: two chains %.3f %.3f ms, one chain %.3f %.3f ms -> %d\n", desc.kind, n, h, w, ms[0], ms[3], ms[1], ms[2], t->decided);
+#endif
     for (auto& pr : t->ev) for (auto& e : pr) { (void)hipEventDestroy(e); e = nullptr; }
     return t->decided;
   }
