@@ -234,47 +234,51 @@ class HipUpscalerService(BaseUpscalerService):
                 self._small[key] = False
         return self._small[key]
 
-    def _check_streams(self, frames: torch.Tensor, tries: int = 8) -> None:
+    def _check_streams(self, frames: torch.Tensor, tries: int = 4) -> None:
         """One-off, at the first small job: do the job sets' streams really run side by side?  HIP serves a process's streams from a few
         hardware queues; two streams that share one are executed in order, whatever the program says - seen on a process that had created
-        many streams before (profiles/r05_n1_probe_streams.txt: 107 instead of 122 frames/s, silently).  So, for every pair of sets: time a
-        one-frame job of each with both on one stream, then on their own streams; if the second form is not faster, the later set takes
-        another stream and is checked again.  Blocks the host for a few dozen jobs' time, once per service."""
+        many streams before (profiles/r05_n1_probe_streams.txt: 107 instead of 122 frames/s, silently).  So, for every pair of sets: six
+        one-frame jobs alternating over the two, first with both sets on ONE stream, then each on its own; side by side they take 0.88-0.92 of
+        the time in order (what is gained is the overlap of a job's tail with the next one's head, so a single pair of jobs shows only half of
+        it), on a shared queue 0.97-1.2.  A set that does not pass takes another stream and is checked again.  Blocks the host for a few dozen
+        jobs' time, once per service."""
         self._streams_checked = True
         frames = frames[:1]   # (one-frame jobs gain 12-15 % from running side by side: a clear signal; multi-frame jobs gain nothing, measured)
         dev, cur = self.torch_device, torch.cuda.current_stream(self.torch_device)
         sets = [self._job_set(k) for k in range(self.overlap_sets)]
         ups = [self._get_upscaler(k) for k in range(self.overlap_sets)]
 
-        def run(which, streams):   # one job on each set of `which`, set which[i] on streams[i]: milliseconds on the current stream
+        def run(seq, stream_of):   # jobs on the sets of `seq`, in that order, set i on stream_of[i]: milliseconds on the current stream
             torch.cuda.synchronize(dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(cur)
-            for st in set(streams):
+            used = {stream_of[i] for i in seq}
+            for st in used:
                 st.wait_stream(cur)
-            for idx, st in zip(which, streams):
-                with torch.cuda.stream(st):
-                    ups[idx](frames)
-            for st in set(streams):
+            for i in seq:
+                with torch.cuda.stream(stream_of[i]):
+                    ups[i](frames)
+            for st in used:
                 cur.wait_stream(st)
             e1.record(cur)
             e1.synchronize()
             return e0.elapsed_time(e1)
 
-        run(range(len(sets)), [js["stream"] for js in sets])   # (first calls size workspaces and raise LDS limits)
+        run(range(len(sets)), {i: js["stream"] for i, js in enumerate(sets)})   # (first calls size workspaces and raise LDS limits)
         for k in range(1, len(sets)):
             for _ in range(tries):
                 bad = None
                 for j in range(k):   # against EVERY earlier set: sets 1 and 2 must not share a queue either
-                    serial = min(run((j, k), [sets[j]["stream"]] * 2) for _ in range(2))
-                    both = min(run((j, k), [sets[j]["stream"], sets[k]["stream"]]) for _ in range(2))
-                    if not both < 0.93 * serial:   # (two one-frame jobs side by side take 0.86-0.89 of their time in order; a shared queue: 0.97-1.2)
+                    seq = (j, k) * 3
+                    serial = run(seq, {j: sets[j]["stream"], k: sets[j]["stream"]})
+                    both = run(seq, {j: sets[j]["stream"], k: sets[k]["stream"]})
+                    if not both < 0.95 * serial:
                         bad = (j, both, serial)
                         break
                 if bad is None:
-                    log(f"job set {k}: runs beside the earlier sets ({both:.2f} ms against {serial:.2f} ms in order with set {k - 1})")
+                    log(f"job set {k}: runs beside the earlier sets (six jobs {both:.2f} ms against {serial:.2f} ms in order)")
                     break
-                log(f"job set {k}: its stream does not run beside set {bad[0]}'s ({bad[1]:.2f} ms against {bad[2]:.2f} ms in order) - taking another stream")
+                log(f"job set {k}: its stream does not run beside set {bad[0]}'s (six jobs {bad[1]:.2f} ms against {bad[2]:.2f} ms in order) - taking another stream")
                 sets[k]["stream"] = torch.cuda.Stream(dev)
             else:
                 log(f"job set {k}: no stream found that overlaps with the earlier sets' after {tries} tries; its jobs will run in order with one of them")
