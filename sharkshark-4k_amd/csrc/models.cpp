@@ -622,11 +622,12 @@ void Model::check_async_error(bool wait) {
 // of tiles): up to 4 frames of 720p per job here; they lose nothing-to-1 % on bigger jobs, and they rely on the two HIP
 // streams being served concurrently by the hardware queues.  So, unless forced by SS4K_LANES, the choice is MEASURED per
 // (n, h, w) over the shape's first six forwards: calls 0 / 1 warm up two chains / one, calls 2-5 run two, one, one, two (A B B A)
-// and are timed with events on the caller's stream (no host synchronisation: the events are polled on later calls); the MEANS
-// of each mode's two samples are compared.  The order matters: a service built a second ago starts on an idle chip whose
-// clock is still ramping, and a drift that is linear over the four timed calls cancels in A B B A, where "two chains first,
-// one chain after" (rounds 3-4) and plain alternation both charge it to the two chains (round 5: one bench leg in a dozen ran
-// its whole job on one chain, 106-112 instead of 115-120 frames/s).
+// and are timed with events on the caller's stream (no host synchronisation: the events are polled on later calls); the BETTER
+// of each mode's two samples is compared.  Both choices come from misjudgements seen in round 5 (dev library: SS4K_LANE_TUNE_LOG=1):
+// a service built a second ago starts on an idle chip whose clock is still ramping, which "two chains first, one chain after"
+// (rounds 3-4) charged to the two chains - in A B B A the latest and the earliest timed call are two-chain calls; and a sample can
+// be an outlier (31.9 and 54.5 ms for the same job: the host stalled in an allocation while it was enqueueing), which a mean
+// turns into a wrong choice for the life of the model (119 instead of 124 frames/s) and a minimum ignores.
 // Returns the mode this call runs in: 2 = two launch chains, 1 = one.
 int Model::tune_step(std::map<std::tuple<int, int, int>, LaneTune>& tab, int n, int h, int w, hipStream_t st) {
   const auto key = std::make_tuple(n, h, w);
@@ -656,7 +657,7 @@ int Model::tune_step(std::map<std::tuple<int, int, int>, LaneTune>& tab, int n, 
     bool ok = true;
     for (int i = 0; i < 4; ++i) ok = ok && hipEventElapsedTime(&ms[i], t->ev[i][0], t->ev[i][1]) == hipSuccess && ms[i] > 0.f;
     if (!ok) (void)hipGetLastError();
-    const float ms2 = 0.5f * (ms[0] + ms[3]), ms1 = 0.5f * (ms[1] + ms[2]);   // calls 2, 5: two chains; 3, 4: one
+    const float ms2 = std::min(ms[0], ms[3]), ms1 = std::min(ms[1], ms[2]);   // calls 2, 5: two chains; 3, 4: one
     // two chains unless one chain was CLEARLY faster: where both were measured carefully (RRDBNet / SRVGG / BSVD, 2-8 frames) two chains win
     // by 4-10 % or lose by at most 1 %, so noisy samples should cost the latter, not the former
     t->decided = !ok ? 1 : (ms1 < 0.97f * ms2 ? 1 : 2);
