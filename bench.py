@@ -26,6 +26,12 @@ import os
 import sys
 import time
 
+# HIP runtime settings of the package (sharkshark-4k_amd/__init__.py: kernel arguments in device memory, eight hardware queues).  The runtime
+# reads them when it is LOADED - `import torch` does that - so a process that imports torch before the package has to have them in its
+# environment already (a service worker inherits them from its parent): set here, ahead of the import
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 

@@ -7,8 +7,8 @@ There is no CPU fallback: constructing a context without the library or a GPU ra
 """
 import os as _os
 
-# Kernel arguments in device memory (a HIP runtime setting, read when the runtime initialises - i.e. at the process's first HIP call, which
-# comes after this import): a network forward is 213-351 launches with ~ 300-byte argument blocks, and fetching them from host memory costs
+# Kernel arguments in device memory (a HIP runtime setting, read when the runtime is LOADED - which `import torch` does: a process that
+# imports torch first must already have these two in its environment, as bench.py and every spawned service worker do): a network forward is 213-351 launches with ~ 300-byte argument blocks, and fetching them from host memory costs
 # launch latency that the launch chains expose.  Headline job, one box, three interleaved processes each: 123.9 -> 125.0 frames/s (+ 0.9 %,
 # profiles/r05_kernarg_ab.txt).  setdefault: an integrator's own setting wins; service workers inherit it through the environment.
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
