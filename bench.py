@@ -418,22 +418,6 @@ def main():
                                   "concurrent_launches": rl["concurrent_launches"],
                                   "launches_per_frame_chain": LAUNCHES_PER_FRAME,
                                   "kernel_time_share_of_step": rl["conv_ms_per_step"] / (1000.0 * elapsed / args.steps)}
-            if args.workload == "rrdbnet" and world == 1 and not args.no_by_kernel:
-                # per kernel build, from a ONE-CHAIN run of the same job (SS4K_MODEL_ONE_CHAIN: with two launch chains in flight a launch's
-                # duration includes the time it shares the chip with the other chain's launch - nobody should have to divide by 1.9)
-                try:
-                    svc1, _ = build_service("rrdbnet", local, lr_shape=in_shape, flags=_capi.MODEL_ONE_CHAIN)
-                    for _ in range(2):
-                        svc1.upscale(frames, wait=False)
-                    rl1 = conv_roofline(svc1, frames, psteps=2, by_kernel=True)
-                    result["roofline"]["by_kernel"] = {"what": "one launch chain (SS4K_MODEL_ONE_CHAIN), every launch alone on the chip: algorithmic GFLOP / average launch "
-                                                               "duration (HIP events on the launch stream) against the dense fp16 MFMA peak",
-                                                       "frames_per_launch": args.batch, "conv_tflops": rl1["achieved"], "conv_frac_of_peak": rl1["frac"],
-                                                       "kernels": rl1.get("by_kernel", [])}
-                    del svc1
-                    torch.cuda.empty_cache()
-                except Exception as e:  # never lose the headline line to a secondary measurement
-                    result["roofline"]["by_kernel"] = {"error": str(e)}
         elif args.workload in ("fsrcnn", "fsrcnn_f16"):
             # FSRCNN: three stages, each against the unit that bounds it (fsrcnn_stage_rooflines); the line's roofline is the
             # stage that takes the longest
@@ -531,6 +515,24 @@ def main():
         except Exception as e:  # never lose the headline line to a secondary measurement
             also["rrdbnet_n1_worker"] = {"error": f"{type(e).__name__}: {e}"}
         result["also"] = also
+    if rank == 0 and "roofline" in result and args.workload == "rrdbnet" and world == 1 and not args.no_by_kernel:
+        # per kernel build, from a ONE-CHAIN run of the same job (SS4K_MODEL_ONE_CHAIN: with two launch chains in flight a launch's
+        # duration includes the time it shares the chip with the other chain's launch - nobody should have to divide by 1.9).
+        # Placed after every other measurement: legs that ran AFTER this pass measured 6-8 % low (bench process only, cause not
+        # found: profiles/NOTES_r05.md 10)
+        try:
+            svc1, _ = build_service("rrdbnet", local, lr_shape=in_shape, flags=_capi.MODEL_ONE_CHAIN)
+            for _ in range(2):
+                svc1.upscale(frames, wait=False)
+            rl1 = conv_roofline(svc1, frames, psteps=2, by_kernel=True)
+            result["roofline"]["by_kernel"] = {"what": "one launch chain (SS4K_MODEL_ONE_CHAIN), every launch alone on the chip: algorithmic GFLOP / average launch "
+                                                       "duration (HIP events on the launch stream) against the dense fp16 MFMA peak",
+                                               "frames_per_launch": args.batch, "conv_tflops": rl1["achieved"], "conv_frac_of_peak": rl1["frac"],
+                                               "kernels": rl1.get("by_kernel", [])}
+            del svc1
+            torch.cuda.empty_cache()
+        except Exception as e:  # never lose the headline line to a secondary measurement
+            result["roofline"]["by_kernel"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, psnr = cpu_baseline(args.workload, _capi.Context(local))
         result["cpu_baseline"] = cb
