@@ -210,7 +210,7 @@ class HipUpscalerService(BaseUpscalerService):
             self._sets.append({"ctx": ctx, "model": _capi.Model(ctx, desc, flat), "denoise": None, "up": None, "key": None, "stream": None})
             log(f"job set {len(self._sets) - 1} built (one-frame jobs alternate over {len(self._sets)} sets)")
         js = self._sets[k]
-        if js["stream"] is None:
+        if js["stream"] is None and self._overlap_active():
             js["stream"] = torch.cuda.Stream(self.torch_device)
         return js
 
@@ -329,21 +329,23 @@ class HipUpscalerService(BaseUpscalerService):
         return out
 
     def upscale(self, frames: torch.Tensor, wait: bool = True):
-        """The job runs on a stream of its job set; the result is then ordered on the caller's current stream like any torch op
-        (``wait=True``).  ``wait=False`` (direct callers only) leaves it ordered on the job set's stream alone - synchronise
-        (``torch.cuda.synchronize()``) before reading it; inside the worker loop the ordering is done when the result leaves."""
+        """``wait=False`` (direct callers only): with the one-frame overlap active the result is ordered on its job set's stream, not
+        on the current one - synchronise (``torch.cuda.synchronize()``) before reading it.  The default orders it on the current
+        stream like any torch op."""
         assert isinstance(frames, torch.Tensor)
         if frames.device != self.torch_device:
             frames = frames.to(self.torch_device, non_blocking=True)
         if frames.ndim != 4:
             raise Exception(frames.shape)
         assert frames.shape[-1] == 3
-        # Every job runs on a stream of its job set, never on the caller's current stream: that is usually the legacy NULL stream, whose launches
-        # get slower with every other stream the process has used (bench.py, same box: the per-frame path's four-frame job 115.5 frames/s, and 108.5
-        # when one more service had existed before - as one chain 32 -> 38 ms per job; on its own stream the same job does not notice).
+        if not self._overlap_active():
+            out = self._run(0, frames)
+            if frames.is_cuda and hasattr(self, "_inflight"):   # (same hold on the input as below: see _retire)
+                self._retire()
+                self._inflight.append((torch.cuda.current_stream(self.torch_device).record_event(), frames))
+            return out
         k = 0
-        if self._overlap_active() and frames.shape[0] <= self.overlap_max_frames and self._small_job(frames):
-            # consecutive one-frame jobs alternate over the sets; a multi-frame job overlaps with itself (frame lanes) on set 0
+        if frames.shape[0] <= self.overlap_max_frames and self._small_job(frames):   # consecutive one-frame jobs alternate; a multi-frame job overlaps with itself (frame lanes) on set 0
             if not self._streams_checked:
                 self._check_streams(frames)
             k, self._alt = self._alt, (self._alt + 1) % self.overlap_sets
