@@ -441,10 +441,10 @@ def main():
             torch.cuda.synchronize()
             return time.perf_counter() - t1
 
-        for name, wl, nb, shape, reps in (("fsrcnn", "fsrcnn", args.batch, (720, 1280), 10),
-                                          ("fsrcnn_f16", "fsrcnn_f16", args.batch, (720, 1280), 10),
-                                          ("pipeline", "pipeline", args.batch, (720, 1280), 10),
-                                          ("srvgg", "srvgg", args.batch, (720, 1280), 10),
+        for name, wl, nb, shape, reps in (("fsrcnn", "fsrcnn", args.batch, (720, 1280), 100),      # (a step is 1.9 / 0.8 ms: enough of them to time)
+                                          ("fsrcnn_f16", "fsrcnn_f16", args.batch, (720, 1280), 150),
+                                          ("pipeline", "pipeline", args.batch, (720, 1280), 15),
+                                          ("srvgg", "srvgg", args.batch, (720, 1280), 30),
                                           ("rrdbnet_n1", "rrdbnet", 1, (720, 1280), 40),
                                           ("rrdbnet_n1_one_set", "rrdbnet", 1, (720, 1280), 20),
                                           ("rrdbnet_x4", "rrdbnet_x4", 1, (1080, 1920), 5)):
