@@ -28,7 +28,8 @@ export SS4K_LANES=2
 # 2. headline: fabric traffic of the conv launches (separate passes)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B --steps 2 --warmup 1 --no-roofline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B --steps 2 --warmup 1 --no-roofline > /dev/null 2>&1
-python3 tools/pmc_traffic.py $O/fetch $O/write $O/${TAG}_conv3x3_pmc_traffic.json 2 3 4 > /dev/null
+# (steps run = 7 settle calls of the lane tuning + 1 warm-up + 2 timed: bench.py)
+python3 tools/pmc_traffic.py $O/fetch $O/write $O/${TAG}_conv3x3_pmc_traffic.json 2 10 4 > /dev/null
 # the name bench.py reads (bench.py PMC_TRAFFIC_FILE): both files are copied into profiles/
 cp $O/${TAG}_conv3x3_pmc_traffic.json $O/conv3x3_pmc_traffic_current.json
 rm -rf $O/fetch $O/write

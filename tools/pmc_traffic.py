@@ -35,9 +35,9 @@ for fam in list(FAMILIES) + sorted(set(fam_f.values()) - set(FAMILIES)):
         by_family[fam] = {"launches_per_step": len(ff) / steps, "traffic_bytes_per_launch": (2 * sum(ff) / len(ff) + sum(ww) / len(ww)) * 1024,
                           "traffic_bytes_per_step": (2 * sum(ff) + sum(ww)) * 1024 / steps}
 out = {
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps %d --warmup 1 "
-              "--no-cpu-baseline --no-roofline --no-also (RRDBNet x2 720p fp16, %d frames per step, %d per launch: SS4K_LANES=2), "
-              "every launch of the 3x3 conv kernels" % (steps - 1, fps, n),
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 "
+              "--no-cpu-baseline --no-roofline --no-also --no-by-kernel (RRDBNet x2 720p fp16, %d frames per step, %d per launch: SS4K_LANES=2; "
+              "%d forwards in all with the settle calls of bench.py), every launch of the 3x3 conv kernels" % (fps, n, steps),
     "launches_counted": len(fetch_d), "steps": steps, "frames_per_step": fps, "frames_per_launch": n,
     "correction": "FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as is; KB x1024",
     "traffic_bytes_per_step": total / steps,
