@@ -518,8 +518,8 @@ def main():
     if rank == 0 and "roofline" in result and args.workload == "rrdbnet" and world == 1 and not args.no_by_kernel:
         # per kernel build, from a ONE-CHAIN run of the same job (SS4K_MODEL_ONE_CHAIN: with two launch chains in flight a launch's
         # duration includes the time it shares the chip with the other chain's launch - nobody should have to divide by 1.9).
-        # Placed after every other measurement: legs that ran AFTER this pass measured 6-8 % low (bench process only, cause not
-        # found: profiles/NOTES_r05.md 10)
+        # Placed after every other measurement: before the library tested its lane stream (ss4k_stream_pair_check), a leg that ran AFTER
+        # this pass could get the hardware queue that is slow beside the NULL stream's and measure 6-8 % low (profiles/NOTES_r05.md 10)
         try:
             svc1, _ = build_service("rrdbnet", local, lr_shape=in_shape, flags=_capi.MODEL_ONE_CHAIN)
             for _ in range(2):

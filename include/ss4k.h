@@ -9,7 +9,10 @@
  *   - *_dev pointers are device (HIP) pointers BORROWED from the caller (PyTorch owns the I/O
  *     tensors); the library owns weights and workspaces.
  *   - work is enqueued on the caller's stream (hipStream_t passed as void*; NULL = default
- *     stream) with no hidden synchronisation, like the reference's eager torch calls.
+ *     stream) with no hidden synchronisation, like the reference's eager torch calls.  One
+ *     exception, once per (ctx, stream): the first multi-frame fp16 forward from a stream tests
+ *     that the ctx's second launch chain really runs beside it (~ 3 ms, the host waits for the
+ *     stream once; see ss4k_stream_pair_check).
  *   - one ss4k_ctx per device; a ctx and its children are not thread-safe (the reference's
  *     worker is a single-threaded process loop, base_service.py:33-60).
  *   - a ctx and everything created from it (models, upscalers) is SINGLE-STREAM: a model reuses its
@@ -32,7 +35,7 @@ extern "C" {
 
 #define SS4K_ABI_VERSION 3   /* 3: the register-stationary kernel and the cross-layer chain left the product library (dev library only): flag bits 8
                                  (NO_RS), 64 (NO_CHAIN), 128 (CHAIN), 2048 (DENSE) and 16384 (CONV5_RS) are no longer accepted;
-                                 ss4k_prof_read_family was added.  2: ss4k_model_desc.reserved[0] became the validated `flags` word */
+                                 ss4k_prof_read_family and ss4k_stream_pair_check were added.  2: ss4k_model_desc.reserved[0] became the validated `flags` word */
 
 enum { SS4K_OK = 0, SS4K_EINVAL = -22, SS4K_ENOMEM = -12, SS4K_EHIP = -5, SS4K_ENODEV = -19 };
 
@@ -229,6 +232,15 @@ int ss4k_prof_read_kind(ss4k_ctx* ctx, int kind, int64_t* launches, double* tota
  * C++ name as rocprofv3 prints it (e.g. "w16::conv3x3_w16_kernel<RL> (...)").  With two launch chains in flight the per-launch times overlap:
  * read these from a one-chain run (SS4K_MODEL_ONE_CHAIN) when a kernel's own rate is wanted. */
 int ss4k_prof_read_family(ss4k_ctx* ctx, int index, char* name, size_t name_capacity, int64_t* launches, double* total_ms, double* flops);
+/* ---- streams
+ * HIP serves a process's streams from a few hardware queues.  Two streams on one queue run in order whatever the program says, and
+ * some pairs of queues launch slowly while both are busy (measured: 14 us per launch instead of 2.5, profiles/r05_lane_queue.txt);
+ * which queue a stream gets depends on how many the process created before it.  This call MEASURES a pair (a 0.2 ms idle kernel on
+ * each, then 200 x 1 us kernels interleaved; ~ 3 ms, synchronises both streams) and sets *side_by_side to 1 or 0.  A host that runs
+ * several contexts on its own streams calls it once per pair and replaces a stream that fails (keep the failed one alive until the
+ * replacement exists, or the new stream lands on the same queue).  The library does this itself for each ctx's internal lane stream. */
+int ss4k_stream_pair_check(ss4k_ctx* ctx, void* hip_stream_a, void* hip_stream_b, int* side_by_side);
+
 /* Conv sections: wall time, on the caller's stream, from the first conv launch of every network forward to the end
  * of its last one (launch boundaries included).  A job's frames may go through the conv layers as two CONCURRENT launch
  * chains (frame lanes): the per-launch times of ss4k_prof_read then overlap, and sum(FLOPs) / section time is the rate

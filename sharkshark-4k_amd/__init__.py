@@ -16,7 +16,8 @@ _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 # current stream, three job-set streams, the context's frame-lane stream); streams that share a hardware queue run in order, whatever the
 # program says (profiles/NOTES_r05.md 3).  Same A/B form: headline 124.9-125.6 either way; the SRVGG job of a process that had used many
 # streams lost its second launch chain in two of three runs at four queues (402 against 423 frames/s) and never at eight
-# (profiles/r05_hwq_ab.txt).  The job sets still check their streams once (hip_upscaler._check_streams).
+# (profiles/r05_hwq_ab.txt).  More queues are not only more room: some PAIRS of them are slow side by side (profiles/r05_lane_queue.txt), so
+# the library tests its lane stream (ss4k_ctx::lane_check) and the service its job-set streams (hip_upscaler._vetted_stream) whatever this is set to.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 __version__ = "0.1.0"

@@ -28,6 +28,7 @@ SYMBOLS = [
     "ss4k_upscaler_read_tap", "ss4k_op_u8nhwc_to_f32nchw", "ss4k_op_area_resize", "ss4k_op_bicubic_resize",
     "ss4k_op_bilinear_resize", "ss4k_op_depthwise_reflect", "ss4k_op_plane_stats", "ss4k_op_f32nchw_to_u8nhwc",
     "ss4k_prof_enable", "ss4k_prof_reset", "ss4k_prof_read", "ss4k_prof_read_kind", "ss4k_prof_read_family", "ss4k_prof_read_section_ms",
+    "ss4k_stream_pair_check",
 ]
 DEV_SYMBOLS = ["ss4k_bench_conv"]  # include/ss4k_dev.h: libss4k_hip_dev.so only (SS4K_LIB=.../libss4k_hip_dev.so)
 
@@ -112,6 +113,7 @@ def load(path: str) -> C.CDLL:
     if hasattr(L, "ss4k_prof_read_family"):
         L.ss4k_prof_read_family.argtypes = [vp, i, C.c_char_p, sz, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ss4k_prof_read_section_ms.argtypes = [vp, C.POINTER(C.c_double)]
+    L.ss4k_stream_pair_check.argtypes = [vp, vp, vp, C.POINTER(C.c_int)]
     return L
 
 
@@ -177,6 +179,12 @@ class Context:
                 return out
             out.append((name.value.decode(), n.value, ms.value, fl.value))
             idx += 1
+
+    def streams_side_by_side(self, a, b) -> bool:
+        """Measured (~ 3 ms, synchronises both): do the torch streams `a` and `b` run beside each other at full launch rate?"""
+        ok = C.c_int()
+        _check(lib().ss4k_stream_pair_check(self._h, int(a.cuda_stream), int(b.cuda_stream), C.byref(ok)))
+        return bool(ok.value)
 
     def prof_read_section_ms(self) -> float:
         """Wall time of the profiled forwards' conv sections (first conv launch to the end of the last, caller's stream)."""

@@ -307,6 +307,7 @@ void ss4k_ctx_destroy(ss4k_ctx* c) {
   for (auto& e : c->prof_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : c->prof_sections) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->lane_stream_) (void)hipStreamDestroy(c->lane_stream_);
+  for (auto ls : c->lane_parked) (void)hipStreamDestroy(ls);
   if (c->fork_event) (void)hipEventDestroy(c->fork_event);
   if (c->done_event) (void)hipEventDestroy(c->done_event);
   delete c;
@@ -481,6 +482,14 @@ static void prof_collect(ss4k_ctx* c) {
     c->prof_pool.push_back(e);
   }
   c->prof_sections.clear();
+}
+int ss4k_stream_pair_check(ss4k_ctx* c, void* a, void* b, int* side_by_side) {
+  return guard([&] {
+    SS4K_REQUIRE(c && side_by_side, "ss4k_stream_pair_check: NULL argument");
+    SS4K_REQUIRE(a != b, "ss4k_stream_pair_check: the same stream twice");
+    SS4K_HIP(hipSetDevice(c->device));
+    *side_by_side = stream_pair_ok((hipStream_t)a, (hipStream_t)b) ? 1 : 0;
+  });
 }
 int ss4k_prof_enable(ss4k_ctx* c, int en) { if (!c) return SS4K_EINVAL; c->prof = en != 0; return SS4K_OK; }
 int ss4k_prof_reset(ss4k_ctx* c) {

@@ -98,6 +98,16 @@ struct ss4k_ctx {
   }
   hipEvent_t lane_fork() { return untimed_event(fork_event); }
   hipEvent_t lane_done() { return untimed_event(done_event); }
+  // A HIP stream is a software queue mapped onto one of a few hardware queues.  Two streams on ONE hardware queue run strictly one after
+  // the other, and some PAIRS of hardware queues are slow when both are busy (measured, round 5: the 5th queue of a process against the
+  // NULL stream's, 14 us per launch instead of 2.5 - a 4-frame RRDBNet job lost 6 %).  Which queue a new stream gets depends on how many
+  // streams the process made before it, so before the first fork from a caller's stream the pair is TESTED (lane_check, models.cpp) and a
+  // lane stream that fails is parked (kept alive, so that its successor lands on another queue) and replaced.  It is tested against the NULL stream as well.
+  // Costs 3-6 ms and a host synchronisation per (context, caller stream), once.
+  std::set<hipStream_t> lane_checked;
+  std::vector<hipStream_t> lane_parked;
+  int lane_replaced = 0;
+  void lane_check(hipStream_t caller);
   // conv sections (bench): wall time on the caller's stream from a forward's first conv launch to the end of its last
   std::vector<ss4k::ProfEvent> prof_sections;
   double prof_section_ms = 0;

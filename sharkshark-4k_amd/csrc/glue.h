@@ -36,6 +36,8 @@ void op_bilinear(const float* in, float* out, int planes, int h, int w, int oh, 
 void op_bicubic(const float* in, float* out, int planes, int h, int w, int oh, int ow, int clamp01, hipStream_t st);
 void op_sub(const float* a, const float* b, float* out, size_t n, hipStream_t st);
 void op_clamp01(float* x, size_t n, hipStream_t st);
+void op_lane_spin(unsigned ticks, hipStream_t st);   // occupies `st` for ticks / 100 MHz (at most 0.5 ms) with one idle wave
+bool stream_pair_ok(hipStream_t a, hipStream_t b);     // models.cpp: do the two streams run side by side at full launch rate? (measured, ~ 3 ms, synchronises)
 void op_f32nchw_to_u8nhwc(const float* in, uint8_t* out, int n, int c, int h, int w, hipStream_t st);
 template <typename T>
 void op_pack_input(const float* in, T* out, int n, int c, int h, int w, int r, int nplanes, hipStream_t st);

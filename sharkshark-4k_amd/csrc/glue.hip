@@ -614,6 +614,16 @@ __global__ void k_clamp01(float* __restrict__ x, size_t n) {
 }
 void op_clamp01(float* x, size_t n, hipStream_t st) { hipLaunchKernelGGL(k_clamp01, grid1d(n), dim3(256), 0, st, x, n); SS4K_LAUNCH_OK(); }
 
+// one wave that occupies its stream for `ticks` of the 100 MHz real-time counter and does nothing else (ss4k_ctx::lane_check times a
+// pair of these to see whether two streams run side by side); bounded: every wave leaves after at most LANE_SPIN_MAX_TICKS
+constexpr unsigned LANE_SPIN_MAX_TICKS = 50000;   // 0.5 ms
+__global__ void k_lane_spin(unsigned ticks) {
+  ticks = ticks < LANE_SPIN_MAX_TICKS ? ticks : LANE_SPIN_MAX_TICKS;
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+void op_lane_spin(unsigned ticks, hipStream_t st) { hipLaunchKernelGGL(k_lane_spin, dim3(1), dim3(64), 0, st, ticks); SS4K_LAUNCH_OK(); }
+
 // (clamp(x,0,1)*255) -> uint8 by truncation, NCHW -> NHWC   (fsrcnn_upscaler.py:232-233, :325-326)
 __global__ void k_f32nchw_to_u8nhwc(const float* __restrict__ in, uint8_t* __restrict__ out, int n, int c, int h,
                                     int w) {

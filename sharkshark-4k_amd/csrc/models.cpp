@@ -672,9 +672,77 @@ int Model::tune_step(std::map<std::tuple<int, int, int>, LaneTune>& tab, int n, 
   return 2;
 }
 
+}  // namespace ss4k
+
+// Do two streams run BESIDE each other, and at full launch rate (see ss4k_ctx::lane_check in common.h for why that is in doubt)?  Two
+// measurements, timed with events on the first stream between a fork to and a join with the second:
+//   PAIR        one 0.2 ms idle kernel on each stream.  Side by side: 0.21-0.22 ms.  Two streams of one hardware queue: 0.4 ms.  The bad
+//               pairing below: 0.27-0.34 ms (the second kernel starts late).
+//   INTERLEAVE  200 kernels of 1 us on each stream, enqueued alternately.  Normally the host's enqueue rate bounds this (1.0 ms, twice
+//               the 0.5 ms of 200 kernels on the caller's stream alone).  On the one bad pairing seen (the process's 5th hardware
+//               queue against the NULL stream's, GPU_MAX_HW_QUEUES=8) it takes 5.6 ms - 14 us per launch while both queues are busy,
+//               which is what cost a 351-launch forward its 6 % (profiles/r05_lane_queue.txt).
+namespace ss4k {
+bool stream_pair_ok(hipStream_t caller, hipStream_t ls) {
+  static const bool log = std::getenv("SS4K_LANE_CHECK_LOG") != nullptr;
+  constexpr unsigned TICKS = 20000;   // 0.2 ms
+  constexpr int BURST = 200;
+  struct Events {
+    hipEvent_t e0 = nullptr, e1 = nullptr, fork = nullptr, done = nullptr;
+    Events() {
+      for (hipEvent_t* e : {&e0, &e1}) if (hipEventCreate(e) != hipSuccess) { drop(); throw Error(SS4K_EHIP, "hipEventCreate failed"); }
+      for (hipEvent_t* e : {&fork, &done}) if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { drop(); throw Error(SS4K_EHIP, "hipEventCreateWithFlags failed"); }
+    }
+    void drop() { for (hipEvent_t* e : {&e0, &e1, &fork, &done}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; } }
+    ~Events() { drop(); }
+  } ev;
+  // the elapsed time on the caller's stream of `body`, run between a fork to and a join with the other stream
+  auto timed = [&](auto&& body) {
+    float ms = 0.f;
+    SS4K_HIP(hipEventRecord(ev.fork, caller));
+    SS4K_HIP(hipStreamWaitEvent(ls, ev.fork, 0));
+    SS4K_HIP(hipEventRecord(ev.e0, caller));
+    body();
+    SS4K_HIP(hipEventRecord(ev.done, ls));
+    SS4K_HIP(hipStreamWaitEvent(caller, ev.done, 0));
+    SS4K_HIP(hipEventRecord(ev.e1, caller));
+    SS4K_HIP(hipEventSynchronize(ev.e1));
+    SS4K_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+    return ms;
+  };
+  op_lane_spin(100, caller);                      // (the first launch of the kernel carries its load time)
+  const float one = timed([&] { op_lane_spin(TICKS, caller); });
+  float p3[3];
+  for (float& v : p3) v = timed([&] { op_lane_spin(TICKS, ls); op_lane_spin(TICKS, caller); });
+  std::sort(p3, p3 + 3);
+  const float pair = p3[1];   // the median: bad pairings showed 0.27-0.34 ms with a stray 0.23, good ones 0.21-0.22 with a stray 0.24
+  const float burst_one = timed([&] { for (int i = 0; i < BURST; ++i) op_lane_spin(100, caller); });
+  const float burst_both = timed([&] { for (int i = 0; i < BURST; ++i) { op_lane_spin(100, caller); op_lane_spin(100, ls); } });
+  const bool ok = pair - one < 0.045f && burst_both < 5.f * burst_one;   // (either sign alone has missed a bad pairing once)
+  if (log) std::fprintf(stderr, "[streams] %p and %p: one 0.2 ms kernel %.3f ms, one on each %.3f ms; %d x 1 us kernels: %.3f ms on the first stream, %.3f ms interleaved -> %s\n",
+                        (void*)caller, (void*)ls, one, pair, BURST, burst_one, burst_both, ok ? "side by side" : "NOT side by side");
+  return ok;
+}
+}  // namespace ss4k
+
+void ss4k_ctx::lane_check(hipStream_t caller) {
+  if (!lane_checked.insert(caller).second) return;
+  static const bool off = std::getenv("SS4K_NO_LANE_CHECK") != nullptr;
+  if (off) return;
+  for (int attempt = 0; attempt < 6; ++attempt) {
+    // ... and beside the NULL stream: the usual place for a host to WAIT for the caller's stream (torch's current stream in a worker that runs
+    // its jobs on side streams), and a queue that only waits slows its slow partner just as a busy one does
+    if (ss4k::stream_pair_ok(caller, lane_stream()) && (caller == nullptr || ss4k::stream_pair_ok(nullptr, lane_stream()))) break;
+    lane_parked.push_back(lane_stream_); lane_stream_ = nullptr; ++lane_replaced;   // (after 6 tries the last new stream is used untested)
+  }
+}
+
+namespace ss4k {
+
 void Model::lanes_begin(int n, int h, int w, hipStream_t st) {
   cur_lanes = 1; cur_n = n; forked = false; tune_timed = nullptr;
   if (plan_only || lanes_mode == 1 || n < 2 || desc.dtype != SS4K_F16 || dbg) return;   // (an odd job splits 1 : 2, 2 : 3, ...)
+  ctx->lane_check(st);   // (first job from this stream only)
   if (lanes_mode == 2) { cur_lanes = 2; return; }
   cur_lanes = tune_step(lane_tune, n, h, w, st);
 }

@@ -211,8 +211,24 @@ class HipUpscalerService(BaseUpscalerService):
             log(f"job set {len(self._sets) - 1} built (one-frame jobs alternate over {len(self._sets)} sets)")
         js = self._sets[k]
         if js["stream"] is None and self._overlap_active():
-            js["stream"] = torch.cuda.Stream(self.torch_device)
+            others = [torch.cuda.current_stream(self.torch_device)] + [o["stream"] for o in self._sets if o["stream"] is not None]
+            js["stream"] = self._vetted_stream(others, f"job set {k}")
         return js
+
+    def _vetted_stream(self, others, what: str, tries: int = 8) -> torch.cuda.Stream:
+        """A new stream that passes the library's pair test (``ss4k_stream_pair_check``, ~ 3 ms a pair) against every stream of `others`: HIP
+        serves a process's streams from a few hardware queues, two streams of one queue run in order, and some PAIRS of queues are slow while
+        both are busy - or while one is merely WAITING for the other, as the current stream does for a job set's (measured: a one-frame job
+        17.5 instead of 9.5 ms on a set-0 stream that was the process's 4th, `profiles/r05_lane_queue.txt`).  Which queue a stream gets depends
+        on how many the process created before."""
+        for _ in range(tries):
+            cand = torch.cuda.Stream(self.torch_device)   # (torch hands out the streams of a fixed pool in turn: always a different one)
+            bad = next((o for o in others if not self.ctx.streams_side_by_side(o, cand)), None)
+            if bad is None:
+                return cand
+            log(f"{what}: stream {cand.cuda_stream:#x} fails the pair test against {bad.cuda_stream:#x} - taking another")
+        log(f"{what}: no stream passed the pair test after {tries} tries; using the last one")
+        return cand
 
     #: a job alternates over the job sets only if the network's activation workspace for it is at most this (RRDBNet x2 on a 720p frame: 1.25 GB -
     #: 0.19 GB of body tensors at 360 x 640 and 1.06 GB of tail tensors at 720p / 1440p -, on a 1080p frame 2.8 GB; RRDBNet x4 on 1080p: 11 GB:
@@ -279,7 +295,7 @@ class HipUpscalerService(BaseUpscalerService):
                     log(f"job set {k}: runs beside the earlier sets (six jobs {both:.2f} ms against {serial:.2f} ms in order)")
                     break
                 log(f"job set {k}: its stream does not run beside set {bad[0]}'s (six jobs {bad[1]:.2f} ms against {bad[2]:.2f} ms in order) - taking another stream")
-                sets[k]["stream"] = torch.cuda.Stream(dev)
+                sets[k]["stream"] = self._vetted_stream([cur] + [sets[j]["stream"] for j in range(k)], f"job set {k}")
             else:
                 log(f"job set {k}: no stream found that overlaps with the earlier sets' after {tries} tries; its jobs will run in order with one of them")
 
