@@ -446,7 +446,7 @@ def main():
                                           ("pipeline", "pipeline", args.batch, (720, 1280), 15),
                                           ("srvgg", "srvgg", args.batch, (720, 1280), 30),
                                           ("rrdbnet_n1", "rrdbnet", 1, (720, 1280), 40),
-                                          ("rrdbnet_n1_one_set", "rrdbnet", 1, (720, 1280), 20),
+                                          ("rrdbnet_n1_one_set", "rrdbnet", 1, (720, 1280), 60),   # (0.55 s: a 0.18 s burst after the service build measured 108-116 by how long the chip had idled)
                                           ("rrdbnet_x4", "rrdbnet_x4", 1, (1080, 1920), 5)):
             # rrdbnet_n1: back-to-back one-frame jobs from ONE service (the image server's caller): consecutive jobs alternate over the
             # service's two job sets (hip_upscaler.py); rrdbnet_n1_one_set: the same with overlap_jobs=False (every job on one set / stream)
