@@ -726,9 +726,14 @@ bool stream_pair_ok(hipStream_t caller, hipStream_t ls) {
 }  // namespace ss4k
 
 void ss4k_ctx::lane_check(hipStream_t caller) {
-  if (!lane_checked.insert(caller).second) return;
+  if (lane_checked.count(caller)) return;
   static const bool off = std::getenv("SS4K_NO_LANE_CHECK") != nullptr;
   if (off) return;
+  // (a stream that is being captured into a graph cannot be synchronised: the test waits for the first forward outside a capture)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(caller, &cap) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (cap != hipStreamCaptureStatusNone) return;
+  lane_checked.insert(caller);
   for (int attempt = 0; attempt < 6; ++attempt) {
     // ... and beside the NULL stream: the usual place for a host to WAIT for the caller's stream (torch's current stream in a worker that runs
     // its jobs on side streams), and a queue that only waits slows its slow partner just as a busy one does

@@ -41,7 +41,8 @@ import torch
 import sharkshark4k_amd
 from sharkshark4k_amd import _capi, weights as W
 from tests.helpers import smooth_u8
-keep = [torch.cuda.Stream() for _ in range({k})]          # K used streams first: the context's lane stream becomes the (K+1)th
+torch.zeros(1, device="cuda")                              # the NULL stream takes the process's first hardware queue ...
+keep = [torch.cuda.Stream() for _ in range({k})]          # ... K used streams the next K: the context's lane stream gets the (K+2)th
 for st in keep:
     with torch.cuda.stream(st): torch.zeros(1, device="cuda")
 torch.cuda.synchronize()
@@ -59,8 +60,8 @@ print("BIT IDENTICAL")
 
 @pytest.mark.parametrize("k", [0, 3])
 def test_lane_stream_is_checked_once_and_a_bad_one_replaced(k):
-    """K = 3 with eight hardware queues is the pairing that was slow in round 5 (5 boxes of 5): there the log must show a replacement and then a
-    stream that passes; everywhere the check runs ONCE per (context, caller stream) - the second forward adds no line - a one-chain model never
+    """K = 3 with eight hardware queues is the pairing that was slow in round 5 (the 1st and the 5th queue a process takes; 5 boxes of 5): if it
+    shows, the log has a replacement and then a stream that passes; everywhere the check runs ONCE per (context, caller stream) - the second forward adds no line - a one-chain model never
     runs it, and the results equal the one-chain model's bit for bit whichever stream serves the second chain."""
     env = dict(os.environ, GPU_MAX_HW_QUEUES="8", SS4K_LANE_CHECK_LOG="1")
     r = subprocess.run([sys.executable, "-c", SCRIPT.format(root=ROOT, k=k)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
