@@ -86,6 +86,47 @@ def build_service(workload, local, lr_shape=(720, 1280), flags=0, overlap_jobs=T
     return svc, flop_px * lr_shape[0] * lr_shape[1]
 
 
+def live_pmc_traffic(batch, timeout_s=180):
+    """roofline.traffic of THIS binary on THIS box: two child runs of this command under `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE: separate
+    passes, with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes), aggregated by tools/pmc_traffic.py exactly like the
+    committed collection (tools/collect_profiles.sh).  -> (dict of tools/pmc_traffic.py, None) or (None, why not).  The children are ordinary
+    child processes of this one (nothing is exec'd over a process that holds the GPU); each is killed as a group if it overruns."""
+    import shutil, signal, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself under a profiler"
+    tmp = tempfile.mkdtemp(prefix="ss4k_pmc_", dir="/tmp")
+    # two launch chains forced (SS4K_LANES=2) so that every conv launch carries batch / 2 frames; the child runs 7 settle calls + 1 warm-up + 2 steps
+    env = dict(os.environ, TMPDIR="/tmp", SS4K_LANES="2")
+    child = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", str(batch), "--no-cpu-baseline", "--no-roofline",
+             "--no-also", "--no-by-kernel", "--no-live-traffic"]
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, counter), "--"] + child
+            p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)   # (exactly the group this call started)
+                p.wait()
+                return None, f"the {counter} pass did not finish in {timeout_s} s"
+            if rc != 0:
+                return None, f"the {counter} pass exited with {rc}"
+        out = os.path.join(tmp, "traffic.json")
+        r = subprocess.run(["python3", os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(tmp, "FETCH_SIZE"), os.path.join(tmp, "WRITE_SIZE"), out,
+                            str(max(1, batch // 2)), "10", str(batch)], cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=120)
+        if r.returncode != 0:
+            return None, "tools/pmc_traffic.py: " + r.stderr.strip().splitlines()[-1][:200]
+        with open(out) as f:
+            return json.load(f), None
+    except Exception as e:  # noqa: BLE001 - a measurement that cannot be taken must not cost the bench line
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def synthetic_frames(batch, shape, seed):
     return torch.from_numpy(np.random.default_rng(seed).integers(0, 256, (batch, shape[0], shape[1], 3), dtype=np.uint8))
 
@@ -303,6 +344,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the short secondary-workload measurements")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed counter passes (profiles/) instead of two rocprofv3 --pmc child runs of this command")
     ap.add_argument("--no-by-kernel", action="store_true", help="skip the one-chain per-kernel pass of the roofline record (a second model: keeps a profiler trace to the headline job)")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks as child processes even for --gpus 1 (exercises the parent / child relay; with "
@@ -371,9 +413,16 @@ def main():
     if rank == 0 and not args.no_roofline:
         rl = conv_roofline(svc, frames, by_kernel=True)
         if rl is not None:
-            traffic, traffic_src = None, None
+            traffic, traffic_src, result_traffic_by_kernel = None, None, None
             pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
-            if args.workload == "rrdbnet" and os.path.exists(pmc) and "traffic_bytes_per_step" in json.load(open(pmc)):
+            live, why_not = (None, "--no-live-traffic") if args.no_live_traffic else (None, "measured for the headline job on one GPU only") \
+                if not (args.workload == "rrdbnet" and world == 1 and args.batch >= 2) else live_pmc_traffic(args.batch)
+            if live is not None and live.get("launches_counted", 0) > 0:
+                traffic = live["traffic_bytes_per_step"] / rl["launches_per_step"]
+                traffic_src = ("live: two child runs of this command under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on this box, "
+                               f"{live['launches_counted']} conv launches over {live['steps']} forwards, {live['frames_per_launch']} frames per launch (SS4K_LANES=2); " + live["correction"])
+                result_traffic_by_kernel = {k: v["traffic_bytes_per_step"] for k, v in live.get("by_kernel", {}).items()}
+            elif args.workload == "rrdbnet" and os.path.exists(pmc) and "traffic_bytes_per_step" in json.load(open(pmc)):
                 # HBM-side bytes per launch cannot be read from inside the process: they come from the
                 # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
                 with open(pmc) as f:
@@ -382,7 +431,9 @@ def main():
                 # per step); per launch = that / this run's launches per step
                 bytes_step_pmc = pj["traffic_bytes_per_step"] * args.batch / pj["frames_per_step"]
                 traffic = bytes_step_pmc / rl["launches_per_step"]
-                traffic_src = f"profiles/{PMC_TRAFFIC_FILE} (" + pj["correction"] + f"; {pj['frames_per_launch']} frames per launch in the counter passes)"
+                traffic_src = f"profiles/{PMC_TRAFFIC_FILE} (" + pj["correction"] + f"; {pj['frames_per_launch']} frames per launch in the counter passes)" + \
+                              f" [committed passes, not this run: {why_not}]"
+                result_traffic_by_kernel = None
             mfma = {"achieved": rl["achieved"], "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rl["frac"]}
             hbm = None
             if traffic is not None:
@@ -404,6 +455,8 @@ def main():
             # wastes more bytes - and live in the "fabric" sub-record, never in frac.
             alg_bytes_step = ALGORITHMIC_BYTES_PER_FRAME * args.batch + ALGORITHMIC_WEIGHT_BYTES
             if hbm is not None:
+                if result_traffic_by_kernel:
+                    hbm["bytes_per_step_by_kernel"] = result_traffic_by_kernel
                 hbm["algorithmic_bytes_per_step"] = alg_bytes_step
                 hbm["measured_over_algorithmic"] = hbm["bytes_per_step"] / alg_bytes_step
             result["roofline"] = {"bound": "mfma", "achieved": mfma["achieved"], "peak": mfma["peak"], "unit": mfma["unit"],

@@ -7,7 +7,7 @@ TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG; mkdir -p $O
-B="python3 bench.py --no-cpu-baseline --no-also --no-by-kernel"
+B="python3 bench.py --no-cpu-baseline --no-also --no-by-kernel --no-live-traffic"
 # 1. headline: per-kernel stats + the bench line printed under the profiler + how many conv launches are in flight
 #    (frame lanes: two concurrent launch chains; the choice is measured by the library over its first calls)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/st -- $B --steps 8 --warmup 6 > $O/bench_under_rocprof.log 2>&1
