@@ -35,7 +35,7 @@ extern "C" {
 
 #define SS4K_ABI_VERSION 3   /* 3: the register-stationary kernel and the cross-layer chain left the product library (dev library only): flag bits 8
                                  (NO_RS), 64 (NO_CHAIN), 128 (CHAIN), 2048 (DENSE) and 16384 (CONV5_RS) are no longer accepted;
-                                 ss4k_prof_read_family and ss4k_stream_pair_check were added.  2: ss4k_model_desc.reserved[0] became the validated `flags` word */
+                                 ss4k_prof_read_family, ss4k_stream_pair_check and ss4k_op_cv_area_* were added.  2: ss4k_model_desc.reserved[0] became the validated `flags` word */
 
 enum { SS4K_OK = 0, SS4K_EINVAL = -22, SS4K_ENOMEM = -12, SS4K_EHIP = -5, SS4K_ENODEV = -19 };
 
@@ -217,6 +217,16 @@ int ss4k_op_plane_stats(ss4k_ctx* ctx, const float* in_dev, float* stats_dev, in
 /* (clamp(x,0,1) * 255).permute(0,2,3,1).to(uint8) — truncation (:232-233) */
 int ss4k_op_f32nchw_to_u8nhwc(ss4k_ctx* ctx, const float* in_dev, uint8_t* out_dev, int n, int c, int h,
                               int w, void* hip_stream);
+
+/* cv2.resize(img, None, fx=fx, fy=fy, interpolation=cv2.INTER_AREA) on uint8 NHWC frames for SHRINKING factors whose inverse is not an integer -
+ * the image server's pre / post scale (0.8 / 0.85 / 0.66: image_pipeline.py:149-150, 259-261, 272-273, 347-348), so that a caller can keep both
+ * on the device next to the upload / download.  OpenCV's general area path (computeResizeAreaTab + ResizeArea_Invoker<uchar, float>), restated
+ * in oracle/cv_area.py; PARITY UNPINNED: the reference pins no OpenCV version and cv2 is not in the build image.  Output size: (cvRound(h * fy),
+ * cvRound(w * fx)) - ss4k_op_cv_area_shape (host only).  Other factors return SS4K_EINVAL.  The first call for a new (h, w, fx, fy) builds and
+ * uploads two small tables (kept per context, at most 64 shapes; no synchronisation unless that cache overflows). */
+int ss4k_op_cv_area_shape(int h, int w, double fx, double fy, int* out_h, int* out_w);
+int ss4k_op_cv_area_resize_u8(ss4k_ctx* ctx, const uint8_t* in_nhwc_dev, uint8_t* out_nhwc_dev, size_t out_capacity_bytes, int n, int h, int w,
+                              int channels, double fx, double fy, void* hip_stream);
 
 /* ---- measurement hooks (bench.py: live per-kernel timing with HIP events on the launch stream) */
 /* When enabled, every launch of the dominant conv kernel is bracketed with hipEvents on the

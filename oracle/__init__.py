@@ -18,4 +18,6 @@ Pinning status
   reference, only "RealESRGAN commit 5ca1078" is, ``README.md:62``) which is absent from this
   image.  ``oracle.nets.rrdbnet`` restates the published BasicSR ``rrdbnet_arch.RRDBNet`` and is
   self-checked by parameter count (16 703 171 for x2 / 16 697 987 for x4) and FLOP count only.
+* ``oracle.cv_area`` (the image server's cv2 ``INTER_AREA`` pre / post scale): **parity unpinned** - OpenCV is neither vendored nor
+  version-pinned by the reference and is absent from this image; the module restates the published algorithm.
 """

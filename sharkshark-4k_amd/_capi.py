@@ -28,7 +28,7 @@ SYMBOLS = [
     "ss4k_upscaler_read_tap", "ss4k_op_u8nhwc_to_f32nchw", "ss4k_op_area_resize", "ss4k_op_bicubic_resize",
     "ss4k_op_bilinear_resize", "ss4k_op_depthwise_reflect", "ss4k_op_plane_stats", "ss4k_op_f32nchw_to_u8nhwc",
     "ss4k_prof_enable", "ss4k_prof_reset", "ss4k_prof_read", "ss4k_prof_read_kind", "ss4k_prof_read_family", "ss4k_prof_read_section_ms",
-    "ss4k_stream_pair_check",
+    "ss4k_stream_pair_check", "ss4k_op_cv_area_shape", "ss4k_op_cv_area_resize_u8",
 ]
 DEV_SYMBOLS = ["ss4k_bench_conv"]  # include/ss4k_dev.h: libss4k_hip_dev.so only (SS4K_LIB=.../libss4k_hip_dev.so)
 
@@ -114,6 +114,8 @@ def load(path: str) -> C.CDLL:
         L.ss4k_prof_read_family.argtypes = [vp, i, C.c_char_p, sz, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ss4k_prof_read_section_ms.argtypes = [vp, C.POINTER(C.c_double)]
     L.ss4k_stream_pair_check.argtypes = [vp, vp, vp, C.POINTER(C.c_int)]
+    L.ss4k_op_cv_area_shape.argtypes = [i, i, C.c_double, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ss4k_op_cv_area_resize_u8.argtypes = [vp, vp, vp, sz, i, i, i, i, C.c_double, C.c_double, vp]
     return L
 
 
@@ -223,6 +225,18 @@ class Context:
 
     def bicubic_resize(self, x, size):
         return self._resize(lib().ss4k_op_bicubic_resize, x, size)
+
+    def cv_area_resize(self, frames: torch.Tensor, fx: float, fy: Optional[float] = None) -> torch.Tensor:
+        """``cv2.resize(frame, None, fx=fx, fy=fy, interpolation=cv2.INTER_AREA)`` of every frame of a uint8 NHWC device tensor (shrinking,
+        non-integer 1 / f: the image server's pre / post scale, image_pipeline.py:272-273,347-348) -> uint8 NHWC."""
+        assert frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.ndim == 4
+        fy = fx if fy is None else fy
+        n, h, w, c = frames.shape
+        oh, ow = C.c_int(), C.c_int()
+        _check(lib().ss4k_op_cv_area_shape(h, w, fx, fy, C.byref(oh), C.byref(ow)))
+        out = torch.empty((n, oh.value, ow.value, c), dtype=torch.uint8, device=frames.device)
+        _check(lib().ss4k_op_cv_area_resize_u8(self._h, frames.data_ptr(), out.data_ptr(), out.numel(), n, h, w, c, fx, fy, _stream()))
+        return out
 
     def bilinear_resize(self, x, size):
         return self._resize(lib().ss4k_op_bilinear_resize, x, size)

@@ -308,6 +308,7 @@ void ss4k_ctx_destroy(ss4k_ctx* c) {
   for (auto& e : c->prof_sections) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->lane_stream_) (void)hipStreamDestroy(c->lane_stream_);
   for (auto ls : c->lane_parked) (void)hipStreamDestroy(ls);
+  for (auto& kv : c->cv_area) if (kv.second.uploaded) (void)hipEventDestroy(kv.second.uploaded);
   if (c->fork_event) (void)hipEventDestroy(c->fork_event);
   if (c->done_event) (void)hipEventDestroy(c->done_event);
   delete c;
@@ -441,6 +442,76 @@ int ss4k_op_depthwise_reflect(ss4k_ctx* c, const float* in, float* out, int p, i
     SS4K_HIP(hipMemcpyAsync(taps, k2d, (size_t)k * k * 4, hipMemcpyHostToDevice, (hipStream_t)s));
     op_depthwise_reflect(in, out, taps, p, h, w, k, 0, nullptr, 0, 0, (hipStream_t)s);
     SS4K_HIP(hipGetLastError());
+  });
+}
+// ---- cv2.resize(..., INTER_AREA), shrinking by a non-integer factor (glue.hip: k_cv_area_u8; oracle/cv_area.py states the algorithm)
+namespace {
+int cv_round(double v) { return (int)std::nearbyint(v); }   // saturate_cast<int>(double): round half to even (default rounding mode)
+void cv_check_factor(double f) {
+  SS4K_REQUIRE(f > 0.0 && f < 1.0, "cv area resize: factors must shrink (0 < f < 1)");
+  const double scale = 1.0 / f;
+  SS4K_REQUIRE(std::fabs(scale - std::nearbyint(scale)) >= 2.220446049250313e-16, "cv area resize: 1 / f is an integer - OpenCV's fast path (other rounding) is not implemented");
+}
+struct CvEnt { int si; float a; };
+// computeResizeAreaTab: the entries of every output cell [d * scale, (d + 1) * scale), in order; ofs[d] = first entry of cell d
+void cv_area_tab(int ssize, int dsize, double scale, std::vector<CvEnt>& ent, std::vector<int>& ofs) {
+  ent.clear(); ofs.assign(dsize + 1, 0);
+  for (int d = 0; d < dsize; ++d) {
+    ofs[d] = (int)ent.size();
+    const double fs1 = d * scale, fs2 = fs1 + scale, cell = std::min(scale, ssize - fs1);
+    int s1 = (int)std::ceil(fs1), s2 = (int)std::floor(fs2);
+    s2 = std::min(s2, ssize - 1);
+    s1 = std::min(s1, s2);
+    if (s1 - fs1 > 1e-3) ent.push_back({s1 - 1, (float)((s1 - fs1) / cell)});
+    for (int sx = s1; sx < s2; ++sx) ent.push_back({sx, float(1.0 / cell)});
+    if (fs2 - s2 > 1e-3) ent.push_back({s2, (float)(std::min(std::min(fs2 - s2, 1.), cell) / cell)});
+  }
+  ofs[dsize] = (int)ent.size();
+}
+}  // namespace
+int ss4k_op_cv_area_shape(int h, int w, double fx, double fy, int* oh, int* ow) {
+  return guard([&] {
+    SS4K_REQUIRE(oh && ow && h > 0 && w > 0, "ss4k_op_cv_area_shape: bad argument");
+    cv_check_factor(fx); cv_check_factor(fy);
+    *oh = cv_round(h * fy); *ow = cv_round(w * fx);
+    SS4K_REQUIRE(*oh > 0 && *ow > 0, "cv area resize: empty output");
+  });
+}
+int ss4k_op_cv_area_resize_u8(ss4k_ctx* c, const uint8_t* in, uint8_t* out, size_t out_capacity, int n, int h, int w, int ch, double fx, double fy, void* s) {
+  return guard([&] {
+    SS4K_REQUIRE(c && in && out, "NULL argument");
+    SS4K_REQUIRE(n > 0 && h > 0 && w > 0 && ch >= 1 && ch <= 4, "cv area resize: n, h, w > 0 and 1 <= channels <= 4");
+    cv_check_factor(fx); cv_check_factor(fy);
+    SS4K_HIP(hipSetDevice(c->device));
+    const auto key = std::make_tuple(h, w, fx, fy);
+    auto it = c->cv_area.find(key);
+    if (it == c->cv_area.end()) {
+      if (c->cv_area.size() >= 64) {   // an image server sees arbitrary sizes: bounded; the tables may still be read by enqueued launches
+        SS4K_HIP(hipDeviceSynchronize());
+        for (auto& kv : c->cv_area) if (kv.second.uploaded) (void)hipEventDestroy(kv.second.uploaded);
+        c->cv_area.clear();
+      }
+      ss4k_ctx::CvAreaTab t;
+      t.oh = cv_round(h * fy); t.ow = cv_round(w * fx);
+      SS4K_REQUIRE(t.oh > 0 && t.ow > 0, "cv area resize: empty output");
+      std::vector<CvEnt> xe, ye; std::vector<int> xo, yo;
+      cv_area_tab(w, t.ow, 1.0 / fx, xe, xo);
+      cv_area_tab(h, t.oh, 1.0 / fy, ye, yo);
+      auto put = [&](const void* p, size_t bytes) { const size_t at = (t.host.size() + 15) & ~size_t(15); t.host.resize(at + bytes); std::memcpy(t.host.data() + at, p, bytes); return at; };
+      t.xe = put(xe.data(), xe.size() * sizeof(CvEnt)); t.xo = put(xo.data(), xo.size() * sizeof(int));
+      t.ye = put(ye.data(), ye.size() * sizeof(CvEnt)); t.yo = put(yo.data(), yo.size() * sizeof(int));
+      t.dev.ensure(t.host.size());
+      it = c->cv_area.emplace(key, std::move(t)).first;   // (the host copy moves with the entry: its buffer address does not change)
+      auto& e = it->second;
+      SS4K_HIP(hipMemcpyAsync(e.dev.ptr, e.host.data(), e.host.size(), hipMemcpyHostToDevice, (hipStream_t)s));
+      SS4K_HIP(hipEventCreateWithFlags(&e.uploaded, hipEventDisableTiming));
+      SS4K_HIP(hipEventRecord(e.uploaded, (hipStream_t)s));
+    }
+    auto& e = it->second;
+    SS4K_REQUIRE(out_capacity >= (size_t)n * e.oh * e.ow * ch, "cv area resize: output buffer too small (ss4k_op_cv_area_shape gives the size)");
+    SS4K_HIP(hipStreamWaitEvent((hipStream_t)s, e.uploaded, 0));
+    const char* d = e.dev.as<char>();
+    op_cv_area_u8(in, out, d + e.xe, reinterpret_cast<const int*>(d + e.xo), d + e.ye, reinterpret_cast<const int*>(d + e.yo), n, h, w, ch, e.oh, e.ow, (hipStream_t)s);
   });
 }
 int ss4k_op_plane_stats(ss4k_ctx* c, const float* in, float* stats, int p, int hw, void* s) {

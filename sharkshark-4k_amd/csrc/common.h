@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <set>
 #include <string>
 #include <vector>
@@ -135,6 +136,10 @@ struct ss4k_ctx {
     if (!b.ptr) { b.ensure(256); (void)hipMemset(b.ptr, 0, 256); }
     return b.as<char>();
   }
+  // cv2-INTER_AREA tables (ss4k_op_cv_area_resize_u8): one entry per (h, w, fx, fy) seen; the host copy lives as long as the entry, so the
+  // upload needs no synchronisation; `uploaded` orders later calls from OTHER streams after it
+  struct CvAreaTab { std::vector<char> host; ss4k::DevBuf dev; hipEvent_t uploaded = nullptr; int oh = 0, ow = 0; size_t xe = 0, xo = 0, ye = 0, yo = 0; };
+  std::map<std::tuple<int, int, double, double>, CvAreaTab> cv_area;
   ss4k::DevBuf& buf(const std::string& name, size_t bytes) {
     auto& b = scratch[name];
     b.ensure(bytes);

@@ -36,6 +36,9 @@ void op_bilinear(const float* in, float* out, int planes, int h, int w, int oh, 
 void op_bicubic(const float* in, float* out, int planes, int h, int w, int oh, int ow, int clamp01, hipStream_t st);
 void op_sub(const float* a, const float* b, float* out, size_t n, hipStream_t st);
 void op_clamp01(float* x, size_t n, hipStream_t st);
+// cv2 INTER_AREA shrink of uint8 NHWC frames (glue.hip); xe / ye: {int source index, float weight} entries, xo / yo: first entry of each output index (+ end)
+void op_cv_area_u8(const uint8_t* in, uint8_t* out, const void* xe, const int* xo, const void* ye, const int* yo, int n, int h, int w, int c, int oh, int ow,
+                   hipStream_t st);
 void op_lane_spin(unsigned ticks, hipStream_t st);   // occupies `st` for ticks / 100 MHz (at most 0.5 ms) with one idle wave
 bool stream_pair_ok(hipStream_t a, hipStream_t b);     // models.cpp: do the two streams run side by side at full launch rate? (measured, ~ 3 ms, synchronises)
 void op_f32nchw_to_u8nhwc(const float* in, uint8_t* out, int n, int c, int h, int w, hipStream_t st);

@@ -614,6 +614,43 @@ __global__ void k_clamp01(float* __restrict__ x, size_t n) {
 }
 void op_clamp01(float* x, size_t n, hipStream_t st) { hipLaunchKernelGGL(k_clamp01, grid1d(n), dim3(256), 0, st, x, n); SS4K_LAUNCH_OK(); }
 
+// cv2.resize(img, None, fx, fy, INTER_AREA) on uint8 NHWC frames, shrinking by a non-integer factor: the image server's pre / post scale
+// (image_pipeline.py:272-273, 347-348).  OpenCV's general area path (modules/imgproc/src/resize.cpp, computeResizeAreaTab +
+// ResizeArea_Invoker<uchar, float>; restated on the CPU in oracle/cv_area.py - PARITY UNPINNED: cv2 is not in the image): per source row
+// buf = sum of S * alpha over the cell's x entries in table order, per output row sum = beta * buf for the first y entry, += for the
+// others, float32, multiply and add rounded separately (OpenCV's baseline build has no FMA), result rounded half to even and clipped.
+// ent: {source index, weight} per table entry; ofs[d] .. ofs[d + 1]: the entries of output index d.
+struct CvAreaEnt { int si; float a; };
+__global__ void k_cv_area_u8(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, const CvAreaEnt* __restrict__ xe, const int* __restrict__ xo,
+                             const CvAreaEnt* __restrict__ ye, const int* __restrict__ yo, int n, int h, int w, int c, int oh, int ow) {
+#pragma clang fp contract(off)   // multiply and add are rounded separately, as in OpenCV's baseline build (plain operators under this pragma: HIP's
+                                 // __fmul_rn / __fadd_rn are inline functions compiled under the header's own contraction mode and DO get fused)
+  const size_t total = (size_t)n * oh * ow;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int dx = (int)(i % ow), dy = (int)((i / ow) % oh), img = (int)(i / ((size_t)ow * oh));
+    const uint8_t* src = in + (size_t)img * h * w * c;
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+    const int x0 = xo[dx], x1 = xo[dx + 1], y0 = yo[dy], y1 = yo[dy + 1];
+    for (int j = y0; j < y1; ++j) {
+      const uint8_t* row = src + (size_t)ye[j].si * w * c;
+      const float beta = ye[j].a;
+      float buf[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int k = x0; k < x1; ++k) {
+        const uint8_t* px = row + (size_t)xe[k].si * c;
+        const float alpha = xe[k].a;
+        for (int ch = 0; ch < c; ++ch) { const float p = (float)px[ch] * alpha; buf[ch] = buf[ch] + p; }
+      }
+      for (int ch = 0; ch < c; ++ch) { const float p = beta * buf[ch]; sum[ch] = j == y0 ? p : sum[ch] + p; }
+    }
+    for (int ch = 0; ch < c; ++ch) out[i * c + ch] = (uint8_t)fminf(fmaxf(rintf(sum[ch]), 0.f), 255.f);
+  }
+}
+void op_cv_area_u8(const uint8_t* in, uint8_t* out, const void* xe, const int* xo, const void* ye, const int* yo, int n, int h, int w, int c, int oh, int ow,
+                   hipStream_t st) {
+  hipLaunchKernelGGL(k_cv_area_u8, grid1d((size_t)n * oh * ow), dim3(256), 0, st, in, out, (const CvAreaEnt*)xe, xo, (const CvAreaEnt*)ye, yo, n, h, w, c, oh, ow);
+  SS4K_LAUNCH_OK();
+}
+
 // one wave that occupies its stream for `ticks` of the 100 MHz real-time counter and does nothing else (ss4k_ctx::lane_check times a
 // pair of these to see whether two streams run side by side); bounded: every wave leaves after at most LANE_SPIN_MAX_TICKS
 constexpr unsigned LANE_SPIN_MAX_TICKS = 50000;   // 0.5 ms
