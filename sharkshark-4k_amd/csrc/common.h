@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <tuple>
@@ -89,8 +90,15 @@ struct ss4k_ctx {
   hipStream_t lane_stream_ = nullptr;
   hipEvent_t fork_event = nullptr, done_event = nullptr;
   hipStream_t lane_stream() {
-    if (!lane_stream_ && hipStreamCreateWithFlags(&lane_stream_, hipStreamNonBlocking) != hipSuccess)
-      throw ss4k::Error(SS4K_EHIP, "hipStreamCreateWithFlags failed");
+    if (!lane_stream_) {
+#ifdef SS4K_DEV
+      if (const char* e = std::getenv("SS4K_LANE_PRIO")) {   // A/B switch: priority of the lane stream (0 normal, -1 high, 1 low)
+        if (hipStreamCreateWithPriority(&lane_stream_, hipStreamNonBlocking, std::atoi(e)) != hipSuccess) throw ss4k::Error(SS4K_EHIP, "hipStreamCreateWithPriority failed");
+        return lane_stream_;
+      }
+#endif
+      if (hipStreamCreateWithFlags(&lane_stream_, hipStreamNonBlocking) != hipSuccess) throw ss4k::Error(SS4K_EHIP, "hipStreamCreateWithFlags failed");
+    }
     return lane_stream_;
   }
   static hipEvent_t untimed_event(hipEvent_t& e) {
