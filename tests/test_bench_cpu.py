@@ -97,3 +97,41 @@ def test_host_cpu_report():
     n, model = _bench().host_cpu()
     assert n == os.cpu_count() and isinstance(model, str) and model
     json.dumps({"host_cpu_count": n, "host_cpu_model": model})
+
+
+def test_live_traffic_declines_cleanly_and_aggregates_what_a_profiler_wrote(tmp_path, monkeypatch):
+    """`live_pmc_traffic` never costs the bench line: no rocprofv3 -> (None, reason); a run that is itself under a profiler -> (None, reason); a
+    counter pass that fails -> (None, reason).  And the aggregation it hands the passes to (tools/pmc_traffic.py) turns rocprofv3's
+    counter_collection.csv rows into bytes per step: FETCH_SIZE doubled, WRITE_SIZE as is, KB x 1024, only the 3x3 conv kernels."""
+    b = _bench()
+    import shutil
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    real_exists = os.path.exists
+    monkeypatch.setattr(os.path, "exists", lambda p: False if p == "/opt/rocm/bin/rocprofv3" else real_exists(p))
+    assert b.live_pmc_traffic(4) == (None, "rocprofv3 not found")
+    monkeypatch.setattr(shutil, "which", lambda name: "/bin/false")
+    monkeypatch.setenv("ROCPROFILER_SDK_TOOL", "1")
+    assert b.live_pmc_traffic(4) == (None, "this run is itself under a profiler")
+    monkeypatch.delenv("ROCPROFILER_SDK_TOOL")
+    monkeypatch.delenv("LD_PRELOAD", raising=False)
+    for k in [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_"))]:
+        monkeypatch.delenv(k)
+    got, why = b.live_pmc_traffic(4, timeout_s=30)          # "/bin/false -- python3 bench.py ..." exits with 1
+    assert got is None and "FETCH_SIZE pass exited with 1" in why
+    # the aggregation on two synthetic passes: 2 forwards of 3 conv launches + a kernel that must not be counted
+    for counter, d in (("FETCH_SIZE", tmp_path / "f"), ("WRITE_SIZE", tmp_path / "w")):
+        (d / "host" / "1").mkdir(parents=True)
+        rows = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value"]
+        for i, name in enumerate(["void ss4k::w16::conv3x3_w16_kernel<false, true>(ss4k::ConvArgs)", "void ss4k::dense::conv3x3_dense2_kernel<8, false>(ss4k::DenseArgs)",
+                                  "ss4k::w16n::conv3x3_w16n_kernel(ss4k::ConvArgs)", "ss4k::k_lane_spin(unsigned int)"] * 2):
+            rows.append(f'{i},"{name}",{counter},{1000.0 if counter == "FETCH_SIZE" else 300.0}')
+        (d / "host" / "1" / "x_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    out = tmp_path / "t.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), str(tmp_path / "f"), str(tmp_path / "w"), str(out), "2", "2", "4"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    import json
+    t = json.load(open(out))
+    assert t["launches_counted"] == 6 and t["steps"] == 2 and t["frames_per_launch"] == 2
+    assert t["traffic_bytes_per_step"] == (2 * 1000.0 + 300.0) * 1024 * 6 / 2
+    assert set(t["by_kernel"]) == {"conv3x3_w16_kernel", "conv3x3_dense2_kernel", "conv3x3_w16n_kernel"}
