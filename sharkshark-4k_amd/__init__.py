@@ -6,18 +6,34 @@ library (``csrc/`` -> ``libss4k_hip.so``, declared in ``include/ss4k.h``) for al
 There is no CPU fallback: constructing a context without the library or a GPU raises.
 """
 import os as _os
+import sys as _sys
 
-# Kernel arguments in device memory (a HIP runtime setting, read when the runtime is LOADED - which `import torch` does: a process that
-# imports torch first must already have these two in its environment, as bench.py and every spawned service worker do): a network forward is 213-351 launches with ~ 300-byte argument blocks, and fetching them from host memory costs
-# launch latency that the launch chains expose.  Headline job, one box, three interleaved processes each: 123.9 -> 125.0 frames/s (+ 0.9 %,
-# profiles/r05_kernarg_ab.txt).  setdefault: an integrator's own setting wins; service workers inherit it through the environment.
-_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
-# Eight hardware queues per process instead of HIP's four.  A service worker uses up to five streams that should run side by side (the
-# current stream, three job-set streams, the context's frame-lane stream); streams that share a hardware queue run in order, whatever the
-# program says (profiles/NOTES_r05.md 3).  Same A/B form: headline 124.9-125.6 either way; the SRVGG job of a process that had used many
-# streams lost its second launch chain in two of three runs at four queues (402 against 423 frames/s) and never at eight
-# (profiles/r05_hwq_ab.txt).  More queues are not only more room: some PAIRS of them are slow side by side (profiles/r05_lane_queue.txt), so
-# the library tests its lane stream (ss4k_ctx::lane_check) and the service its job-set streams (hip_upscaler._vetted_stream) whatever this is set to.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+#: The two HIP runtime settings this build's published numbers were measured with.  They are read when the runtime INITIALISES in a
+#: process, so they belong in the environment a worker process starts with - importing this package does NOT set them (an import-time
+#: side effect would reach a process that imported torch and touched the GPU first only by luck):
+#:  * ``BaseService.start()`` applies them (``setdefault``: an integrator's own value wins) before the worker process is created, so every
+#:    service worker - forked or spawned, single or one of a node's G - runs with them; ``bench.py`` sets them at its top;
+#:  * a process that calls the library IN-PROCESS (``_capi`` directly) sets them itself before its first GPU call, or accepts the defaults;
+#:    ``runtime_env_state()`` says which of the two it has.
+#: HIP_FORCE_DEV_KERNARG=1: kernel-argument blocks in device memory (a forward is 213-351 launches; + 0.9 % on the headline job,
+#: profiles/r05_kernarg_ab.txt).  GPU_MAX_HW_QUEUES=8: room for a worker's five side-by-side streams (profiles/r05_hwq_ab.txt); streams
+#: that share a hardware queue run in order and some queue PAIRS are slow (profiles/r05_lane_queue.txt), which the library and the service
+#: test for whatever this is set to (ss4k_stream_pair_check).
+RUNTIME_ENV = {"HIP_FORCE_DEV_KERNARG": "1", "GPU_MAX_HW_QUEUES": "8"}
+
+
+def apply_runtime_env(env=None):
+    """``setdefault`` the two settings into ``env`` (default: this process's environment, which child processes inherit)."""
+    env = _os.environ if env is None else env
+    for k, v in RUNTIME_ENV.items():
+        env.setdefault(k, v)
+    return env
+
+
+def runtime_env_state() -> dict:
+    """{name: (value in this process's environment or None, recommended)} - for logs; a GPU runtime that is already initialised read
+    whatever was there at that moment."""
+    return {k: (_os.environ.get(k), v) for k, v in RUNTIME_ENV.items()}
+
 
 __version__ = "0.1.0"

@@ -60,6 +60,9 @@ class Ss4kError(RuntimeError):
 
 
 _lib = None
+#: set once this process has created a library context = initialised the HIP runtime (BaseService.start_method reads it: a child forked
+#: from such a process cannot use the GPU)
+GPU_TOUCHED = False
 
 
 def lib() -> C.CDLL:
@@ -140,7 +143,11 @@ class Context:
         self.device_index = _dev_index(device)
         self.device = torch.device("cuda", self.device_index)
         h = C.c_void_p()
-        _check(lib().ss4k_ctx_create(self.device_index, C.byref(h)))
+        global GPU_TOUCHED
+        rc = lib().ss4k_ctx_create(self.device_index, C.byref(h))
+        # (a box without any GPU has no runtime to initialise: the failed attempt leaves the process as fork-safe as it was)
+        GPU_TOUCHED = GPU_TOUCHED or rc == 0 or torch.cuda.device_count() > 0
+        _check(rc)
         self._h = h
 
     def close(self):

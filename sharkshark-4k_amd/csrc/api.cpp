@@ -501,11 +501,17 @@ int ss4k_op_cv_area_resize_u8(ss4k_ctx* c, const uint8_t* in, uint8_t* out, size
       t.xe = put(xe.data(), xe.size() * sizeof(CvEnt)); t.xo = put(xo.data(), xo.size() * sizeof(int));
       t.ye = put(ye.data(), ye.size() * sizeof(CvEnt)); t.yo = put(yo.data(), yo.size() * sizeof(int));
       t.dev.ensure(t.host.size());
-      it = c->cv_area.emplace(key, std::move(t)).first;   // (the host copy moves with the entry: its buffer address does not change)
-      auto& e = it->second;
-      SS4K_HIP(hipMemcpyAsync(e.dev.ptr, e.host.data(), e.host.size(), hipMemcpyHostToDevice, (hipStream_t)s));
-      SS4K_HIP(hipEventCreateWithFlags(&e.uploaded, hipEventDisableTiming));
-      SS4K_HIP(hipEventRecord(e.uploaded, (hipStream_t)s));
+      // upload and event on the LOCAL table; only a complete entry enters the cache (a throw here leaves no half-built entry behind whose
+      // NULL event every later call for this shape would wait on).  Moving the table keeps its host buffer's address: the copy stays valid.
+      SS4K_HIP(hipMemcpyAsync(t.dev.ptr, t.host.data(), t.host.size(), hipMemcpyHostToDevice, (hipStream_t)s));
+      SS4K_HIP(hipEventCreateWithFlags(&t.uploaded, hipEventDisableTiming));
+      const hipError_t rec = hipEventRecord(t.uploaded, (hipStream_t)s);
+      if (rec != hipSuccess) {
+        (void)hipStreamSynchronize((hipStream_t)s);   // the copy above reads t.host: let it finish before the table dies
+        (void)hipEventDestroy(t.uploaded);
+        SS4K_HIP(rec);
+      }
+      it = c->cv_area.emplace(key, std::move(t)).first;
     }
     auto& e = it->second;
     SS4K_REQUIRE(out_capacity >= (size_t)n * e.oh * e.ow * ch, "cv area resize: output buffer too small (ss4k_op_cv_area_shape gives the size)");

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 namespace ss4k {
 
@@ -727,7 +728,15 @@ bool stream_pair_ok(hipStream_t caller, hipStream_t ls) {
 
 void ss4k_ctx::lane_check(hipStream_t caller) {
   if (lane_checked.count(caller)) return;
-  static const bool off = std::getenv("SS4K_NO_LANE_CHECK") != nullptr;
+  // SS4K_NO_LANE_CHECK (include/ss4k.h, INTEGRATION.md "Runtime settings") switches the test off; so does a profiler that has loaded itself into
+  // the process (rocprofv3 sets ROCP_TOOL_LIBRARIES / preloads librocprofiler-sdk): counter collection serialises kernels, every pair
+  // "fails", and six parked streams later the last one is used untested anyway
+  static const bool off = [] {
+    if (std::getenv("SS4K_NO_LANE_CHECK")) return true;
+    if (std::getenv("ROCP_TOOL_LIBRARIES")) return true;
+    const char* pre = std::getenv("LD_PRELOAD");
+    return pre && (std::strstr(pre, "rocprofiler") || std::strstr(pre, "roctracer"));
+  }();
   if (off) return;
   // (a stream that is being captured into a graph cannot be synchronised: the test waits for the first forward outside a capture)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -737,7 +746,16 @@ void ss4k_ctx::lane_check(hipStream_t caller) {
   for (int attempt = 0; attempt < 6; ++attempt) {
     // ... and beside the NULL stream: the usual place for a host to WAIT for the caller's stream (torch's current stream in a worker that runs
     // its jobs on side streams), and a queue that only waits slows its slow partner just as a busy one does
-    if (ss4k::stream_pair_ok(caller, lane_stream()) && (caller == nullptr || ss4k::stream_pair_ok(nullptr, lane_stream()))) break;
+    // The NULL-stream half launches on the legacy stream: skipped when the caller IS that stream, and when some OTHER stream of the process
+    // is under a global-mode graph capture (a legacy-stream launch would invalidate that capture: the runtime reports it as an error of
+    // hipStreamIsCapturing on the NULL stream).
+    bool null_probe = caller != nullptr;
+    if (null_probe) {
+      hipStreamCaptureStatus ncap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(nullptr, &ncap) != hipSuccess) { (void)hipGetLastError(); null_probe = false; }
+      else if (ncap != hipStreamCaptureStatusNone) null_probe = false;
+    }
+    if (ss4k::stream_pair_ok(caller, lane_stream()) && (!null_probe || ss4k::stream_pair_ok(nullptr, lane_stream()))) break;
     lane_parked.push_back(lane_stream_); lane_stream_ = nullptr; ++lane_replaced;   // (after 6 tries the last new stream is used untested)
   }
 }

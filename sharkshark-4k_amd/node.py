@@ -67,7 +67,8 @@ class UpscalerNode:
         svc = self.service_cls(device=self.devices[k], group=group, **self.service_kwargs)
         if self.output_shape != "unset":
             svc.output_shape = self.output_shape
-        svc.ready_event = mp.get_context(svc.mp_start_method).Event()
+        svc.mp_start_method = "spawn"   # the launcher may have touched the GPU (warm-up, device queries); workers are fresh interpreters
+        svc.ready_event = mp.get_context("spawn").Event()
         return svc
 
     # ------------------------------------------------------------------------------------------

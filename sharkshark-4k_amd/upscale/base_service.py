@@ -13,14 +13,26 @@ the pipelines drive it directly:
   the exception propagates and the worker dies; a full result queue drops the result with a warning;
 * the object itself is what gets pickled into the worker, minus its ``Process`` handle.
 
-Differences that matter on ROCm: the worker is spawned (a HIP context does not survive ``fork``), it
-blocks on the job queue instead of spinning, and on exit it flushes the result queue's feeder thread
-before it terminates so that the last results are not lost.
+Differences that matter on ROCm: it blocks on the job queue instead of spinning, on exit it flushes the result queue's feeder
+thread before it terminates so that the last results are not lost, and the START METHOD is chosen when ``start()`` runs
+(``mp_start_method = None``): the reference forks (``mp.Process`` on Linux), and its callers rely on it - the stream pipeline's
+``on_queue`` is a bound method of an object that owns two more services and their fork-context queues (``pipeline.py:29-58``), the
+image server's ``on_queue`` reads a module global that only a forked child inherits (``image_pipeline.py:38-47,54-64``); neither
+survives pickling into a spawned interpreter.  A HIP context, on the other hand, does not survive ``fork``.  Both callers start their
+services BEFORE anything in the parent touches the GPU, so: a parent whose GPU runtime is still untouched forks (exactly the
+reference's behaviour, nothing has to be picklable), a parent that already holds a HIP context (tests, ``bench.py``, the multi-GPU
+node's launcher after a warm-up) spawns a fresh interpreter and the service object travels by pickle.  ``mp_start_method = 'spawn'``
+/ ``'fork'`` pins the choice; forking a parent that has initialised the GPU is refused with an error instead of a hung child.  The
+queues are created from the spawn context either way (its semaphores are named, so they work in forked and in spawned children alike).
 
-Two additions the multi-GPU node (``node.py``) and the one-frame-job overlap (``hip_upscaler.py``) use, both inert by default:
+Two additions the multi-GPU node (``node.py``) and the jobs-in-flight overlap (``hip_upscaler.py``) use, both inert by default:
 ``ready_event`` (a ``multiprocessing.Event`` the worker sets when ``proc_init`` has returned, so that a launcher can wait for G
-workers without sending a job) and ``deliver_lag`` (results handed over - still in job order - that many jobs late while the queue
-keeps coming, and at once when it runs dry; ``proc_before_deliver(entry)`` runs right before a result leaves the worker).
+workers without sending a job) and HELD RESULTS: a service whose ``proc_job_recieved`` only ENQUEUES device work may keep up to
+``proc_deliver_lag()`` finished-looking results back (in job order) while it reads and enqueues the next jobs, so that a consumer
+callback that blocks on a result (``.cpu()``) does not stall the device.  A held result leaves as soon as ``proc_result_ready(entry)``
+says its device work is done (polled every ``_HELD_POLL_S`` while the job queue is idle, so an isolated request is never kept waiting
+for a successor), or when more than the lag are held; ``proc_before_deliver(entry)`` runs right before a result leaves the worker.
+The defaults (lag 0, always ready) are the reference's loop: every result leaves before the next job is read.
 """
 from __future__ import annotations
 
@@ -40,6 +52,7 @@ _RESULT_DEPTH = 32
 _COMMAND_DEPTH = 4096
 _EXIT = "exit"
 _IDLE_WAIT_S = 0.001
+_HELD_POLL_S = 0.0002   # job-queue wait while results are held back: bounds how long a finished result sits in the worker
 
 
 class ProcessDeadException(Exception):
@@ -52,21 +65,35 @@ def _interrupt_process_group(ex: BaseException) -> None:
     os.killpg(os.getpgid(os.getpid()), signal.SIGINT)
 
 
+def gpu_runtime_touched() -> bool:
+    """Has this process initialised the HIP runtime (through torch, through this package's library, or because a profiler that
+    preloads itself did it before ``main``)?  A child forked from such a process cannot use the GPU."""
+    import torch
+    if torch.cuda.is_initialized():
+        return True
+    capi = sys.modules.get(__name__.rsplit(".", 2)[0] + "._capi")
+    if capi is not None and getattr(capi, "GPU_TOUCHED", False):
+        return True
+    preload = " ".join(os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+    return "rocprofiler" in preload or "roctracer" in preload
+
+
 class BaseService(abc.ABC):
     on_queue = None
     exit_on_error = False
-    #: multiprocessing start method ('spawn': the parent may already hold a HIP context)
-    mp_start_method = "spawn"
-    #: results held back (in order) while later jobs are being enqueued; 0 = every result leaves before the next job is read
+    #: multiprocessing start method: None = fork while this process has not touched the GPU (the reference's method), else spawn
+    mp_start_method = None
+    #: most results held back (in order) while later jobs are being enqueued; 0 = every result leaves before the next job is read
     deliver_lag = 0
     #: set by the worker once proc_init() has returned (None: nobody waits for it)
     ready_event = None
 
     def __init__(self) -> None:
-        mpctx = mp.get_context(self.mp_start_method)
+        mpctx = mp.get_context("spawn")   # (named semaphores: usable from a forked and from a spawned worker)
         self.job_queue = mpctx.Queue(maxsize=_JOB_DEPTH)
         self.result_queue = mpctx.Queue(maxsize=_RESULT_DEPTH)
         self.cmd_queue = mpctx.Queue(maxsize=_COMMAND_DEPTH)
+        # callers read `proc` (sentinel, is_alive, exitcode) after start(); start() replaces it when the method turns out to be fork
         self.proc = mpctx.Process(target=self.proc_pre_main, daemon=True)
 
     def __getstate__(self):
@@ -86,6 +113,14 @@ class BaseService(abc.ABC):
 
     def proc_before_deliver(self, entry) -> None:
         """Runs in the worker right before ``entry`` is handed to ``on_queue`` / the result queue."""
+
+    def proc_deliver_lag(self) -> int:
+        """How many results may stay held right now (asked after every job: a service can make it depend on the newest job)."""
+        return self.deliver_lag
+
+    def proc_result_ready(self, entry) -> bool:
+        """Is the device work behind this held result finished (so that handing it over cannot block)?"""
+        return True
 
     def proc_pre_main(self) -> None:
         self.proc_main()
@@ -116,13 +151,14 @@ class BaseService(abc.ABC):
             held = collections.deque()
             while not self._exit_requested():
                 try:
-                    job = self.job_queue.get(timeout=_IDLE_WAIT_S)
+                    job = self.job_queue.get(timeout=_HELD_POLL_S if held else _IDLE_WAIT_S)
+                    held.append(self.proc_job_recieved(job))
                 except queue.Empty:
-                    while held:  # the queue ran dry: nothing left to overlap with
-                        self._deliver(held.popleft())
-                    continue
-                held.append(self.proc_job_recieved(job))
-                while len(held) > self.deliver_lag:
+                    pass
+                lag = self.proc_deliver_lag()
+                # in job order: whatever exceeds the lag leaves now (its consumer may block on it - the later jobs are already on the
+                # device), and the oldest results leave as soon as they are ready, successor or not
+                while held and (len(held) > lag or self.proc_result_ready(held[0])):
                     self._deliver(held.popleft())
             while held:
                 self._deliver(held.popleft())
@@ -138,7 +174,23 @@ class BaseService(abc.ABC):
         os.kill(os.getpid(), signal.SIGTERM)  # daemon threads of the runtime must not keep it alive
 
     # ---------------------------------------------------------------- client side
+    def start_method(self) -> str:
+        """'fork' or 'spawn' for a worker started NOW from this process (see the module docstring)."""
+        touched = gpu_runtime_touched()
+        method = self.mp_start_method
+        if method is None:
+            return "spawn" if touched else "fork"
+        if method == "fork" and touched:
+            raise RuntimeError(f"{type(self).__name__}: mp_start_method='fork' but this process has already initialised the GPU runtime - "
+                               "a forked child cannot use it; start the service before the first GPU call or leave mp_start_method=None")
+        return method
+
     def start(self) -> None:
+        method = self.start_method()
+        from .. import apply_runtime_env
+        apply_runtime_env()   # the worker's HIP runtime initialises in the child: it inherits this environment (setdefault, package __init__)
+        if method != "spawn":
+            self.proc = mp.get_context(method).Process(target=self.proc_pre_main, daemon=True)
         self.proc.start()
 
     def check_proc(self) -> None:

@@ -27,8 +27,9 @@ independent.  The reference builds one service on ``device=0`` (``src/sharkshark
 One-frame jobs (``overlap_jobs=True``, batched path only - the image server's caller, ``image_pipeline.py:54-64,280-287``): consecutive
 one-frame jobs alternate over ``overlap_sets`` (3) job sets (context + model + upscaler + stream), so that job i + 1's launches fill the
 launch boundaries and partly filled tile rounds of job i - what frame lanes do inside a multi-frame job.  Frames are bit-identical to the
-single-set path (same kernels, same weights).  The worker hands result i over after the next ``overlap_sets - 1`` jobs have been enqueued, or
-at once when the queue runs dry (``BaseService.deliver_lag``); ``upscale()`` called directly stays synchronous with the current stream unless ``wait=False``.
+single-set path (same kernels, same weights).  The worker keeps at most ``overlap_sets - 1`` results of ALTERNATING jobs back while it
+enqueues their successors, and hands each over as soon as its end event has fired (``BaseService``: held results; a multi-frame job flushes
+them and leaves at once, as in the reference's loop); ``upscale()`` called directly stays synchronous with the current stream unless ``wait=False``.
 Measured on one box (RRDBNet x2, 720p, ``profiles/r05_n1_probe_sets.txt``): one set 108.8 frames/s, two 122.8, three 125.6, four 124.9 -
 against 127.5 for four-frame jobs; two- and four-frame jobs gain nothing from alternating (125.5 / 125.7 against 125.0 / 127.5), so they
 stay on set 0.  Cost per extra set: a copy of the SR weights and activation workspace (RRDBNet x2 at 720p: 67 MB + 1.25 GB), built on the
@@ -46,7 +47,7 @@ import torch
 
 from .. import sharding
 from ..util.profiler import Profiler
-from .upscaler_base import BaseUpscalerService, UpscalerQueueEntry  # noqa: F401
+from .upscaler_base import BaseUpscalerService, UpscalerQueueEntry, record_span  # noqa: F401
 
 LR_LEVELS = [(360, 640), (540, 960), (630, 1120), (720, 1280), (900, 1600), (1080, 1920)]
 
@@ -66,8 +67,11 @@ class HipUpscalerService(BaseUpscalerService):
                  scale=4, model_name=None, dtype="f16", weights=None, checkpoint_dir: Optional[str] = None,
                  lr_shape=None, single_mode=None, seed=0, model_flags=0, fsrcnn_dtype="f32",
                  group: Optional[sharding.GroupSpec] = None, overlap_jobs=True, overlap_sets=3, overlap_max_frames=1):
-        if jit_mode not in (None, "hip"):
-            raise Exception(f"jit_mode={jit_mode!r}: this build has one backend, 'hip'")
+        # None (the stream pipeline's default: "the compiled backend", pipeline.py:23,41-44) and False (the image server: "eager",
+        # image_pipeline.py:58-61) both mean "whatever this build runs the network with" to a caller that cannot know about 'hip';
+        # a backend asked for BY NAME that this build does not have ('trt', 'jit', 'ds', 't2trt': realesrgan/factory.py:175-230) is refused
+        if not (jit_mode is None or jit_mode is False or jit_mode == "hip"):
+            raise Exception(f"jit_mode={jit_mode!r}: this build has one backend, 'hip' (None and False select it too)")
         if upscaler_model not in ("fsrcnn", "realesrgan"):
             raise Exception(upscaler_model)
         self.lr_shape = tuple(lr_shape) if lr_shape is not None else LR_LEVELS[lr_level]
@@ -195,9 +199,12 @@ class HipUpscalerService(BaseUpscalerService):
         if not (self.overlap_jobs and not self.single_mode):
             self._flats.pop("sr", None)      # (no second set will ever be built: drop the host copy)
         self._flats.pop("denoise", None)     # (the batched path never denoises)
-        # the worker hands result i over once jobs i + 1 .. i + sets - 1 have been enqueued: the wait for result i goes onto the current stream,
-        # which every later job's stream waits for before it starts - delivered any earlier, result i would hold back job i + sets - 1
+        # the most results the worker holds back (BaseService: held results).  While one-frame jobs alternate over the job sets, result i may
+        # wait until jobs i + 1 .. i + sets - 1 have been enqueued - the wait for result i goes onto the current stream, which every later job's
+        # stream waits for before it starts, and a consumer callback may block on it - but it leaves as soon as its end event has fired
+        # (proc_result_ready).  A job that does not alternate (multi-frame: frame lanes on set 0) sets the lag to 0 and flushes (proc_deliver_lag).
         self.deliver_lag = self.overlap_sets - 1 if self._overlap_active() else 0
+        self._lag_now = 0
 
     def _overlap_active(self) -> bool:
         return bool(self.overlap_jobs) and not self.single_mode and "sr" in getattr(self, "_flats", {})
@@ -328,6 +335,14 @@ class HipUpscalerService(BaseUpscalerService):
         if rec is not None:
             torch.cuda.current_stream(self.torch_device).wait_event(rec[1])
 
+    def proc_deliver_lag(self) -> int:
+        return getattr(self, "_lag_now", 0)   # set by upscale() from the path the NEWEST job took
+
+    def proc_result_ready(self, entry) -> bool:
+        pending = getattr(self, "_pending", None)
+        rec = pending.get(id(entry.frames)) if pending and getattr(entry, "frames", None) is not None else None
+        return rec is None or rec[1].query()
+
     def proc_cleanup(self):
         pass
 
@@ -340,8 +355,8 @@ class HipUpscalerService(BaseUpscalerService):
             # asynchronous stage launches, measured inside the library
             denoise_ms, model_ms = up.last_enqueue_ms()
             if self._sets[k]["denoise"] is not None:
-                prof.add("fsrcnn.denoise", denoise_ms / 1000.0)
-            prof.add("fsrcnn.model", model_ms / 1000.0)
+                record_span(prof, "fsrcnn.denoise", denoise_ms / 1000.0)
+            record_span(prof, "fsrcnn.model", model_ms / 1000.0)
         return out
 
     def upscale(self, frames: torch.Tensor, wait: bool = True):
@@ -354,6 +369,7 @@ class HipUpscalerService(BaseUpscalerService):
         if frames.ndim != 4:
             raise Exception(frames.shape)
         assert frames.shape[-1] == 3
+        self._lag_now = 0
         if not self._overlap_active():
             out = self._run(0, frames)
             if frames.is_cuda and hasattr(self, "_inflight"):   # (same hold on the input as below: see _retire)
@@ -365,6 +381,7 @@ class HipUpscalerService(BaseUpscalerService):
             if not self._streams_checked:
                 self._check_streams(frames)
             k, self._alt = self._alt, (self._alt + 1) % self.overlap_sets
+            self._lag_now = self.overlap_sets - 1   # (only while jobs alternate: the next ones have something to overlap with)
         cur = torch.cuda.current_stream(self.torch_device)
         side = self._job_set(k)["stream"]
         side.wait_stream(cur)   # the frames (an IPC tensor's ready event, a .to(device) copy) are ordered on the current stream

@@ -28,14 +28,40 @@ from .base_service import BaseService
 class UpscalerQueueEntry:
     frames: Optional[torch.Tensor] = None
     audio_segment: Any = None
-    step: int = 0
+    step: Any = 0          # the stream pipeline counts jobs (pipeline.py:98), the image server passes a sha1 string (image_pipeline.py:283)
     elapsed: float = 0
     last_modified: float = 0
     profiler: Optional[Profiler] = None
 
-    def answered_by(self, frames: torch.Tensor, elapsed: float) -> "UpscalerQueueEntry":
-        """The result record of this job: same step / audio / profiler, new frames and timing."""
-        return dataclasses.replace(self, frames=frames, elapsed=elapsed, last_modified=time.time())
+
+#: the six fields every caller's entry type has (reference: upscaler_base.py:17-24) - the only thing this package assumes about a job
+ENTRY_FIELDS = ("frames", "audio_segment", "step", "elapsed", "last_modified", "profiler")
+
+
+def answer(job, frames, elapsed: float, profiler):
+    """The result record of ``job``: same step / audio, new frames and timing - an entry of the CALLER's own type when that type takes the
+    six fields as keywords (the reference's dataclass does, and so does any stand-in shaped like it), else this package's entry.  Nothing
+    but the six fields is read from ``job``: a caller that imported ``UpscalerQueueEntry`` from its own tree keeps working."""
+    fields = dict(frames=frames, audio_segment=getattr(job, "audio_segment", None), step=getattr(job, "step", 0),
+                  elapsed=elapsed, last_modified=time.time(), profiler=profiler)
+    cls = type(job)
+    if cls is not UpscalerQueueEntry:
+        try:
+            return cls(**fields)
+        except TypeError:
+            pass
+    return UpscalerQueueEntry(**fields)
+
+
+def record_span(prof, name: str, seconds: float) -> None:
+    """Put a span that was timed elsewhere (inside the native library) under ``prof.data[name]``.  This package's profiler folds it into
+    the running mean (``add``); a caller's own profiler offers ``set / start / end / data`` only (reference: src/util/profiler.py:3-26) and
+    gets the value through ``set``."""
+    add = getattr(prof, "add", None)
+    if add is not None:
+        add(name, seconds)
+    else:
+        prof.set(name, seconds)
 
 
 class BaseUpscalerService(BaseService):
@@ -47,14 +73,18 @@ class BaseUpscalerService(BaseService):
     def upscale(self, frames: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError("an upscaler service implements upscale(uint8 NHWC) -> uint8 NHWC")
 
-    def proc_job_recieved(self, job: UpscalerQueueEntry) -> UpscalerQueueEntry:  # (sic) the reference's spelling
-        prof = job.profiler if job.profiler is not None else Profiler()
+    def proc_job_recieved(self, job):  # (sic) the reference's spelling
+        # only what the reference's own objects offer is used on `job` and its profiler (upscaler_base.py:17-24, util/profiler.py:3-26:
+        # the six fields; set / start / end / data): the callers build both from THEIR modules (pipeline.py:95-100, image_pipeline.py:280-287)
+        prof = job.profiler if getattr(job, "profiler", None) is not None else Profiler()
         self.profiler = prof  # upscale() implementations add their own spans to the job's profiler
         arrived = time.time()
         prof.end("recoder.output")
-        with prof.span("upscaler.upscale"):
+        prof.start("upscaler.upscale")
+        try:
             upscaled = self.upscale(job.frames)
-        result = job.answered_by(upscaled, elapsed=time.time() - arrived)
-        result.profiler = prof
+        finally:
+            prof.end("upscaler.upscale")
+        elapsed = time.time() - arrived
         prof.start("upscaler.output")
-        return result
+        return answer(job, upscaled, elapsed, prof)

@@ -9,6 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# in-process GPU tests run the library in the documented runtime configuration (set before the HIP runtime initialises in this process)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def pytest_configure(config):

@@ -114,12 +114,14 @@ def test_config2_rrdbnet_x2_720p_fp16_service_vs_oracle(ctx):
     p = psnr(got.float(), want.float(), peak=255.0)
     print(f"configs[2] fp16 vs oracle: PSNR {p:.2f} dB, max |delta| {int(d.max())} LSB, {float((d > 0).float().mean()):.4%} bytes differ")
     record_measured("config2_rrdbnet_x2_720p_fp16_service", psnr_db=p, max_lsb=int(d.max()), bytes_differ=float((d > 0).float().mean()),
-                    bytes_2lsb=int((d >= 2).sum()), asserted="PSNR >= 55.5 dB, max <= 3 LSB")
+                    bytes_2lsb=int((d >= 2).sum()), asserted="PSNR >= 55.5 dB, max <= 2 LSB, at most 16 bytes at 2 LSB")
     # measured 57.50 dB / 2 LSB - the 2 in ONE byte of 11 059 200 (profiles/r05_parity_measured.json: bytes_2lsb = 1); with either of the
     # two not-bit-identical route choices pinned off (NO_W16, NO_UPS_PRESUM) the worst byte is 1 LSB, with both off it is 2 again: a byte
-    # on a rounding edge that any change of summation order moves, not the cost of one route.  Asserted at measured - 2 dB / + 1 LSB.
+    # on a rounding edge that any change of summation order moves, not the cost of one route.  Asserted at measured - 2 dB, the measured
+    # worst byte, and a count: a handful of rounding-edge bytes may reach 2 LSB, thousands of them (or one byte at 3) is a regression.
     assert p >= 55.5, f"PSNR {p:.2f} dB"
-    assert int(d.max()) <= 3, f"max |delta| {int(d.max())} LSB"
+    assert int(d.max()) <= 2, f"max |delta| {int(d.max())} LSB"
+    assert int((d >= 2).sum()) <= 16, f"{int((d >= 2).sum())} bytes at 2 LSB"
     # which route costs what against the oracle (round 4 moved the worst byte from 1 to 2 LSB): each non-bit-identical choice pinned off in turn
     for tag, fl in (("no_ups_presum", _capi.MODEL_NO_UPS_PRESUM), ("no_w16", _capi.MODEL_NO_W16), ("no_w16_no_ups_presum", _capi.MODEL_NO_W16 | _capi.MODEL_NO_UPS_PRESUM)):
         sr_r = _capi.Model(ctx, _capi.make_desc(_capi.RRDBNET, _capi.F16, scale=2, flags=fl), W.flatten(table, W.rrdbnet_keys(23)))

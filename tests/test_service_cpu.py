@@ -25,6 +25,14 @@ class NearestDouble(BaseUpscalerService):
         return frames.repeat_interleave(2, 1).repeat_interleave(2, 2)
 
 
+class NearestDoubleKw(NearestDouble):
+    """The double with the constructor shape of the real service (``on_queue=`` keyword), for ``CallerPipeline``."""
+
+    def __init__(self, on_queue=None, **_):
+        super().__init__()
+        self.on_queue = on_queue
+
+
 class Boom(BaseUpscalerService):
     def proc_init(self):
         raise RuntimeError("init failed loudly")
@@ -106,11 +114,101 @@ def test_hip_service_configuration_mirrors_reference():
     with pytest.raises(Exception):
         HipUpscalerService(upscaler_model="egvsr")
     with pytest.raises(Exception):
-        HipUpscalerService(jit_mode="trt")
+        HipUpscalerService(jit_mode="trt")   # a backend asked for by name that this build does not have
+    # the callers' own literals: None (stream pipeline default) and False (the image server's "eager") select the one backend
+    for jm in (None, False, "hip"):
+        assert HipUpscalerService(denoising=False, jit_mode=jm).jit_mode == "hip"
+    image_server = HipUpscalerService(lr_level=3, device=0, denoising=False, denoise_rate=0.2, on_queue=None, upscaler_model="realesrgan",
+                                      batch_size=1, jit_mode=False, lr_hr_resize=False)   # the image server's constructor call, literally
+    assert image_server.single_mode is False and image_server.lr_hr_resize is False
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_hip_service_fails_loudly_without_gpu():
+    from sharkshark4k_amd import _capi
     svc = HipUpscalerService(denoising=False, upscaler_model="fsrcnn", scale=2)
     with pytest.raises(Exception):
         svc.proc_init()  # no silent CPU fallback
+    assert not _capi.GPU_TOUCHED   # no GPU, no runtime initialised: the process is as fork-safe as before
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The callers' OWN objects: a six-field record and a set/start/end/data profiler that are not this package's types (tests/caller_shapes.py)
+
+from tests.caller_shapes import CallerEntry, CallerPipeline, CallerProfiler  # noqa: E402
+
+
+@pytest.mark.parametrize("method", ["fork", "spawn"])
+def test_caller_shaped_entry_and_profiler_through_a_worker(method):
+    """A worker fed the caller's record and profiler: nothing but the six fields and set / start / end / data is touched, the result
+    is a record of the CALLER's type, a string step (the image server's sha1) passes through."""
+    svc = NearestDouble()
+    svc.mp_start_method = method
+    svc.start()
+    try:
+        for step in (0, "9f2c01aa", 2):
+            prof = CallerProfiler()
+            prof.start("recoder.output")
+            svc.push_job(CallerEntry(frames=torch.full((1, 4, 6, 3), 7, dtype=torch.uint8), audio_segment=torch.ones(5), step=step, profiler=prof))
+        got = [svc.get_result(timeout=120) for _ in range(3)]
+        assert [g.step for g in got] == [0, "9f2c01aa", 2]
+        for g in got:
+            assert type(g) is CallerEntry and type(g.profiler) is CallerProfiler
+            assert g.frames.shape == (1, 8, 12, 3) and int(g.frames.min()) == 7 and g.audio_segment.shape == (5,)
+            assert g.elapsed >= 0 and g.last_modified > 0
+            assert {"recoder.output", "upscaler.upscale"} <= set(g.profiler.data) and "upscaler.output" in g.profiler.opened
+    finally:
+        svc.stop()
+    assert svc.start_method() in ("fork", "spawn")
+
+
+def test_start_method_follows_the_gpu_state(monkeypatch):
+    from sharkshark4k_amd.upscale import base_service as bs
+    svc = NearestDouble()
+    monkeypatch.setattr(bs, "gpu_runtime_touched", lambda: False)
+    assert svc.start_method() == "fork"            # an untouched parent does what the reference does
+    monkeypatch.setattr(bs, "gpu_runtime_touched", lambda: True)
+    assert svc.start_method() == "spawn"           # a parent that holds a HIP context must not fork
+    svc.mp_start_method = "fork"
+    with pytest.raises(RuntimeError, match="already initialised the GPU"):
+        svc.start_method()
+    svc.mp_start_method = "spawn"
+    assert svc.start_method() == "spawn"
+
+
+@pytest.mark.parametrize("method", ["fork", "spawn"])
+def test_on_queue_as_bound_method_of_the_pipeline_that_owns_two_services(method):
+    """The stream caller's wiring: ``on_queue`` is a bound method of an object that holds the upscaler and the NEXT service; it runs
+    inside the upscaler's worker and pushes into the other service's queue from there.  Forked (the reference's way) nothing is
+    pickled; spawned, the whole pipeline object travels into the worker with the service."""
+    pipe = CallerPipeline(NearestDoubleKw)
+    pipe.upscaler.mp_start_method = pipe.sink.mp_start_method = method
+    pipe.start()
+    try:
+        for step in range(4):
+            prof = CallerProfiler()
+            prof.start("recoder.output")
+            pipe.upscaler.push_job_nowait(CallerEntry(frames=torch.full((2, 3, 5, 3), step, dtype=torch.uint8), audio_segment=torch.zeros(3),
+                                                      step=step, profiler=prof))
+        got = [pipe.sink.get_result(timeout=120) for _ in range(4)]
+        assert [g["step"] for g in got] == [0, 1, 2, 3]
+        for g in got:
+            assert g["shape"] == (2, 6, 10, 3) and g["sum"] == g["step"] * 2 * 6 * 10 * 3
+            assert {"upscaler.upscale", "upscaler.output", "upscaler.output.queue", "upscaler.output.frames.shape"} <= set(g["keys"])
+        assert pipe.forwarded == 0    # the callback ran in the worker's copy of the pipeline, not here
+    finally:
+        pipe.stop()
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference"), reason="container-only: drives the reference's own caller modules")
+def test_reference_callers_drive_the_service_with_one_import_swapped():
+    """`tests/golden/drive_reference_callers.py`: the reference's real ``TwitchUpscalerPostStreamer`` (recorder callback -> OUR worker ->
+    its ``upscaler_on_queue`` bound method -> its streamer's queue) and its real image-server module (its handler thread, its
+    ``start_pipeline()`` constructor call, its ``pipeline_onqueue`` global) run against a CPU double of ``HipUpscalerService`` - with the
+    reference's own ``UpscalerQueueEntry`` / ``Profiler`` / ``RecoderEntry`` / ``TwitchStreamerEntry`` objects in the queues."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "drive_reference_callers.py")], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DRIVE OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
