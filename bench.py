@@ -26,9 +26,9 @@ import os
 import sys
 import time
 
-# HIP runtime settings of the package (sharkshark-4k_amd/__init__.py: kernel arguments in device memory, eight hardware queues).  The runtime
-# reads them when it is LOADED - `import torch` does that - so a process that imports torch before the package has to have them in its
-# environment already (a service worker inherits them from its parent): set here, ahead of the import
+# HIP runtime settings of the package (sharkshark-4k_amd/__init__.py RUNTIME_ENV: kernel arguments in device memory, eight hardware queues).
+# They belong in the environment a process has BEFORE its HIP runtime comes up; importing the package does not set them (BaseService.start()
+# does, for the workers it creates).  This process is its own worker: set here, ahead of `import torch`
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -247,8 +247,12 @@ def run_timed(step, steps, warmup, world, sync, device):
         step()
     sync(); barrier(); sync()
     elapsed = time.perf_counter() - t0
+    run_timed.per_rank = [elapsed]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(every, t)      # (diagnostic: which rank was the slow one; outside the timed region)
+        run_timed.per_rank = [float(x.item()) for x in every]
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
@@ -317,6 +321,39 @@ def fsrcnn_stage_rooflines(svc, frames, psteps=3, half=False):
                             "peak_tflops": peak, "peak_is": unit, "frac": ach / peak}
     ctx.prof_enable(False)
     return stages
+
+
+def host_frames_leg(local, in_shape, batch, resident_fps, flops_per_frame, n_jobs=40, in_flight=3):
+    from sharkshark4k_amd.node import UpscalerNode
+    kw, _, _ = SERVICE_OF["rrdbnet"]
+    node = UpscalerNode(devices=[local], fps=24 if batch >= 4 else batch, frame_skips=False, weights="synthetic", seed=0, dtype="f16", lr_shape=in_shape, **kw)
+    node.start(timeout=600)
+    try:
+        job = node.dispatcher.small_batch_size
+        host = synthetic_frames(job, in_shape, seed=2000).numpy()       # frames in pageable host memory, as a recorder holds them
+        checksum = 0
+
+        def pump(n):
+            nonlocal checksum
+            sent = got = 0
+            while got < n:
+                while sent < n and sent - got < in_flight:
+                    sent += len(node.submit_batch(host))
+                for e in node.poll(0.002):
+                    assert not e.frames.is_cuda
+                    checksum += int(e.frames[0, 0, 0, 0])               # (the consumer touches the host result)
+                    got += 1
+        pump(10)
+        t1 = time.perf_counter(); pump(n_jobs); dt = time.perf_counter() - t1
+        rep = node.report()
+        fps = n_jobs * job / dt
+        return {"workload": WORKLOADS["rrdbnet"] + f", HOST frames in and out through node.UpscalerNode (one spawned worker; pinned shared-memory rings, H2D / D2H on the "
+                            f"worker's copy streams, {in_flight} jobs in flight): PCIe-inclusive, never the headline value",
+                "frames_per_step": job, "fps": fps, "of_resident_value": fps / resident_fps, "net_tflops": flops_per_frame * fps / 1e12,
+                "host_bytes_per_frame": in_shape[0] * in_shape[1] * 3 + 4 * in_shape[0] * in_shape[1] * 3, "report": {k: rep[k] for k in ("host_jobs", "host_fallback", "lost", "dropped")}}
+    finally:
+        node.stop()
+        node.close()
 
 
 def host_cpu():
@@ -400,6 +437,7 @@ def main():
                   else "upscaled frames/sec at 1080p->4K x4 (whole job)", "value": fps, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "per_rank_ms_per_step": [1000.0 * t / args.steps for t in run_timed.per_rank],   # each rank's own clock; ms_per_step is their max
         "dtype": "f32" if args.workload == "fsrcnn" else "f16", "data": "synthetic",
         "config": {"workload": WORKLOADS[args.workload], "frames_per_step_per_gpu": args.batch,
                    "in": [in_shape[0], in_shape[1], 3], "out": [oh, ow, 3], "io": "uint8 NHWC resident in HBM",
@@ -567,6 +605,13 @@ def main():
                                          "frames_per_step": 1, "fps": n_jobs / dt, "net_tflops": flops_per_frame * n_jobs / dt / 1e12}
         except Exception as e:  # never lose the headline line to a secondary measurement
             also["rrdbnet_n1_worker"] = {"error": f"{type(e).__name__}: {e}"}
+        # ... and HOST frames on both sides through the node (SURVEY 8(d) "with and without H2D/D2H"): UpscalerNode with one spawned worker on
+        # this GPU, numpy frames in host memory -> the worker's pinned input ring -> H2D on the worker's copy stream -> the job -> D2H into
+        # the pinned output ring -> a host view at the sink; 4-frame jobs, three in flight.  PCIe-inclusive: never the headline `value`.
+        try:
+            also["host_frames"] = host_frames_leg(local, in_shape, args.batch, fps, flops_per_frame)
+        except Exception as e:  # never lose the headline line to a secondary measurement
+            also["host_frames"] = {"error": f"{type(e).__name__}: {e}"}
         result["also"] = also
     if rank == 0 and "roofline" in result and args.workload == "rrdbnet" and world == 1 and not args.no_by_kernel:
         # per kernel build, from a ONE-CHAIN run of the same job (SS4K_MODEL_ONE_CHAIN: with two launch chains in flight a launch's

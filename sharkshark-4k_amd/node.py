@@ -7,8 +7,8 @@ them, and this class is everything an integrator needs around that::
     node = UpscalerNode(devices=8, upscaler_model="realesrgan", model_name="RealESRGAN_x2plus", denoising=False,
                         checkpoint_dir="/models")          # same keyword arguments as HipUpscalerService
     node.start()                                           # G spawned workers; rank 0 loads, RCCL broadcast, all ready
-    steps = node.submit_batch(frames_u8_nhwc)              # 1 s of frames -> jobs of min(4, fps) frames, job `step` -> GPU step % G
-    for entry in node.poll(timeout=0.1): sink(entry)       # results re-ordered by step
+    steps = node.submit_batch(frames_u8_nhwc)              # 1 s of HOST frames (numpy / CPU tensor) -> jobs of min(4, fps) frames, job `step` -> GPU step % G
+    for entry in node.poll(timeout=0.1): sink(entry)       # results re-ordered by step; entry.frames = a view of pinned host memory, valid until the next poll()
     node.stop()
 
 What it does, in order:
@@ -19,6 +19,11 @@ What it does, in order:
   when two workers share one or on CPU), ONLY RANK 0 reads / repacks / blends the checkpoints, ``sharding.broadcast_weights`` hands
   every blob to the others, and the group is left again: no collective ever runs on the data path;
 * ``start()`` returns when every worker has reported ready (``BaseService.ready_event``) - or raises if one died during start-up;
+* HOST FRAMES are the node's native input (``hostring.py``; the reference's recorder / streamer processes hold host numpy frames,
+  ``pipeline.py:84-93``, ``streamer.py:92-98``): per worker, two rings of ``host_slots`` pinned shared-memory slots sized for one job of
+  ``host_frames`` = (H, W) frames in and its result out are created HERE, once, before the worker starts; worker k copies job frames to
+  and from GPU k on its own copy streams with two jobs in flight; the parent never opens a HIP context.  A device tensor given to
+  ``submit_batch`` passes through as before (one on the wrong GPU is copied over by the worker and counted in ``report()['peer_copies']``);
 * a ``StreamDispatcher`` fans jobs out ``step % G`` over the LIVING workers and re-orders results by ``step``;
 * a worker that dies later is routed around at once (the node runs on G - 1; the jobs that were inside it are counted in
   ``report()['lost']``); ``replace_dead()`` starts a new child in its slot - a world-of-one worker that loads the weights itself, as
@@ -30,7 +35,7 @@ import socket
 import time
 from typing import List, Optional, Sequence, Union
 
-from . import sharding
+from . import hostring, sharding
 from .stream import StreamDispatcher
 from .upscale.hip_upscaler import HipUpscalerService
 
@@ -44,7 +49,7 @@ def _free_port() -> int:
 class UpscalerNode:
     def __init__(self, devices: Union[int, Sequence[int], None] = None, service_cls=HipUpscalerService, backend: Optional[str] = None,
                  fps: int = 24, frame_skips: bool = True, on_result=None, lost_after_s: float = 5.0, force_group: bool = False,
-                 output_shape="unset", **service_kwargs):
+                 output_shape="unset", host_frames=True, host_slots: int = 6, **service_kwargs):
         if devices is None:
             import torch
             devices = torch.cuda.device_count()   # (counting devices does not initialise the GPU in this process)
@@ -55,6 +60,9 @@ class UpscalerNode:
             backend = "gloo"   # RCCL refuses two ranks on one GPU: workers that share a device exchange the weights through host memory
         self.service_cls, self.service_kwargs, self.backend, self.force_group = service_cls, dict(service_kwargs), backend, force_group
         self.output_shape = output_shape   # the pipelines overwrite this attribute on the service object (pipeline.py:46-50)
+        # host-frame rings per worker: True = sized for jobs of min(4, fps) frames of the service's lr_shape; (H, W) = of that frame size
+        # (a recorder that delivers frames bigger than lr_shape, which the service area-resizes); None / False = no rings
+        self.host_frames, self.host_slots, self.job_frames = host_frames, int(host_slots), min(4, int(fps))
         self.port = _free_port()
         self.services = [self._make_service(k, len(self.devices)) for k in range(len(self.devices))]
         self.dispatcher = StreamDispatcher(self.services, fps=fps, frame_skips=frame_skips, on_result=on_result, lost_after_s=lost_after_s)
@@ -67,6 +75,10 @@ class UpscalerNode:
         svc = self.service_cls(device=self.devices[k], group=group, **self.service_kwargs)
         if self.output_shape != "unset":
             svc.output_shape = self.output_shape
+        if self.host_frames:
+            h, w = svc.lr_shape if self.host_frames is True else self.host_frames
+            oh, ow = svc.out_hw(h, w)
+            svc.host_rings = hostring.make_rings(self.host_slots, self.job_frames * h * w * 3, self.job_frames * oh * ow * 3)
         svc.mp_start_method = "spawn"   # the launcher may have touched the GPU (warm-up, device queries); workers are fresh interpreters
         svc.ready_event = mp.get_context("spawn").Event()
         return svc
@@ -106,9 +118,16 @@ class UpscalerNode:
             fresh.append(svc)
         self._wait_ready(fresh, timeout)
         for k, svc in zip(slots, fresh):
+            old = self.services[k]
             self.services[k] = svc
             self.dispatcher.services[k] = svc
+            self._close_rings(old)
         return slots
+
+    @staticmethod
+    def _close_rings(svc) -> None:
+        for ring in getattr(svc, "host_rings", None) or ():
+            ring.close()
 
     # ------------------------------------------------------------------------------------------ the stream caller's interface
     def submit_batch(self, frames, audio_segment=None, profiler=None):
@@ -140,6 +159,11 @@ class UpscalerNode:
                     svc.proc.join(timeout=15)
             codes.append(svc.proc.exitcode)
         return codes
+
+    def close(self) -> None:
+        """Give the host rings back (after ``stop()``; views handed out by ``poll()`` die with them)."""
+        for svc in self.services:
+            self._close_rings(svc)
 
     def __enter__(self):
         return self.start() if not self.started else self

@@ -13,6 +13,13 @@ Restates what the reference's ``TwitchUpscalerPostStreamer`` does around the ups
   (``pipeline.py:140-149``);
 * a worker process that has died is routed around at once: its steps go to the next living service (the node runs on G - 1), and a
   step whose result can no longer come back because the worker it was queued in is gone is declared lost without waiting;
+* HOST frames (numpy arrays / CPU tensors) go through the target worker's pinned rings when it has them (``hostring.py``, allocated by
+  ``node.UpscalerNode``): the job is copied into a free input slot, a ~ 100-byte descriptor travels through the queue, the worker moves
+  the frames to and from ITS GPU on its own copy streams, and the result handed to the sink is a zero-copy view of the worker's output
+  ring, VALID UNTIL THE NEXT ``poll()`` (``drain()`` hands out copies).  No free slot counts as a full queue (frame skip), or - with
+  ``frame_skips=False`` - is waited for while finished results are copied out of the rings to make room.  Device tensors pass through
+  untouched (a tensor on another GPU than the worker's is copied over once by the worker: ``report()['peer_copies']``); host frames for a
+  worker without rings, or bigger than a slot, travel as pickled tensors the old way (``report()['host_fallback']``);
 * a result that never arrives (a worker died, or ``BaseService`` dropped it on a full result queue)
   must not stall a 24/7 stream: a step that keeps later results waiting for more than
   ``lost_after_s`` seconds, or behind more than ``max_reorder`` pending results, is declared lost,
@@ -28,6 +35,7 @@ from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
 
+from .hostring import HostFrames, SlotPool
 from .upscale.upscaler_base import UpscalerQueueEntry
 from .util.profiler import Profiler
 
@@ -55,6 +63,15 @@ class StreamDispatcher:
         self.lost_after_s = lost_after_s
         self._stalled_since: Optional[float] = None
         self.last_reported = time.time()
+        # host-frame rings: slot accounting per worker (keyed by the service object), the slots a queued step holds, and the output slots
+        # whose views the last poll() handed out (given back at the start of the next one)
+        self._slots: Dict[object, tuple] = {}     # step -> (service, input slot, output slot); ('view', step) -> (service, output slot)
+        self._lent: List[tuple] = []              # (service, output slot) behind the views the last poll() handed out
+        self._lent_steps = set()
+        self.host_jobs_total = 0
+        self.host_fallback_total = 0
+        self._peer_copies: Dict[int, int] = {}    # service index -> the worker's running count, from its latest result
+        self.push_timeout = 10.0
 
     @property
     def dropped(self) -> List[int]:
@@ -79,6 +96,45 @@ class StreamDispatcher:
                 return svc
         raise RuntimeError("StreamDispatcher: no living upscaler worker")
 
+    # ------------------------------------------------------------------------------------------ host-frame rings
+    def _pool(self, svc) -> Optional[SlotPool]:
+        rings = getattr(svc, "host_rings", None)
+        if rings is None:
+            return None
+        pool = svc.__dict__.get("_slot_pool")      # (parent-side state kept on the service object: a replaced worker brings its own)
+        if pool is None:
+            pool = svc.__dict__["_slot_pool"] = SlotPool(rings[0].slots)
+        return pool
+
+    def _release_lent(self) -> None:
+        for svc, out_slot in self._lent:
+            self._pool(svc).give_out(out_slot)
+        self._lent.clear()
+        self._lent_steps.clear()
+
+    def _own_result(self, e) -> None:
+        """Turn a pending result that is still a ring view into a tensor of its own and give the slot back (slow path: only when the
+        rings run out because the consumer is behind)."""
+        held = self._slots.pop(("view", e.step), None)
+        if held is not None:
+            e.frames = e.frames.clone()
+            self._pool(held[0]).give_out(held[1])
+
+    def _take_slots(self, svc, wait: bool):
+        pool = self._pool(svc)
+        got = pool.take()
+        if got is not None or not wait:
+            return got
+        deadline = time.monotonic() + self.push_timeout
+        while got is None and time.monotonic() < deadline:   # (views the last poll() handed out stay valid: only pending results are moved)
+            self._collect()
+            for e in self._pending.values():          # finished results waiting for an earlier step: copy them out of the ring
+                self._own_result(e)
+            got = pool.take()
+            if got is None:
+                time.sleep(0.0005)
+        return got
+
     # pipeline.py:61-108
     def submit_batch(self, frames, audio_segment=None, profiler: Optional[Profiler] = None) -> List[int]:
         """Cut one recorder batch into jobs and fan them out; returns the steps actually queued."""
@@ -88,25 +144,43 @@ class StreamDispatcher:
         queued = []
         for i in range(njobs):
             profiler.start("recoder.output.entry")
-            chunk = torch.as_tensor(frames[i * self.small_batch_size:(i + 1) * self.small_batch_size])
+            chunk = frames[i * self.small_batch_size:(i + 1) * self.small_batch_size]
             audio = None
             if audio_segment is not None:
                 per = len(audio_segment) // njobs
                 audio = torch.as_tensor(audio_segment[i * per:(i + 1) * per])
             step = self.frame_step
             self.frame_step += 1
-            entry = UpscalerQueueEntry(frames=chunk, audio_segment=audio, step=step, profiler=profiler)
-            profiler.set("recoder.output.frames.shape", str(tuple(chunk.shape)))
-            profiler.end("recoder.output.entry")
             svc = self._pick(step)
+            slots = None
             try:
+                on_host = not (isinstance(chunk, torch.Tensor) and chunk.is_cuda)
+                if on_host and self._pool(svc) is not None and svc.host_rings[0].fits(chunk.shape):
+                    slots = self._take_slots(svc, wait=not self.frame_skips)
+                    if slots is None:
+                        raise queue.Full
+                    shape = svc.host_rings[0].write(slots[0], chunk)
+                    payload = HostFrames(slot=slots[0], out_slot=slots[1], shape=shape)
+                    self.host_jobs_total += 1
+                else:
+                    payload = torch.as_tensor(chunk)
+                    shape = tuple(payload.shape)
+                    self.host_fallback_total += int(on_host)
+                entry = UpscalerQueueEntry(frames=payload, audio_segment=audio, step=step, profiler=profiler)
+                profiler.set("recoder.output.frames.shape", str(shape))
+                profiler.end("recoder.output.entry")
                 if self.frame_skips:
                     svc.push_job_nowait(entry)
                 else:
-                    svc.push_job(entry)
+                    svc.push_job(entry, timeout=self.push_timeout)
                 queued.append(step)
                 self._owner[step] = svc
+                if slots is not None:
+                    self._slots[step] = (svc, slots[0], slots[1])
             except queue.Full:
+                if slots is not None:
+                    self._pool(svc).give_in(slots[0])
+                    self._pool(svc).give_out(slots[1])
                 self._dropped.add(step)
                 self.dropped_total += 1
                 print("StreamDispatcher: upscaler queue full, job skipped", file=sys.stderr)
@@ -135,7 +209,8 @@ class StreamDispatcher:
                     gone = [s for s in range(self.next_emit, nxt) if s not in self._dropped]
                     self.lost_total += len(gone)
                     for g in gone:
-                        self._owner.pop(g, None)
+                        self._owner.pop(g, None)   # (ring slots of a lost step stay taken: its worker may still write the result; they
+                                                    #  come back with a late result, or go with the worker)
                     self._dropped.difference_update(range(self.next_emit, nxt))
                     print(f"StreamDispatcher: step(s) {gone} never came back, skipped", file=sys.stderr)
                     self.next_emit = nxt
@@ -153,27 +228,52 @@ class StreamDispatcher:
                 self.on_result(e)
         return out
 
-    def poll(self, timeout: float = 0.0) -> List[UpscalerQueueEntry]:
-        """Collect finished jobs from every service and return those that can be emitted in order."""
-        deadline = time.monotonic() + timeout
-        while True:
-            got_any = False
-            for svc in self.services:
+    def _collect(self) -> bool:
+        """Read every service's result queue into ``_pending``; host results become views of the worker's output ring."""
+        got_any = False
+        for k, svc in enumerate(self.services):
+            while True:
                 try:
                     e = svc.result_queue.get_nowait()
-                    got_any = True
-                    if e.step < self.next_emit:
-                        # its step was already passed (declared lost after lost_after_s, or skipped): emitting it now would
-                        # put a stale frame behind newer ones and rewind next_emit, so it is counted and dropped
-                        self.late_total += 1
-                        print(f"StreamDispatcher: result of step {e.step} arrived late (stream is at {self.next_emit}), discarded", file=sys.stderr)
-                        continue
-                    self._pending[e.step] = e
-                    self._owner.pop(e.step, None)
                 except queue.Empty:
-                    pass
+                    break
+                got_any = True
+                held = self._slots.pop(e.step, None)
+                if isinstance(e.frames, HostFrames):
+                    e.frames = svc.host_rings[1].view(e.frames.out_slot, e.frames.shape)
+                    if held is not None:
+                        self._pool(svc).give_in(held[1])                    # the input slot is free once the result exists
+                        self._slots[("view", e.step)] = (svc, held[2])      # the output slot stays taken while the view is out
+                prof = getattr(e, "profiler", None)
+                if prof is not None and "upscaler.input.peer_copies" in getattr(prof, "data", {}):
+                    self._peer_copies[k] = int(prof.data["upscaler.input.peer_copies"])
+                if e.step < self.next_emit:
+                    # its step was already passed (declared lost after lost_after_s, or skipped): emitting it now would
+                    # put a stale frame behind newer ones and rewind next_emit, so it is counted and dropped
+                    self.late_total += 1
+                    print(f"StreamDispatcher: result of step {e.step} arrived late (stream is at {self.next_emit}), discarded", file=sys.stderr)
+                    view = self._slots.pop(("view", e.step), None)
+                    if view is not None:
+                        self._pool(view[0]).give_out(view[1])
+                    continue
+                self._pending[e.step] = e
+                self._owner.pop(e.step, None)
+        return got_any
+
+    def poll(self, timeout: float = 0.0) -> List[UpscalerQueueEntry]:
+        """Collect finished jobs from every service and return those that can be emitted in order.  Frames that came back through a
+        worker's host ring are views of it: valid until the next call of ``poll()``."""
+        self._release_lent()
+        deadline = time.monotonic() + timeout
+        while True:
+            got_any = self._collect()
             ready = self._emit_ready(force=len(self._pending) > self.max_reorder)
             if ready or time.monotonic() >= deadline:
+                for e in ready:
+                    view = self._slots.pop(("view", e.step), None)
+                    if view is not None:
+                        self._lent.append(view)
+                        self._lent_steps.add(e.step)
                 return ready
             if not got_any:
                 time.sleep(0.001)
@@ -183,11 +283,14 @@ class StreamDispatcher:
         deadline = time.monotonic() + timeout
         while want and time.monotonic() < deadline:
             for e in self.poll(timeout=0.05):
+                if e.step in self._lent_steps:
+                    e.frames = e.frames.clone()   # (a ring view would not survive the next poll(): drain() collects over many)
                 out.append(e)
                 want.discard(e.step)
         return out
 
     def report(self) -> dict:
         return {"frame_step": self.frame_step, "dropped": self.dropped_total, "lost": self.lost_total, "late": self.late_total,
-                "pending": len(self._pending), "rerouted": self.rerouted_total,
+                "pending": len(self._pending), "rerouted": self.rerouted_total, "host_jobs": self.host_jobs_total,
+                "host_fallback": self.host_fallback_total, "peer_copies": [self._peer_copies.get(k, 0) for k in range(len(self.services))],
                 "upscaler.inputq": [s.job_queue.qsize() for s in self.services]}

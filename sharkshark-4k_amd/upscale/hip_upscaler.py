@@ -35,6 +35,12 @@ against 127.5 for four-frame jobs; two- and four-frame jobs gain nothing from al
 stay on set 0.  Cost per extra set: a copy of the SR weights and activation workspace (RRDBNet x2 at 720p: 67 MB + 1.25 GB), built on the
 first one-frame job.  HIP serves a process's streams from a few hardware queues: the sets' streams are checked once to really run side by
 side (``_check_streams``).
+
+Host frames (``host_rings``, set by ``node.UpscalerNode``; ``hostring.py``): a job whose ``frames`` is a ``HostFrames`` descriptor names a slot
+of this worker's pinned input ring; the worker copies it to the device on its own copy stream, runs the job, copies the result into the
+named slot of the pinned output ring on a second copy stream and answers with a descriptor.  One more job is enqueued before a result is
+waited for (two jobs in flight), so both copies run under the neighbouring jobs' kernels (``pipeline.py:84-93`` / ``streamer.py:92-98`` are the
+reference's host <-> device hops).  A device tensor that lives on ANOTHER GPU is copied over once, counted in ``'upscaler.input.peer_copies'``.
 """
 from __future__ import annotations
 
@@ -46,8 +52,9 @@ from typing import Mapping, Optional
 import torch
 
 from .. import sharding
+from ..hostring import HostFrames
 from ..util.profiler import Profiler
-from .upscaler_base import BaseUpscalerService, UpscalerQueueEntry, record_span  # noqa: F401
+from .upscaler_base import BaseUpscalerService, UpscalerQueueEntry, answer, record_span  # noqa: F401
 
 LR_LEVELS = [(360, 640), (540, 960), (630, 1120), (720, 1280), (900, 1600), (1080, 1920)]
 
@@ -60,6 +67,8 @@ def log(*args, **kwargs):
 
 class HipUpscalerService(BaseUpscalerService):
     profiler: Profiler
+    #: (input ring, output ring) of pinned shared host memory for ``HostFrames`` jobs (hostring.py); None: every job carries a tensor
+    host_rings = None
 
     def __init__(self, lr_level=3, device=0, on_queue=None, denoising=True, denoise_rate=1.0,
                  upscaler_model="realesrgan", batch_size=1, jit_mode="hip", lr_hr_resize=True,
@@ -102,6 +111,26 @@ class HipUpscalerService(BaseUpscalerService):
         self.overlap_max_frames = int(overlap_max_frames)        # jobs of up to this many frames alternate (bigger ones overlap with themselves: frame lanes)
         super().__init__()
 
+    def net_scale(self) -> int:
+        """The SR network's own factor (no GPU needed: from the model name / ``scale``)."""
+        from . import model as factory
+        if self.upscaler_model == "fsrcnn":
+            return int(self.scale)
+        kind, kw = factory.REALESRGAN_ZOO[self.model_name or factory.DEFAULT_REALESRGAN]
+        return int(kw["scale"] if kind == "rrdbnet" else kw["upscale"])
+
+    def out_hw(self, h: int, w: int):
+        """(H, W) of the frames ``upscale`` returns for ``h x w`` input frames - the rule of ``ss4k_upscaler_out_shape`` (csrc/api.cpp
+        ``Upscaler::out_shape``; reference: fsrcnn_upscaler.py:174-176,223-233,236-241,316-326), evaluated on the host so that a launcher
+        without a HIP context can size result buffers."""
+        lh, lw = h, w
+        if self.single_mode or ((w > self.lr_shape[1] or h > self.lr_shape[0]) and self.lr_hr_resize):
+            lh, lw = self.lr_shape
+        if self.output_shape is not None and (self.single_mode or self.lr_hr_resize):
+            return int(self.output_shape[0]), int(self.output_shape[1])
+        k = self.net_scale()
+        return lh * k, lw * k
+
     # worker side -----------------------------------------------------------------------------
     def proc_main(self):
         self._in_worker = True   # results leave through _deliver: proc_before_deliver orders them on the current stream
@@ -139,6 +168,7 @@ class HipUpscalerService(BaseUpscalerService):
         with self._node_group():
             self._build_models()   # (weights resolved on rank 0 only, see _shared_flat)
         self._init_job_sets()
+        self._init_host_io()
         log("model loaded")
 
     def _open_device(self):
@@ -205,6 +235,88 @@ class HipUpscalerService(BaseUpscalerService):
         # (proc_result_ready).  A job that does not alternate (multi-frame: frame lanes on set 0) sets the lag to 0 and flushes (proc_deliver_lag).
         self.deliver_lag = self.overlap_sets - 1 if self._overlap_active() else 0
         self._lag_now = 0
+
+    def _init_host_io(self):
+        self._peer_copies = 0
+        self._host_jobs = 0
+        if not hasattr(self, "_pending"):
+            self._pending = {}
+        if self.host_rings is None:
+            return
+        self._host_on_gpu = self.torch_device.type == "cuda"   # (a CPU double of the worker - tests - reads and writes the rings directly)
+        if not self._host_on_gpu:
+            return
+        for ring in self.host_rings:
+            ring.pin()
+        self._s_in, self._s_out = torch.cuda.Stream(self.torch_device), torch.cuda.Stream(self.torch_device)
+        self._stage = {}    # input shape -> [[device tensor, event after which it may be overwritten], ...], used round robin
+        self._stage_at = {}
+        log(f"host frame rings pinned: {self.host_rings[0].slots} slots, {self.host_rings[0].slot_bytes >> 10} KB in / {self.host_rings[1].slot_bytes >> 10} KB out each")
+
+    def _staging(self, shape):
+        """A device tensor for one job's input frames.  More of them than jobs can be in flight, each guarded by the end event of the job
+        that last read it (the copy stream waits for it before it overwrites the tensor)."""
+        bufs = self._stage.setdefault(shape, [])
+        depth = self.overlap_sets + 2
+        if len(bufs) < depth:
+            bufs.append([torch.empty(shape, dtype=torch.uint8, device=self.torch_device), None])
+            return bufs[-1]
+        i = self._stage_at.get(shape, 0)
+        self._stage_at[shape] = (i + 1) % depth
+        return bufs[i]
+
+    def _host_job(self, hf: HostFrames):
+        """H2D on the copy stream -> upscale -> D2H on the other copy stream; returns (result shape, event after which the result slot holds
+        the frames - None when it already does)."""
+        src = self.host_rings[0].view(hf.slot, hf.shape)
+        if not self._host_on_gpu:
+            out = self.upscale(src)
+            self.host_rings[1].view(hf.out_slot, tuple(out.shape)).copy_(out)
+            return tuple(out.shape), None
+        cur = torch.cuda.current_stream(self.torch_device)
+        stage = self._staging(tuple(hf.shape))
+        with torch.cuda.stream(self._s_in):
+            if stage[1] is not None:
+                self._s_in.wait_event(stage[1])
+            stage[0].copy_(src, non_blocking=True)
+            copied = self._s_in.record_event()
+        cur.wait_event(copied)
+        out = self.upscale(stage[0])
+        rec = self._pending.pop(id(out), None)           # (job-set path: the result is ordered on its set's stream, not on the current one)
+        done = rec[1] if rec is not None else cur.record_event()
+        stage[1] = done
+        with torch.cuda.stream(self._s_out):
+            self._s_out.wait_event(done)
+            self.host_rings[1].view(hf.out_slot, tuple(out.shape)).copy_(out, non_blocking=True)
+            landed = self._s_out.record_event()
+        out.record_stream(self._s_out)
+        return tuple(out.shape), landed
+
+    def proc_job_recieved(self, job):
+        if not isinstance(getattr(job, "frames", None), HostFrames):
+            return super().proc_job_recieved(job)
+        # the same spans as BaseUpscalerService.proc_job_recieved, around the host job
+        import time
+        hf = job.frames
+        if self.host_rings is None:
+            raise RuntimeError("a HostFrames job reached a worker that was started without host rings")
+        prof = job.profiler if getattr(job, "profiler", None) is not None else Profiler()
+        self.profiler = prof
+        arrived = time.time()
+        prof.end("recoder.output")
+        prof.start("upscaler.upscale")
+        try:
+            shape, landed = self._host_job(hf)
+        finally:
+            prof.end("upscaler.upscale")
+        self._host_jobs += 1
+        answer_frames = HostFrames(slot=hf.slot, out_slot=hf.out_slot, shape=shape, result=True)
+        if landed is not None:
+            self._lag_now = max(getattr(self, "_lag_now", 0), 1)   # one more job is enqueued before this result is waited for: the copies hide under it
+            self._pending[id(answer_frames)] = (answer_frames, landed, "host")
+        prof.set("upscaler.input.peer_copies", self._peer_copies)
+        prof.start("upscaler.output")
+        return answer(job, answer_frames, time.time() - arrived, prof)
 
     def _overlap_active(self) -> bool:
         return bool(self.overlap_jobs) and not self.single_mode and "sr" in getattr(self, "_flats", {})
@@ -332,7 +444,9 @@ class HipUpscalerService(BaseUpscalerService):
         # (on_queue, or the IPC event torch records when the tensor is pickled into the result queue) - waits for it here
         pending = getattr(self, "_pending", None)
         rec = pending.pop(id(entry.frames), None) if pending and getattr(entry, "frames", None) is not None else None
-        if rec is not None:
+        if rec is not None and len(rec) > 2:
+            rec[1].synchronize()     # a host result: the consumer sits in another process and reads the ring slot - the bytes must have landed
+        elif rec is not None:
             torch.cuda.current_stream(self.torch_device).wait_event(rec[1])
 
     def proc_deliver_lag(self) -> int:
@@ -365,6 +479,11 @@ class HipUpscalerService(BaseUpscalerService):
         stream like any torch op."""
         assert isinstance(frames, torch.Tensor)
         if frames.device != self.torch_device:
+            if frames.is_cuda:   # a device tensor from ANOTHER GPU (the caller put job s somewhere else than on GPU s % G): one peer copy, counted
+                self._peer_copies = getattr(self, "_peer_copies", 0) + 1
+                prof = getattr(self, "profiler", None)
+                if prof is not None:
+                    prof.set("upscaler.input.peer_copies", self._peer_copies)
             frames = frames.to(self.torch_device, non_blocking=True)
         if frames.ndim != 4:
             raise Exception(frames.shape)

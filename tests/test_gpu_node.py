@@ -49,6 +49,63 @@ def test_node_world1_nccl_through_the_launcher(want):
     assert node.alive() == [False]
 
 
+def test_node_host_frames_through_the_pinned_rings(want):
+    """Host frames are the node's native input: numpy frames -> the worker's pinned input ring -> H2D on the WORKER's copy stream -> the
+    job -> D2H into the pinned output ring -> a host view at the sink.  Bit-identical to the resident path; 4-frame and 1-frame jobs
+    (the latter alternate over the job sets with two more in flight), more jobs than ring slots."""
+    frames, ref = want
+    for fps, nslots in ((24, 3), (1, 6)):
+        node = UpscalerNode(devices=[0], fps=fps, frame_skips=False, host_slots=nslots, **KW)
+        with node:
+            got = {}
+            host = frames.numpy()
+            for rep in range(3):     # 3 x 12 frames: 9 jobs of four (3 slots) / 36 jobs of one (6 slots)
+                steps = node.submit_batch(host)
+                deadline = time.monotonic() + 300
+                while not set(steps) <= set(got) and time.monotonic() < deadline:
+                    for e in node.poll(0.01):
+                        assert not e.frames.is_cuda
+                        got[e.step] = e.frames.clone()       # (a view of the ring: valid until the next poll)
+            order = sorted(got)
+            assert order == list(range(len(order))) and len(order) == (9 if fps == 24 else 36)
+            allf = torch.cat([got[s] for s in order])
+            assert torch.equal(allf, torch.cat([ref, ref, ref]))
+            rep = node.report()
+            assert rep["host_jobs"] == len(order) and rep["host_fallback"] == 0 and rep["lost"] == 0 and rep["dropped"] == 0 and rep["peer_copies"] == [0]
+            # device tensors still pass through untouched, interleaved with host jobs
+            steps = node.submit_batch(frames[:4].cuda()) + node.submit_batch(frames[4:8].numpy())
+            out = node.drain(steps, timeout=300)
+            assert torch.equal(torch.cat([e.frames.cpu() for e in out]), ref[:8])
+        node.close()
+
+
+def test_node_over_every_visible_gpu(want):
+    """``devices=None``: one worker per visible GPU, RCCL (``nccl``) for the start-up broadcast when there is more than one - on a one-GPU box
+    this is the world-1 case; on a multi-GPU node it is the first real N > 1 run of the product path (rank 0 loads, broadcast, fan-out
+    ``step % G``, ordered fan-in, host rings per worker)."""
+    frames, ref = want
+    g = torch.cuda.device_count()
+    node = UpscalerNode(devices=None, fps=24, frame_skips=False, **KW)
+    assert node.devices == list(range(g)) and (node.backend is None)      # -> nccl in the workers when g > 1
+    with node:
+        host = frames.numpy()
+        steps = []
+        for _ in range(max(1, g)):
+            steps += node.submit_batch(host)
+        out = node.drain(steps, timeout=600)
+        assert [e.step for e in out] == steps
+        assert torch.equal(torch.cat([e.frames for e in out]), torch.cat([ref] * max(1, g)))
+        rep = node.report()
+        assert rep["lost"] == 0 and rep["host_jobs"] == len(steps) and rep["alive"] == [True] * g
+        if g > 1:   # a device tensor on GPU 0 sent to every worker: the others copy it over once each and say so
+            steps = node.submit_batch(frames.cuda(0))
+            out = node.drain(steps, timeout=600)
+            assert torch.equal(torch.cat([e.frames.cpu() for e in out]), ref)
+            pc = node.report()["peer_copies"]
+            assert pc[0] == 0 and all(c >= 1 for c in pc[1:min(g, 3)]), pc
+    node.close()
+
+
 def test_node_two_workers_one_gpu_rank0_loads_jobs_alternate(want):
     frames, ref = want
     node = UpscalerNode(devices=[0, 0], fps=1, frame_skips=False, **KW)   # fps 1 -> one-frame jobs (the image server's job size)
