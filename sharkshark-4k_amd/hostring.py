@@ -31,6 +31,8 @@ import numpy as np
 import torch
 
 _PAGE = 4096
+#: the rings this process has mapped, by id: a ``RingView`` that arrives through a queue finds its memory here
+_RINGS = {}
 
 
 @dataclasses.dataclass
@@ -51,6 +53,8 @@ class HostRing:
     """``slots`` x ``slot_bytes`` of shared host memory, addressable as uint8 tensors / arrays; pinned on request (worker side)."""
 
     def __init__(self, slots: int, slot_bytes: int, name: str = "ss4k_ring"):
+        import uuid
+        self.uid = uuid.uuid4().hex
         self.slots = int(slots)
         self.slot_bytes = (int(slot_bytes) + _PAGE - 1) // _PAGE * _PAGE
         self.fd = os.memfd_create(name)
@@ -61,13 +65,14 @@ class HostRing:
         self._mm = mmap.mmap(self.fd, self.slots * self.slot_bytes)      # MAP_SHARED: one memory for every process that maps the fd
         self._t = torch.frombuffer(self._mm, dtype=torch.uint8)
         self._pinned = False
+        _RINGS[self.uid] = self
 
     # a spawned worker gets the descriptor (duplicated into the child by multiprocessing) and maps it again; a forked one inherits the map
     def __getstate__(self):
-        return {"slots": self.slots, "slot_bytes": self.slot_bytes, "fd": reduction.DupFd(self.fd)}
+        return {"uid": self.uid, "slots": self.slots, "slot_bytes": self.slot_bytes, "fd": reduction.DupFd(self.fd)}
 
     def __setstate__(self, state):
-        self.slots, self.slot_bytes = state["slots"], state["slot_bytes"]
+        self.uid, self.slots, self.slot_bytes = state["uid"], state["slots"], state["slot_bytes"]
         self.fd = state["fd"].detach()
         self._map()
 
@@ -121,6 +126,7 @@ class HostRing:
         except Exception:  # noqa: BLE001 - the context may be gone already
             pass
         self._t = None
+        _RINGS.pop(self.uid, None)
         try:
             self._mm.close()
         except (BufferError, ValueError):
@@ -129,6 +135,30 @@ class HostRing:
             os.close(self.fd)
         except OSError:
             pass
+
+
+def _ring_view(uid: str, slot: int, shape):
+    ring = _RINGS.get(uid)
+    if ring is None:
+        raise RuntimeError("a result frame arrived as a view of a host ring this process has not mapped: rings are created by the service "
+                           "object before start() and reach forked / spawned children of that process only (clone() the frames before "
+                           "handing them to another process)")
+    return ring.view(slot, shape)
+
+
+class RingView:
+    """What a worker puts into the RESULT QUEUE for a host result: ~ 100 bytes that unpickle, in a process that has the ring mapped, as an
+    ordinary uint8 CPU tensor over the slot - no per-result shared-memory segment (creating one 11 MB ``torch.multiprocessing`` segment
+    per result costs ~ 90 ms in a process that holds a HIP context: profiles/r06_latency.txt)."""
+
+    def __init__(self, ring: HostRing, slot: int, shape):
+        self.uid, self.slot, self.shape = ring.uid, int(slot), tuple(int(s) for s in shape)
+
+    def __reduce__(self):
+        return _ring_view, (self.uid, self.slot, self.shape)
+
+    def __len__(self) -> int:
+        return self.shape[0]
 
 
 def make_rings(slots: int, in_bytes: int, out_bytes: int) -> Tuple[HostRing, HostRing]:

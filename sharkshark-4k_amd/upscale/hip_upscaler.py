@@ -69,6 +69,17 @@ class HipUpscalerService(BaseUpscalerService):
     profiler: Profiler
     #: (input ring, output ring) of pinned shared host memory for ``HostFrames`` jobs (hostring.py); None: every job carries a tensor
     host_rings = None
+    #: True (set before ``start()``): a worker's results are HOST tensors instead of device tensors - copied by the worker on its D2H stream
+    #: into a ring of ``HOST_RESULT_SLOTS`` pinned shared-memory slots (``result_ring``, created by ``start()`` in the calling process).  For
+    #: consumers that want the frames on the host anyway (the image server: image_pipeline.py:38-47,123): ``on_queue`` gets a tensor view of
+    #: the slot, ``get_result()`` / ``result_queue.get()`` in the process that started the service (or a child of it) get the same view - it
+    #: travels as ~ 100 bytes, not as a new 11 MB shared-memory segment per result (~ 90 ms each in a process that holds a HIP context,
+    #: profiles/r06_latency.txt).  A view stays valid until ``HOST_RESULT_SLOTS`` later results; ``.clone()`` to keep.  A result bigger than a
+    #: slot (``host_result_bytes``; default: ``batch_size`` frames of ``out_hw(lr_shape)``) stays a device tensor.
+    host_results = False
+    host_result_bytes = None
+    result_ring = None
+    HOST_RESULT_SLOTS = 8
 
     def __init__(self, lr_level=3, device=0, on_queue=None, denoising=True, denoise_rate=1.0,
                  upscaler_model="realesrgan", batch_size=1, jit_mode="hip", lr_hr_resize=True,
@@ -294,7 +305,8 @@ class HipUpscalerService(BaseUpscalerService):
 
     def proc_job_recieved(self, job):
         if not isinstance(getattr(job, "frames", None), HostFrames):
-            return super().proc_job_recieved(job)
+            entry = super().proc_job_recieved(job)
+            return self._to_host_result(entry) if self.host_results and getattr(self, "_in_worker", False) else entry
         # the same spans as BaseUpscalerService.proc_job_recieved, around the host job
         import time
         hf = job.frames
@@ -317,6 +329,47 @@ class HipUpscalerService(BaseUpscalerService):
         prof.set("upscaler.input.peer_copies", self._peer_copies)
         prof.start("upscaler.output")
         return answer(job, answer_frames, time.time() - arrived, prof)
+
+    def start(self) -> None:
+        if self.host_results and self.result_ring is None:   # (here, in the caller's process: the ring must exist before the worker does)
+            from ..hostring import HostRing
+            oh, ow = self.out_hw(*self.lr_shape)
+            nbytes = self.host_result_bytes or max(1, int(self.batch_size)) * oh * ow * 3
+            self.result_ring = HostRing(self.HOST_RESULT_SLOTS, nbytes, "ss4k_results")
+        super().start()
+
+    def _to_host_result(self, entry):
+        """``host_results``: replace the entry's device frames by a view of the next slot of the pinned result ring (D2H on the worker's
+        copy stream, ordered after the job's end event; the entry is held until the bytes have landed - ``proc_result_ready`` /
+        ``proc_before_deliver``)."""
+        from ..hostring import RingView
+        out = entry.frames
+        ring = self.result_ring
+        if ring is None or not (isinstance(out, torch.Tensor) and out.is_cuda):
+            return entry
+        if not ring.fits(out.shape):
+            if not getattr(self, "_warned_big", False):
+                self._warned_big = True
+                log(f"host_results: a result of {tuple(out.shape)} does not fit a {ring.slot_bytes}-byte slot (host_result_bytes) - it stays on the device")
+            return entry
+        if not hasattr(self, "_s_out"):
+            self._s_out = torch.cuda.Stream(self.torch_device)
+        ring.pin()
+        slot = self._result_slot = (getattr(self, "_result_slot", -1) + 1) % ring.slots
+        dst = ring.view(slot, tuple(out.shape))
+        rec = self._pending.pop(id(out), None)
+        cur = torch.cuda.current_stream(self.torch_device)
+        done = rec[1] if rec is not None else cur.record_event()
+        with torch.cuda.stream(self._s_out):
+            self._s_out.wait_event(done)
+            dst.copy_(out, non_blocking=True)
+            landed = self._s_out.record_event()
+        out.record_stream(self._s_out)
+        # on_queue runs in this process: it gets the tensor; the result queue gets the 100-byte handle that unpickles as the same view
+        entry.frames = dst if self.on_queue is not None else RingView(ring, slot, out.shape)
+        self._pending[id(entry.frames)] = (entry.frames, landed, "host")
+        self._lag_now = max(getattr(self, "_lag_now", 0), 1)
+        return entry
 
     def _overlap_active(self) -> bool:
         return bool(self.overlap_jobs) and not self.single_mode and "sr" in getattr(self, "_flats", {})
@@ -445,7 +498,7 @@ class HipUpscalerService(BaseUpscalerService):
         pending = getattr(self, "_pending", None)
         rec = pending.pop(id(entry.frames), None) if pending and getattr(entry, "frames", None) is not None else None
         if rec is not None and len(rec) > 2:
-            rec[1].synchronize()     # a host result: the consumer sits in another process and reads the ring slot - the bytes must have landed
+            rec[1].synchronize()     # a host result: the consumer reads host memory (a ring slot, possibly from another process) - the bytes must have landed
         elif rec is not None:
             torch.cuda.current_stream(self.torch_device).wait_event(rec[1])
 

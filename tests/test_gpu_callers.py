@@ -79,3 +79,44 @@ def test_forked_worker_from_an_untouched_parent_the_reference_callers_way():
     worker, unpicklable callback state, device tensors created in the parent afterwards; results byte for byte."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "drive_forked_hip_service.py")], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "FORKED SERVICE OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+class _KeepOnQueue:
+    """An on_queue that does what the image server's does - take the result to the host and put it on the result queue - for a result
+    that already IS on the host: ``.cpu()`` is free, ``.clone()`` a host memcpy (the clone is small here: a new big host tensor through
+    a torch queue is exactly what ``host_results`` exists to avoid)."""
+
+    def __init__(self, svc):
+        self.q = svc.result_queue
+
+    def __call__(self, entry):
+        assert not entry.frames.is_cuda and entry.frames.is_pinned()
+        self.q.put(type(entry)(frames=entry.frames.cpu().clone(), audio_segment=None, step=entry.step, elapsed=entry.elapsed,
+                               last_modified=entry.last_modified, profiler=entry.profiler))
+
+
+@pytest.mark.parametrize("with_on_queue", [False, True])
+def test_host_results_arrive_as_host_tensors_bit_identical(want, with_on_queue):
+    """``host_results``: the worker copies each result into its pinned result ring on its D2H stream; the consumer - ``on_queue`` inside the
+    worker, or ``get_result()`` in the process that started the service - gets a uint8 HOST tensor (a view of the slot; through the queue
+    it travels as a 100-byte handle).  More jobs than slots, one- and two-frame jobs, string steps."""
+    frames, ref = want
+    svc = HipUpscalerService(**dict(KW, batch_size=2))
+    svc.host_results = True
+    if with_on_queue:
+        svc.on_queue = _KeepOnQueue(svc)
+    svc.start()
+    try:
+        assert svc.result_ring is not None and svc.result_ring.slot_bytes >= 2 * 144 * 208 * 3
+        dev = frames.cuda()
+        jobs = [(i, i + 1) for i in range(8)] + [(0, 2), (2, 4), (4, 6), (6, 8)] + [(i, i + 1) for i in range(8)]     # 20 jobs through 8 slots
+        for step, (a, b) in enumerate(jobs):
+            svc.push_job(CallerEntry(frames=dev[a:b].clone(), audio_segment=None, step=f"s{step}", profiler=CallerProfiler()), timeout=300)
+            if step % 4 == 3:        # consume as we go: a view is valid until HOST_RESULT_SLOTS later results
+                for k in range(step - 3, step + 1):
+                    g = svc.get_result(timeout=300)
+                    a2, b2 = jobs[k]
+                    assert g.step == f"s{k}" and isinstance(g.frames, torch.Tensor) and not g.frames.is_cuda
+                    assert torch.equal(g.frames, ref[a2:b2]), f"job {k}"
+    finally:
+        svc.stop()

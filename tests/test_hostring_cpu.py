@@ -134,3 +134,17 @@ def test_dispatcher_ceiling_with_eight_noop_workers():
     print(rows)
     assert rows[4]["frames_per_s"] > 8 * 130, rows
     assert rows[1]["frames_per_s"] > 8 * 125, rows
+
+
+def test_ring_view_travels_as_a_handle_and_unpickles_as_a_tensor():
+    import pickle
+    from sharkshark4k_amd.hostring import RingView
+    ring = HostRing(2, 4096)
+    ring.view(1, (2, 3)).copy_(torch.tensor([[1, 2, 3], [4, 5, 6]], dtype=torch.uint8))
+    blob = pickle.dumps(RingView(ring, 1, (2, 3)))
+    assert len(blob) < 300
+    t = pickle.loads(blob)
+    assert isinstance(t, torch.Tensor) and t.tolist() == [[1, 2, 3], [4, 5, 6]] and t.data_ptr() == ring.view(1, (2, 3)).data_ptr()
+    ring.close()
+    with pytest.raises(RuntimeError, match="has not mapped"):
+        pickle.loads(blob)
