@@ -3,6 +3,8 @@
 fp32 path: rtol 1e-3 / atol 1e-4 (BASELINE.json north_star).  uint8 frames: at most one LSB
 (truncation of floats that agree to 1e-4 can flip the integer).  fp16 path: PSNR.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -394,6 +396,37 @@ def test_image_mode_max_size_runs(ctx):
 
 
 # ------------------------------------------------------------------------------ full size (BASELINE configs), size-independent properties
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_config1_fsrcnn_x2_t91_720p_service_vs_oracle(ctx, dtype):
+    """BASELINE configs[1] at its full size with the REAL checkpoint: FSRCNN x2 (T91), one 720p frame -> 1440p through
+    ``ss4k_upscale_frames`` (per-frame path on the three colour planes, statistics match, truncation) against the oracle service, in
+    both arithmetic modes: fp32-grade (uint8 within 1 LSB, float taps at the literal tolerance) and the reference engine's fp16
+    (uint8 within 1 LSB, PSNR recorded)."""
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    table = _t91(2)
+    sr = factory.build_model_fsrcnn(ctx, factor=2, weights=table, dtype=dtype)
+    up = _capi.Upscaler(ctx, sr, (720, 1280), None, True, True, None, 1.0)
+    frames = torch.from_numpy(smooth_u8(41, (1, 720, 1280, 3)))
+    if dtype == "f32":
+        up.enable_taps(True)
+    got = up(frames.cuda()).cpu()
+    osv = osvc.OracleUpscaler(lambda x: onets.fsrcnn(x, table, 2), upscaler_model="fsrcnn", lr_shape=(720, 1280))
+    taps = {}
+    want = osv.upscale_single(frames[0], taps)[None]
+    assert got.shape == (1, 1440, 2560, 3) and got.dtype == torch.uint8
+    d = (got.int() - want.int()).abs()
+    p = psnr(got.float(), want.float(), peak=255.0)
+    frac = float((d > 0).float().mean())
+    record_measured(f"config1_fsrcnn_x2_t91_720p_{dtype}_service", psnr_db=p, max_lsb=int(d.max()), bytes_differ=frac)
+    print(f"configs[1] FSRCNN x2 T91 720p {dtype}: PSNR {p:.2f} dB, max {int(d.max())} LSB, {frac:.4%} of the bytes differ")
+    if dtype == "f32":
+        assert_u8_close(got, want, what="configs[1] FSRCNN x2 T91 720p")
+        assert_close(up.read_tap(1)[0], taps["model"][:, 0], what="configs[1] model tap")
+        assert_close(up.read_tap(4)[0], taps["final"][:, 0], what="configs[1] final float")
+    else:
+        assert int(d.max()) <= 1 and frac < 0.08 and p > 55.0, (int(d.max()), frac, p)
+
+
 def test_fsrcnn_720p_properties(ctx):
     """C2 size: linearity in the deconv bias and per-plane independence, plus a sampled-window oracle check."""
     table = W.fsrcnn_table(seed=2)

@@ -62,4 +62,20 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
   --kernel-trace --output-format csv -d $O/sqf -- python3 bench.py --workload fsrcnn --steps 1 --warmup 1 --no-cpu-baseline --no-also --no-roofline > /dev/null 2>&1
 python3 tools/pmc_summary.py $O/sqf $O/${TAG}_fsrcnn_sq_counters.json > /dev/null
 rm -rf $O/sqf
+# 5b. ... and of the fp16 mode's kernels (k_fs_head_m<false>, k_fs_maps4_h, k_fs_tail_r<..., false, true>)
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS \
+  --kernel-trace --output-format csv -d $O/sqh -- python3 bench.py --workload fsrcnn_f16 --steps 1 --warmup 1 --no-cpu-baseline --no-also --no-roofline > /dev/null 2>&1
+python3 tools/pmc_summary.py $O/sqh $O/${TAG}_fsrcnn_f16_sq_counters.json > /dev/null
+rm -rf $O/sqh
+# 6. the fused dense-block pairs on v_mfma_f32_16x16x32_f16 (conv_d16.hip, dev library) against the default 32x32x16 build, on this binary:
+#    interleaved A/B at 4 / 2 / 1 frames, its phase stamps, and its own duration per launch from a one-chain bench run
+DEV=$PWD/sharkshark-4k_amd/libss4k_hip_dev.so
+{ for b in 4 2 1; do SS4K_LIB=$DEV python3 tools/env_ab.py "SS4K_D16=0;SS4K_D16=1" $b 3 2>&1 | grep -v "^HipUpscalerService"; done
+  SS4K_LIB=$DEV SS4K_D16=1 SS4K_D16_STAMP=1 python3 tools/env_ab.py "SS4K_D16=1" 4 1 2>&1 | grep "d16 K1" | head -4
+  for d in 0 1; do SS4K_LIB=$DEV SS4K_D16=$d python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-also --no-live-traffic 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); bk=d['roofline']['by_kernel']
+print('SS4K_D16=$d: headline %.1f frames/s, conv frac %.3f; one chain, per kernel build:' % (d['value'], d['roofline']['frac']))
+for k in bk['kernels'][:4]: print('   %-60s %6.1f us per 4-frame launch  %.3f of peak  %.1f %% of kernel time' % (k['kernel'][:60], k['avg_launch_us'], k['frac'], 100*k['share_of_kernel_time']))
+"; done; } > $O/${TAG}_d16_gate.txt 2>&1
 ls -la $O
