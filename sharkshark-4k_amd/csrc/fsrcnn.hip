@@ -409,33 +409,44 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
   const int px = ws * CI - HALO + p;
   const bool col_ok = px >= 0 && px < w;
   const bool interior = p >= HALO && p < 32 - HALO && px < w;
-  // this lane's 8 input channels of its pixel (half 0: channels 0-7, half 1: 8-11 + zeros), fetched one row ahead
-  // (fp16 mode: the 12-channel tensor is fp16, 8 bytes per pixel and group; .x/.y of a0 and a1 carry the packed pairs)
+  // this lane's 8 input channels of its pixel (half 0: channels 0-7, half 1: 8-11 + zeros), fetched PF rows ahead into a register ring.
+  // (fp16 mode: the 12-channel tensor is fp16, 8 bytes per pixel and group; .x/.y of a0 and a1 carry the packed pairs.)  Every load is
+  // UNCONDITIONAL - address clamped into the image, the value replaced where it is used - and several rows are in flight: with one row
+  // ahead and the load under a branch (rounds 2-5) the fp16 mode, whose row is 14 MFMAs, spent 63 % of its wave cycles in s_waitcnt
+  // (profiles/r06_fsrcnn_f16_sq_counters.json: SQ_WAIT_ANY) - a row is shorter than a trip to HBM.
+  constexpr int PF = SPLIT ? (S == 2 ? 2 : 1) : 4;   // (the x4 split build has no registers to spare: 168 of 170)
+  const int pxc = min(max(px, 0), w - 1);
+  const int g0i = hh ? 2 : 0, g1i = hh ? 2 : 1;   // half 1 reads group 2 twice (the same line) instead of branching
   auto load_x = [&](int yy, float4& a0, float4& a1) {
-    a0 = a1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (yy >= 0 && yy < h && col_ok) {
-      if constexpr (SPLIT) {
-        const float4* src = reinterpret_cast<const float4*>(in12) + (size_t)plane * plane_px + (size_t)yy * w + px;
-        if (hh == 0) { a0 = src[0]; a1 = src[total]; } else a0 = src[2 * total];
-      } else {
-        const float2* src = reinterpret_cast<const float2*>(in12) + (size_t)plane * plane_px + (size_t)yy * w + px;
-        if (hh == 0) { const float2 u = src[0], v = src[total]; a0.x = u.x; a0.y = u.y; a1.x = v.x; a1.y = v.y; }
-        else { const float2 u = src[2 * total]; a0.x = u.x; a0.y = u.y; }
-      }
+    const size_t at = (size_t)plane * plane_px + (size_t)min(max(yy, 0), h - 1) * w + pxc;
+    if constexpr (SPLIT) {
+      const float4* src = reinterpret_cast<const float4*>(in12) + at;
+      a0 = src[g0i * total]; a1 = src[g1i * total];
+    } else {
+      const float2* src = reinterpret_cast<const float2*>(in12) + at;
+      const float2 u = src[g0i * total], v = src[g1i * total];
+      a0 = make_float4(u.x, u.y, 0.f, 0.f); a1 = make_float4(v.x, v.y, 0.f, 0.f);
     }
   };
   typedef float fvS __attribute__((ext_vector_type(S)));
   fvS V[5];   // output rows S*y - 4 + 2j + hh under construction, this lane's S columns of each
 #pragma unroll
   for (int j = 0; j < 5; ++j) V[j] = fvS(0.f);
-  float4 n0, n1;
-  load_x(ylo - 2, n0, n1);
+  float4 n0[PF], n1[PF];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) load_x(ylo - 2 + u, n0[u], n1[u]);
   constexpr float LO = 1.f / 2048.f;
   const f32x16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int y = ylo - 2; y < yhi + 2; ++y) {
+  for (int yb = ylo - 2; yb < yhi + 2; yb += PF) {
+#pragma unroll
+   for (int u = 0; u < PF; ++u) {
+    const int y = yb + u;
+    if (y >= yhi + 2) break;   // wave-uniform
     const bool row_ok = y >= 0 && y < h;  // wave-uniform
-    const float4 g0 = n0, g1 = n1;
-    load_x(y + 1, n0, n1);
+    float4 g0 = n0[u], g1 = n1[u];
+    load_x(y + PF, n0[u], n1[u]);
+    if (!col_ok) { g0 = make_float4(0.f, 0.f, 0.f, 0.f); g1 = g0; }   // (a column outside the image is zero padding; a row outside is skipped)
+    if (hh) g1 = make_float4(0.f, 0.f, 0.f, 0.f);                      // half 1: channels 8-11 only
     if (row_ok) {
       uint4 xh, xl;
       if constexpr (SPLIT) {
@@ -547,6 +558,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
     }
 #pragma unroll
     for (int j = 0; j < 5; ++j) V[j] = j + JSTEP < 5 ? V[j + JSTEP] : fvS(0.f);
+   }
   }
 }
 
@@ -676,8 +688,8 @@ __global__ __launch_bounds__(256, 2) void k_fs_head_m(const float* __restrict__ 
     }
   };
   float pre[3];
-  for (int y = ylo - 2; y < ylo + 2; ++y) { fetch(y, pre); put(y, pre); }
-  fetch(ylo + 2, pre);
+  for (int y = ylo - 2; y < ylo + 3; ++y) { fetch(y, pre); put(y, pre); }
+  fetch(ylo + 3, pre);
   const f32x16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   auto a1 = [&](int part, int g, int s3, int b) -> uint4 {   // the weight operand of shift g
     if constexpr (!SPLIT) return A1[part][g][s3][b];
@@ -693,8 +705,8 @@ __global__ __launch_bounds__(256, 2) void k_fs_head_m(const float* __restrict__ 
   const uint4 one_op = make_uint4(0x00003c00u, 0u, 0u, 0u), zero_op = make_uint4(0u, 0u, 0u, 0u);   // {1.0, 0, ...}: the bias slot's pixel operand
   constexpr float LO = 1.f / 2048.f;
   for (int y = ylo; y < yhi; ++y) {
-    put(y + 2, pre);
-    fetch(y + 3, pre);
+    // (row y + 3 enters the ring at the END of this iteration: the wait for its prefetched pixels then sits behind a row of MFMAs instead of
+    // in front of this row's operand reads, which must follow the ring stores - may_alias below)
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int P = X0 + 64 * pass;
@@ -705,7 +717,11 @@ __global__ __launch_bounds__(256, 2) void k_fs_head_m(const float* __restrict__ 
       for (int part = 0; part < NP; ++part)
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3) {
-          const uint32_t* p32 = reinterpret_cast<const uint32_t*>(&ring[(y - 2 + 2 * s3 + kq) & (FH_RING - 1)][part][64 * pass + 2 * n]);
+          // (may_alias: the ring rows are WRITTEN through fp16 / 16-bit pointers in put(); read through a plain uint32_t pointer the compiler
+          // may move these reads above those writes - type-based aliasing - and did, the moment round 6 unrolled the row loop by two for a
+          // second input row in flight: NaNs.  That variant measured 3 % slower on the stage and was dropped; the annotation stays.)
+          typedef uint32_t u32_any __attribute__((may_alias));
+          const u32_any* p32 = reinterpret_cast<const u32_any*>(&ring[(y - 2 + 2 * s3 + kq) & (FH_RING - 1)][part][64 * pass + 2 * n]);
           B1[part][s3] = make_uint4(p32[0], p32[1], p32[2], p32[3]);
         }
       if (kq == 1) { B1[0][2] = one_op; if constexpr (SPLIT) B1[1][2] = zero_op; }
@@ -792,6 +808,8 @@ __global__ __launch_bounds__(256, 2) void k_fs_head_m(const float* __restrict__ 
         }
       }
     }
+    put(y + 3, pre);
+    fetch(y + 4, pre);
   }
 }
 
