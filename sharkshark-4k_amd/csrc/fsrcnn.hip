@@ -313,9 +313,15 @@ __device__ __forceinline__ uint32_t half2_rne(float x0, float x1) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h16x2v));
 }
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+// PReLU on a packed fp16 pair as max(v, v s): a packed multiply and a packed max (rounds 3-5: max(v, 0) + s min(v, 0), three
+// instructions - the fp16 kernels issue 10-11 vector instructions per MFMA, profiles/r06_fsrcnn_f16_inst_counters.json, and a third to
+// three quarters of them are this function).  max(v, v s) is PReLU only for s <= 1; an fp16-mode model therefore carries every channel
+// with s > 1 NEGATED through its activation (its producing weights and bias and its consuming weights are negated when the model is
+// built, models.cpp): max(-v, -v s) = -min(v, v s) = -PReLU(v) for s > 1.  Same bits as the three-instruction form either way
+// (v < 0: s v >= v, and fl(s v) is what the fma form rounds to; v >= 0: s v <= v; rounding to nearest is sign-symmetric).
 __device__ __forceinline__ uint32_t prelu_h2(uint32_t x, uint32_t a) {
-  const h16x2 v = __builtin_bit_cast(h16x2, x), sl = __builtin_bit_cast(h16x2, a), z = {(_Float16)0.f, (_Float16)0.f};
-  const h16x2 r = __builtin_elementwise_max(v, z) + sl * __builtin_elementwise_min(v, z);
+  const h16x2 v = __builtin_bit_cast(h16x2, x), sl = __builtin_bit_cast(h16x2, a);
+  const h16x2 r = __builtin_elementwise_max(v, v * sl);
   return __builtin_bit_cast(uint32_t, r);
 }
 template <bool SPLIT>
@@ -414,7 +420,10 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
   // UNCONDITIONAL - address clamped into the image, the value replaced where it is used - and several rows are in flight: with one row
   // ahead and the load under a branch (rounds 2-5) the fp16 mode, whose row is 14 MFMAs, spent 63 % of its wave cycles in s_waitcnt
   // (profiles/r06_fsrcnn_f16_sq_counters.json: SQ_WAIT_ANY) - a row is shorter than a trip to HBM.
-  constexpr int PF = SPLIT ? (S == 2 ? 2 : 1) : 4;   // (the x4 split build has no registers to spare: 168 of 170)
+  // fp16 mode: FIVE rows per trip of the unrolled loop - the five output rows under construction then rotate by INDEX (row j of sub-step u
+  // is register set (j + JSTEP u) % 5: a compile-time constant) instead of by ten register moves per row
+  constexpr int PF = SPLIT ? (S == 2 ? 2 : 1) : 5;   // (the x4 split build has no registers to spare: 168 of 170)
+  constexpr bool ROT = PF == 5;
   const int pxc = min(max(px, 0), w - 1);
   const int g0i = hh ? 2 : 0, g1i = hh ? 2 : 1;   // half 1 reads group 2 twice (the same line) instead of branching
   auto load_x = [&](int yy, float4& a0, float4& a1) {
@@ -526,14 +535,15 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
         float t[9];
 #pragma unroll
         for (int kx = 0; kx < 9; ++kx) { const int ord = 9 * j + kx; t[kx] = T[ord >> 4][ord & 15]; }
+        fvS& Vj = V[ROT ? (j + JSTEP * u) % 5 : j];
         if constexpr (S == 2) {
-          V[j][0] += dpp_shl1(dpp_shl1(t[0]) + t[2]) + t[4] + dpp_shr1(dpp_shr1(t[8]) + t[6]);
-          V[j][1] += dpp_shl1(dpp_shl1(t[1]) + t[3]) + t[5] + dpp_shr1(t[7]);
+          Vj[0] += dpp_shl1(dpp_shl1(t[0]) + t[2]) + t[4] + dpp_shr1(dpp_shr1(t[8]) + t[6]);
+          Vj[1] += dpp_shl1(dpp_shl1(t[1]) + t[3]) + t[5] + dpp_shr1(t[7]);
         } else {
-          V[j][0] += dpp_shl1(t[0]) + t[4] + dpp_shr1(t[8]);
-          V[j][1] += dpp_shl1(t[1]) + t[5];
-          V[j][2] += dpp_shl1(t[2]) + t[6];
-          V[j][3] += dpp_shl1(t[3]) + t[7];
+          Vj[0] += dpp_shl1(t[0]) + t[4] + dpp_shr1(t[8]);
+          Vj[1] += dpp_shl1(t[1]) + t[5];
+          Vj[2] += dpp_shl1(t[2]) + t[6];
+          Vj[3] += dpp_shl1(t[3]) + t[7];
         }
       }
     }
@@ -542,7 +552,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
     for (int j = 0; j < JSTEP; ++j) {
       const int Y = S * y - 4 + 2 * j + hh;
       if (interior && Y >= S * ylo && Y < S * yhi) {
-        fvS o = V[j];
+        fvS o = V[ROT ? (j + JSTEP * u) % 5 : j];
 #pragma unroll
         for (int e = 0; e < S; ++e) o[e] += bias;
         if constexpr (OUT_HALF) {   // the service's fp16 HR tensor (an fp16 model): S halves per lane and row
@@ -556,8 +566,13 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
         *reinterpret_cast<fvS*>(&oplane[(size_t)Y * OW + (size_t)S * px]) = o;
       }
     }
+    if constexpr (ROT) {
 #pragma unroll
-    for (int j = 0; j < 5; ++j) V[j] = j + JSTEP < 5 ? V[j + JSTEP] : fvS(0.f);
+      for (int j = 0; j < JSTEP; ++j) V[(j + JSTEP * u) % 5] = fvS(0.f);   // the rows that left start again as the newest ones
+    } else {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) V[j] = j + JSTEP < 5 ? V[j + JSTEP] : fvS(0.f);
+    }
    }
   }
 }
@@ -1220,8 +1235,11 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
     const int hb0 = std::max(1, std::min((h + 7) / 8, 4 * per_simd * ctx->num_cu / std::max(1, planes * hstrips)));
     const int hbands = (h + (h + hb0 - 1) / hb0 - 1) / ((h + hb0 - 1) / hb0);
     const unsigned hwaves = (unsigned)(planes * hbands * hstrips);
-    if (half) hipLaunchKernelGGL(k_fs_head_m<false>, dim3((hwaves + 3) / 4), block, 0, st, in, static_cast<void*>(ws12a), W.w_feat, W.b_feat,
-                                 W.a_feat, W.w_shrink, W.b_shrink, W.a_shrink, planes, h, w, hbands);
+    if (half) {
+      SS4K_REQUIRE(W.prelu_le1, "FSRCNN fp16 mode: the weight blob is not sign-folded for the max-form PReLU (models.cpp)");
+      hipLaunchKernelGGL(k_fs_head_m<false>, dim3((hwaves + 3) / 4), block, 0, st, in, static_cast<void*>(ws12a), W.w_feat, W.b_feat,
+                         W.a_feat, W.w_shrink, W.b_shrink, W.a_shrink, planes, h, w, hbands);
+    }
     else hipLaunchKernelGGL(k_fs_head_m<true>, dim3((hwaves + 3) / 4), block, 0, st, in, static_cast<void*>(ws12a), W.w_feat, W.b_feat,
                             W.a_feat, W.w_shrink, W.b_shrink, W.a_shrink, planes, h, w, hbands);
   } else
