@@ -20,7 +20,10 @@ SOURCES = ["conv_mfma.hip", "conv_pair.hip", "conv_dense.hip", "conv_w16.hip", "
 DEV_SOURCES = ["conv_s3.hip", "conv_d16.hip", "conv_rs.hip", "conv_chain.hip"]
 # conv_rs.hip: the per-tile body is thousands of fully unrolled MFMAs (weights live in named registers); hipcc's
 # default cap on '#pragma unroll' size would leave the chunk loop rolled and the weights in scratch
-EXTRA_FLAGS = {"conv_rs.hip": ["-mllvm", "-pragma-unroll-threshold=4000000"]}
+# fsrcnn.hip: no SLP vectorisation - left on, the tail's overlap-add (two adjacent output columns per lane) is packed into v_pk_add_f32,
+# which cannot take a DPP operand: 20 of its 35 wave shifts per row then become separate v_mov_b32_dpp, and packed fp32 adds are slower
+# than two plain ones beside MFMAs (MI355X_MICROARCH.md, cycle constants).  Without it every shift is folded into its add (v_add_f32_dpp)
+EXTRA_FLAGS = {"conv_rs.hip": ["-mllvm", "-pragma-unroll-threshold=4000000"], "fsrcnn.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-x", "hip", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable"]
 

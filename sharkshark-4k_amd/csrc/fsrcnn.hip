@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
   // (profiles/r06_fsrcnn_f16_sq_counters.json: SQ_WAIT_ANY) - a row is shorter than a trip to HBM.
   // fp16 mode: FIVE rows per trip of the unrolled loop - the five output rows under construction then rotate by INDEX (row j of sub-step u
   // is register set (j + JSTEP u) % 5: a compile-time constant) instead of by ten register moves per row
-  constexpr int PF = SPLIT ? (S == 2 ? 2 : 1) : 5;   // (the x4 split build has no registers to spare: 168 of 170)
+  constexpr int PF = SPLIT ? (S == 2 ? 3 : 2) : 5;   // (fp32-grade: three | two rows in flight fit the 170 registers of three workgroups per CU)
   constexpr bool ROT = PF == 5;
   const int pxc = min(max(px, 0), w - 1);
   const int g0i = hh ? 2 : 0, g1i = hh ? 2 : 1;   // half 1 reads group 2 twice (the same line) instead of branching
@@ -529,21 +529,33 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
 #pragma unroll
         for (int i = 0; i < 16; ++i) T[tb][i] = SPLIT ? fmaf(T2[i], LO, T1[i]) : T1[i];
       }
-      // horizontal overlap-add in registers, then into the rows under construction
+      // horizontal overlap-add in registers, then into the rows under construction.  Stage by stage ACROSS the five rows, so that every wave
+      // shift (folded into its add: v_add_f32_dpp) reads a register written ten or more instructions earlier - a DPP operand written by
+      // the previous instruction costs a 2-cycle s_nop, and the row-by-row form was a chain of them
+      auto tap = [&](int j, int kx) -> float { const int ord = 9 * j + kx; return T[ord >> 4][ord & 15]; };
+      if constexpr (S == 2) {
+        float a0[5], a1[5], c0[5];
 #pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        float t[9];
+        for (int j = 0; j < 5; ++j) { a0[j] = dpp_shl1(tap(j, 0)) + tap(j, 2); a1[j] = dpp_shl1(tap(j, 1)) + tap(j, 3); c0[j] = dpp_shr1(tap(j, 8)) + tap(j, 6); }
 #pragma unroll
-        for (int kx = 0; kx < 9; ++kx) { const int ord = 9 * j + kx; t[kx] = T[ord >> 4][ord & 15]; }
-        fvS& Vj = V[ROT ? (j + JSTEP * u) % 5 : j];
-        if constexpr (S == 2) {
-          Vj[0] += dpp_shl1(dpp_shl1(t[0]) + t[2]) + t[4] + dpp_shr1(dpp_shr1(t[8]) + t[6]);
-          Vj[1] += dpp_shl1(dpp_shl1(t[1]) + t[3]) + t[5] + dpp_shr1(t[7]);
-        } else {
-          Vj[0] += dpp_shl1(t[0]) + t[4] + dpp_shr1(t[8]);
-          Vj[1] += dpp_shl1(t[1]) + t[5];
-          Vj[2] += dpp_shl1(t[2]) + t[6];
-          Vj[3] += dpp_shl1(t[3]) + t[7];
+        for (int j = 0; j < 5; ++j) { a0[j] = dpp_shl1(a0[j]) + tap(j, 4); a1[j] = dpp_shl1(a1[j]) + tap(j, 5); }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { a0[j] = dpp_shr1(c0[j]) + a0[j]; a1[j] = dpp_shr1(tap(j, 7)) + a1[j]; }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { fvS& Vj = V[ROT ? (j + JSTEP * u) % 5 : j]; Vj[0] += a0[j]; Vj[1] += a1[j]; }
+      } else {
+        float b[5][4];
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[j][e] = dpp_shl1(tap(j, e)) + tap(j, 4 + e);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) b[j][0] = dpp_shr1(tap(j, 8)) + b[j][0];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          fvS& Vj = V[ROT ? (j + JSTEP * u) % 5 : j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) Vj[e] += b[j][e];
         }
       }
     }
