@@ -59,6 +59,15 @@ from .upscaler_base import BaseUpscalerService, UpscalerQueueEntry, answer, reco
 LR_LEVELS = [(360, 640), (540, 960), (630, 1120), (720, 1280), (900, 1600), (1080, 1920)]
 
 
+def under_profiler() -> bool:
+    """A profiler has loaded itself into this process (rocprofv3 sets ROCP_TOOL_LIBRARIES and preloads librocprofiler-sdk): counter
+    collection serialises kernels, so every "do these two streams run side by side?" measurement fails - the library skips its lane check
+    then (models.cpp ss4k_ctx::lane_check) and the service its stream vetting (eight candidates x ~ 600 probe launches per stream otherwise)."""
+    import os
+    env = os.environ
+    return bool(env.get("ROCP_TOOL_LIBRARIES")) or any(t in env.get("LD_PRELOAD", "") for t in ("rocprofiler", "roctracer"))
+
+
 def log(*args, **kwargs):
     # stderr: a process that prints a result on stdout (bench.py's one JSON line) may run a service in-process
     kwargs.setdefault("file", sys.stderr)
@@ -258,7 +267,10 @@ class HipUpscalerService(BaseUpscalerService):
         if not self._host_on_gpu:
             return
         for ring in self.host_rings:
-            ring.pin()
+            try:
+                ring.pin()
+            except RuntimeError as e:   # (copies to and from pageable memory still work - staged by the runtime, no longer asynchronous)
+                log(f"WARNING: {e}: host frames go through UNPINNED memory")
         self._s_in, self._s_out = torch.cuda.Stream(self.torch_device), torch.cuda.Stream(self.torch_device)
         self._stage = {}    # input shape -> [[device tensor, event after which it may be overwritten], ...], used round robin
         self._stage_at = {}
@@ -354,7 +366,12 @@ class HipUpscalerService(BaseUpscalerService):
             return entry
         if not hasattr(self, "_s_out"):
             self._s_out = torch.cuda.Stream(self.torch_device)
-        ring.pin()
+        if not getattr(self, "_result_ring_pinned", False):
+            self._result_ring_pinned = True
+            try:
+                ring.pin()
+            except RuntimeError as e:
+                log(f"WARNING: {e}: host results go through UNPINNED memory")
         slot = self._result_slot = (getattr(self, "_result_slot", -1) + 1) % ring.slots
         dst = ring.view(slot, tuple(out.shape))
         rec = self._pending.pop(id(out), None)
@@ -393,6 +410,8 @@ class HipUpscalerService(BaseUpscalerService):
         both are busy - or while one is merely WAITING for the other, as the current stream does for a job set's (measured: a one-frame job
         17.5 instead of 9.5 ms on a set-0 stream that was the process's 4th, `profiles/r05_lane_queue.txt`).  Which queue a stream gets depends
         on how many the process created before."""
+        if under_profiler():
+            return torch.cuda.Stream(self.torch_device)
         for _ in range(tries):
             cand = torch.cuda.Stream(self.torch_device)   # (torch hands out the streams of a fixed pool in turn: always a different one)
             bad = next((o for o in others if not self.ctx.streams_side_by_side(o, cand)), None)
@@ -431,6 +450,8 @@ class HipUpscalerService(BaseUpscalerService):
         it), on a shared queue 0.97-1.2.  A set that does not pass takes another stream and is checked again.  Blocks the host for a few dozen
         jobs' time, once per service."""
         self._streams_checked = True
+        if under_profiler():
+            return
         frames = frames[:1]   # (one-frame jobs gain 12-15 % from running side by side: a clear signal; multi-frame jobs gain nothing, measured)
         dev, cur = self.torch_device, torch.cuda.current_stream(self.torch_device)
         sets = [self._job_set(k) for k in range(self.overlap_sets)]
