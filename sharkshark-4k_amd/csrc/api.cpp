@@ -178,6 +178,40 @@ struct Upscaler {
   void single(const uint8_t* in, int n, int h, int w, uint8_t* out, hipStream_t st) {
     const int lh = cfg.lr_h, lw = cfg.lr_w, P = 3 * n;
     const size_t plane = (size_t)lh * lw;
+    // FSRCNN on frames that need neither the area resize nor the denoiser reads the uint8 frames ITSELF (fsrcnn.hip, U8IN: the same
+    // (float)byte / 255.0f) and the low-resolution statistics come straight from the bytes: the fp32 colour planes are never written
+    // (round 6: one launch and 44 MB + 44 MB of traffic per four 720p frames less).  The parity path (taps) keeps the planes.
+    const bool u8_direct = !taps_on && !cfg.denoising && !cfg.sr_is_realesrgan && h == lh && w == lw && sr->can_u8_in();
+    if (u8_direct) {
+      int oc, H, W; sr->out_shape(1, lh, lw, &oc, &H, &W);
+      const bool hr16 = sr->can_half_out();
+      hr.ensure((size_t)P * H * W * 4 * 2);
+      st_hr.ensure(P * 8); st_lr.ensure(P * 8);
+      SS4K_REQUIRE(P <= STATS_MAX_PLANES, "too many frames in one job");
+      // one set of accumulators for both tensors' statistics - the frames' [0, P) and the network output's [P, 2 P) - zeroed by ONE memset
+      // and finished by ONE launch (two memsets and two finishing launches less than two op_plane_stats calls: ~ 10 us of a 0.7 ms job)
+      SS4K_REQUIRE(2 * P <= STATS_MAX_PLANES, "too many frames in one job");
+      st_acc.ensure(sizeof(double) * 2 * 2 * P * STATS_SLOTS);
+      SS4K_HIP(hipMemsetAsync(st_acc.as<double>(), 0, sizeof(double) * 2 * 2 * P * STATS_SLOTS, st));
+      op_plane_stats_u8nhwc_partial(st_acc.as<double>(), in, n, lh * lw, 2 * P, 0, st);
+      enq_denoise_ms = 0;
+      const double tm0 = now_ms();
+      sr->out_half = hr16; sr->in_u8 = true;
+      sr->forward(reinterpret_cast<const float*>(in), hr.as<float>(), P, lh, lw, st);
+      enq_model_ms = now_ms() - tm0;
+      const bool rs_ = cfg.out_h > 0 && !(cfg.out_h == H && cfg.out_w == W);
+      auto finish = [&](auto* hrt) {
+        op_plane_stats_partial(st_acc.as<double>(), hrt, P, H * W, 2 * P, P, st);
+        op_plane_stats_finish2(st_acc.as<double>(), st_lr.as<float>(), st_hr.as<float>(), P, lh * lw, H * W, st);
+        if (!rs_) op_tail_fused(hrt, out, static_cast<const float*>(nullptr), n, 3, H, W, 1, 1, st_hr.as<float>(), st_lr.as<float>(), st);
+        else {
+          op_tail_fused(hrt, static_cast<uint8_t*>(nullptr), static_cast<const float*>(nullptr), n, 3, H, W, 1, 1, st_hr.as<float>(), st_lr.as<float>(), st);
+          op_bicubic_u8(hrt, out, n, 3, H, W, cfg.out_h, cfg.out_w, st);
+        }
+      };
+      if (hr16) finish(hr.as<__half>()); else finish(hr.as<float>());
+      return;
+    }
     img.ensure((size_t)P * h * w * 4);
     op_u8nhwc_to_f32nchw(in, img.as<float>(), n, h, w, 3, st);
     // area resize, unconditional in this path (:239-241); at equal size adaptive average pooling is the identity: no copy

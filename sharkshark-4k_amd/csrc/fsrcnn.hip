@@ -607,7 +607,10 @@ constexpr int FH_COLS = 128, FH_RING = 8, FH_ROWH = 136 + 8;   // ring row: colu
 
 // SPLIT: the same structure at fp32 accuracy (the default, fp32-grade mode): every operand hi + 2^-11 lo, three MFMAs per product (as the
 // mapping stage and the tail), two fp16 input rings, fp32 PReLU and re-split of the 56-channel map, fp32 output.
-template <bool SPLIT>
+// U8IN (round 6): the input is the service's uint8 NHWC frame tensor itself - plane p is colour p % 3 of frame p / 3, a pixel is
+// (float)byte / 255.0f, the expression of glue.hip's conversion kernel - so a job whose frames need no area resize and no denoising
+// never writes or reads the fp32 colour planes (44 MB per four 720p frames, one launch)
+template <bool SPLIT, bool U8IN = false>
 __global__ __launch_bounds__(256, 2) void k_fs_head_m(const float* __restrict__ in, void* __restrict__ outv,
                                                       const float* __restrict__ wf, const float* __restrict__ bf,
                                                       const float* __restrict__ af, const float* __restrict__ ws,
@@ -621,6 +624,10 @@ __global__ __launch_bounds__(256, 2) void k_fs_head_m(const float* __restrict__ 
   const int wid = blockIdx.x * 4 + wave;
   const int strip = wid % strips, band = (wid / strips) % bands, plane = wid / (strips * bands);
   const int rpb = (h + bands - 1) / bands, ylo = band * rpb, yhi = min(h, ylo + rpb);
+  // U8IN: the 256 values a byte can become, (float)k / 255.0f exactly as glue.hip's conversion kernel divides (a true division is ~ 10
+  // vector instructions; the loader needs three per row): a table read instead
+  __shared__ float u8_lut[U8IN ? 256 : 1];
+  if constexpr (U8IN) { u8_lut[tid & 255] = (float)(tid & 255) / 255.0f; if constexpr (!SPLIT) __syncthreads(); }
   if constexpr (SPLIT) {
     // [kq][block b][i]: slope of channel 32b + (i&3) + 8(i>>2) + 4kq; then [kq][i] for the shrink's rows (i&3) + 8(i>>2) + 4kq
     if (tid < 64) { const int q = tid >> 5, bb = (tid >> 4) & 1, i = tid & 15, c = 32 * bb + (i & 3) + 8 * (i >> 2) + 4 * q; slope_lds[tid] = c < 56 ? af[c] : 1.f; }
@@ -692,15 +699,26 @@ __global__ __launch_bounds__(256, 2) void k_fs_head_m(const float* __restrict__ 
 
   const size_t plane_px = (size_t)h * w, total = (size_t)planes * plane_px;
   const float* src = in + (size_t)plane * plane_px;
+  const uint8_t* src8 = reinterpret_cast<const uint8_t*>(in) + (size_t)(plane / 3) * plane_px * 3 + (plane % 3);
   // loader: ring column c is image column X0 - 2 + c; a lane moves columns lane, lane + 64 and (lane < 8) lane + 128
   auto fetch = [&](int y, float (&v)[3]) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int x = X0 - 2 + lane + 64 * k;
-      v[k] = (y >= 0 && y < h && x >= 0 && x < w && (k < 2 || lane < 8)) ? src[(size_t)y * w + x] : 0.f;
+      const bool ok = y >= 0 && y < h && x >= 0 && x < w && (k < 2 || lane < 8);
+      // (U8IN: the raw byte travels in the prefetch register - 256 = "outside the image" - and becomes a float in put(), one row later:
+      //  looked up here, the table read would wait for the load it depends on and the row-ahead prefetch would be none)
+      if constexpr (U8IN) v[k] = __int_as_float(ok ? (int)src8[((size_t)y * w + x) * 3] : 256);
+      else v[k] = ok ? src[(size_t)y * w + x] : 0.f;
     }
   };
-  auto put = [&](int y, const float (&v)[3]) {
+  auto put = [&](int y, const float (&vin)[3]) {
+    float v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if constexpr (U8IN) { const int b = __float_as_int(vin[k]); v[k] = b < 256 ? u8_lut[b & 255] : 0.f; }
+      else v[k] = vin[k];
+    }
     _Float16 (*row)[FH_ROWH] = ring[y & (FH_RING - 1)];
     if constexpr (SPLIT) {
       uint32_t h01, l01, h2, l2;
@@ -1225,9 +1243,10 @@ __global__ __launch_bounds__(256, 4 / NU) void k_fs_maps4_h(const uint2* __restr
 }
 
 void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const float* in, float* out, int planes, int h,
-                    int w, float* ws12a, float* ws12b, int mode, hipStream_t st, bool out_half) {
+                    int w, float* ws12a, float* ws12b, int mode, hipStream_t st, bool out_half, bool in_u8) {
   const bool exact = mode == FS_MODE_EXACT, half = mode == FS_MODE_HALF;
   SS4K_REQUIRE(!out_half || half, "FSRCNN: an fp16 output tensor is offered in fp16 mode only");
+  SS4K_REQUIRE(!in_u8 || (!exact && planes % 3 == 0), "FSRCNN: uint8 NHWC input is read by the matrix-core head only, three colour planes per frame");
   const size_t total = (size_t)planes * h * w;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   // exact (SS4K_FS_EXACT=1 when the model was built): the exact-fp32 kernels - vector-ALU mapping layers, fp32-MFMA tail with
@@ -1249,11 +1268,15 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
     const unsigned hwaves = (unsigned)(planes * hbands * hstrips);
     if (half) {
       SS4K_REQUIRE(W.prelu_le1, "FSRCNN fp16 mode: the weight blob is not sign-folded for the max-form PReLU (models.cpp)");
-      hipLaunchKernelGGL(k_fs_head_m<false>, dim3((hwaves + 3) / 4), block, 0, st, in, static_cast<void*>(ws12a), W.w_feat, W.b_feat,
+      auto hk = in_u8 ? &k_fs_head_m<false, true> : &k_fs_head_m<false, false>;
+      hipLaunchKernelGGL(hk, dim3((hwaves + 3) / 4), block, 0, st, in, static_cast<void*>(ws12a), W.w_feat, W.b_feat,
                          W.a_feat, W.w_shrink, W.b_shrink, W.a_shrink, planes, h, w, hbands);
     }
-    else hipLaunchKernelGGL(k_fs_head_m<true>, dim3((hwaves + 3) / 4), block, 0, st, in, static_cast<void*>(ws12a), W.w_feat, W.b_feat,
-                            W.a_feat, W.w_shrink, W.b_shrink, W.a_shrink, planes, h, w, hbands);
+    else {
+      auto hk = in_u8 ? &k_fs_head_m<true, true> : &k_fs_head_m<true, false>;
+      hipLaunchKernelGGL(hk, dim3((hwaves + 3) / 4), block, 0, st, in, static_cast<void*>(ws12a), W.w_feat, W.b_feat,
+                         W.a_feat, W.w_shrink, W.b_shrink, W.a_shrink, planes, h, w, hbands);
+    }
   } else
   hipLaunchKernelGGL(k_fs_head, grid, block, 0, st, in, ws12a, W.w_feat, W.b_feat, W.a_feat, W.w_shrink, W.b_shrink,
                      W.a_shrink, planes, h, w);

@@ -16,6 +16,14 @@ constexpr int STATS_SLOTS = 32;
 template <typename HT>
 void op_plane_stats(double* acc, const HT* in, float* stats, int planes, int hw, hipStream_t st);
 void op_plane_stats_finish(const double* acc, float* stats, int planes, int hw, hipStream_t st);
+// mean / unbiased std of the colour planes of uint8 NHWC frames as the fp32 planes (float)byte / 255.0f would give them (same accumulators)
+void op_plane_stats_u8nhwc(double* acc, const uint8_t* in, float* stats, int n, int hw, hipStream_t st);
+// the two halves of the above and of op_plane_stats, for a caller that accumulates two tensors' statistics (accumulators zeroed by one memset:
+// acc holds 2 x planes plane records, [0, planes) and [planes, 2 planes)) and finishes both with one launch
+void op_plane_stats_u8nhwc_partial(double* acc, const uint8_t* in, int n, int hw, int acc_planes, int plane0, hipStream_t st);
+template <typename HT>
+void op_plane_stats_partial(double* acc, const HT* in, int planes, int hw, int acc_planes, int plane0, hipStream_t st);
+void op_plane_stats_finish2(const double* acc, float* stats_a, float* stats_b, int planes, int hw_a, int hw_b, hipStream_t st);
 // HT: element type of the network's HR output tensor (float, or __half where the network's tail can write it)
 template <typename HT>
 void op_area_normalized(const HT* in, float* out, int planes, int h, int w, int oh, int ow, const float* st_hr, const float* st_lr,
@@ -71,6 +79,7 @@ struct FsrcnnWeights {
 // plain fp16 operands with fp32 accumulation (an SS4K_F16 model: the precision the reference's TensorRT engine runs FSRCNN in)
 enum { FS_MODE_SPLIT = 0, FS_MODE_EXACT = 1, FS_MODE_HALF = 2 };
 void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const float* in, float* out, int planes, int h,
-                    int w, float* ws12a, float* ws12b, int mode, hipStream_t st, bool out_half = false);   // out_half: fp16 mode only, HR planes as fp16
+                    int w, float* ws12a, float* ws12b, int mode, hipStream_t st, bool out_half = false,
+                    bool in_u8 = false);   // out_half: fp16 mode only, HR planes as fp16; in_u8: `in` is the uint8 NHWC frame tensor (planes / 3 frames)
 
 }  // namespace ss4k

@@ -139,8 +139,9 @@ template void op_area_normalized<__half>(const __half*, float*, int, int, int, i
 
 // ------------------------------------------------------------------ per-plane mean / unbiased std
 template <typename HT = float>
-__global__ void k_stats_partial(const HT* __restrict__ in, double* __restrict__ acc, int hw) {
+__global__ void k_stats_partial(const HT* __restrict__ in, double* __restrict__ acc, int hw, int acc_planes = 0, int plane0 = 0) {
   const int pl = blockIdx.y;
+  if (acc_planes == 0) acc_planes = gridDim.y;
   const HT* src = in + (size_t)pl * hw;
   double s = 0.0, q = 0.0;
   if ((hw & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
@@ -166,7 +167,7 @@ __global__ void k_stats_partial(const HT* __restrict__ in, double* __restrict__ 
   if (threadIdx.x == 0) {
     double S = 0, Q = 0;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { S += ss[i]; Q += sq[i]; }
-    double* a = acc + ((size_t)(blockIdx.x % STATS_SLOTS) * gridDim.y + pl) * 2;
+    double* a = acc + ((size_t)(blockIdx.x % STATS_SLOTS) * acc_planes + plane0 + pl) * 2;
     atomicAdd(&a[0], S);
     atomicAdd(&a[1], Q);
   }
@@ -194,6 +195,88 @@ void op_plane_stats(double* acc, const HT* in, float* stats, int planes, int hw,
   gx = std::max(1, std::min(gx, 128));
   hipLaunchKernelGGL(k_stats_partial<HT>, dim3(gx, planes), dim3(256), 0, st, in, acc, hw); SS4K_LAUNCH_OK();
   op_plane_stats_finish(acc, stats, planes, hw, st);
+}
+// the same statistics straight from uint8 NHWC frames (plane 3 f + c = colour c of frame f): every value is (float)byte / 255.0f, the
+// conversion kernel's expression, summed in fp64 like k_stats_partial - a job that never materialises its fp32 planes (FSRCNN reading the
+// frames itself) still owes the service the low-resolution statistics
+__global__ void k_stats_partial_u8(const uint8_t* __restrict__ in, double* __restrict__ acc, int hw, int planes, int plane0 = 0) {
+  const int f = blockIdx.y;
+  const uint8_t* src = in + (size_t)f * hw * 3;
+  __shared__ double lut[256];   // (double)((float)k / 255.0f): the division once per byte value, not once per pixel
+  lut[threadIdx.x & 255] = (double)((float)(threadIdx.x & 255) / 255.0f);
+  __syncthreads();
+  double s[3] = {0, 0, 0}, q[3] = {0, 0, 0};
+  // four pixels = twelve bytes = three aligned words per step where the frame allows it
+  const bool vec = (hw & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+  if (vec) {
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)hw / 4; i += (size_t)gridDim.x * blockDim.x) {
+      const uint32_t w0 = s32[3 * i], w1 = s32[3 * i + 1], w2 = s32[3 * i + 2];
+      const uint32_t b[12] = {w0 & 255, (w0 >> 8) & 255, (w0 >> 16) & 255, w0 >> 24, w1 & 255, (w1 >> 8) & 255, (w1 >> 16) & 255, w1 >> 24,
+                              w2 & 255, (w2 >> 8) & 255, (w2 >> 16) & 255, w2 >> 24};
+#pragma unroll
+      for (int k = 0; k < 12; ++k) { const double v = lut[b[k]]; s[k % 3] += v; q[k % 3] += v * v; }
+    }
+  } else
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)hw; i += (size_t)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const double v = lut[src[3 * i + c]]; s[c] += v; q[c] += v * v; }
+  }
+  __shared__ double ss[3][4], sq[3][4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    for (int off = 32; off > 0; off >>= 1) { s[c] += __shfl_down(s[c], off, 64); q[c] += __shfl_down(q[c], off, 64); }
+    if (lane == 0) { ss[c][wv] = s[c]; sq[c][wv] = q[c]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int c = threadIdx.x;
+    double S = 0, Q = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { S += ss[c][i]; Q += sq[c][i]; }
+    double* a = acc + ((size_t)(blockIdx.x % STATS_SLOTS) * planes + plane0 + 3 * f + c) * 2;
+    atomicAdd(&a[0], S);
+    atomicAdd(&a[1], Q);
+  }
+}
+void op_plane_stats_u8nhwc(double* acc, const uint8_t* in, float* stats, int n, int hw, hipStream_t st) {
+  const int planes = 3 * n;
+  SS4K_REQUIRE(planes <= STATS_MAX_PLANES, "plane_stats: too many planes");
+  SS4K_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 2 * planes * STATS_SLOTS, st));
+  int gx = (hw + 256 * 16 - 1) / (256 * 16);
+  gx = std::max(1, std::min(gx, 128));
+  hipLaunchKernelGGL(k_stats_partial_u8, dim3(gx, n), dim3(256), 0, st, in, acc, hw, planes); SS4K_LAUNCH_OK();
+  op_plane_stats_finish(acc, stats, planes, hw, st);
+}
+void op_plane_stats_u8nhwc_partial(double* acc, const uint8_t* in, int n, int hw, int acc_planes, int plane0, hipStream_t st) {
+  int gx = (hw + 256 * 16 - 1) / (256 * 16);
+  gx = std::max(1, std::min(gx, 128));
+  hipLaunchKernelGGL(k_stats_partial_u8, dim3(gx, n), dim3(256), 0, st, in, acc, hw, acc_planes, plane0); SS4K_LAUNCH_OK();
+}
+template <typename HT>
+void op_plane_stats_partial(double* acc, const HT* in, int planes, int hw, int acc_planes, int plane0, hipStream_t st) {
+  int gx = (hw + 256 * 16 - 1) / (256 * 16);
+  gx = std::max(1, std::min(gx, 128));
+  hipLaunchKernelGGL(k_stats_partial<HT>, dim3(gx, planes), dim3(256), 0, st, in, acc, hw, acc_planes, plane0); SS4K_LAUNCH_OK();
+}
+template void op_plane_stats_partial<float>(double*, const float*, int, int, int, int, hipStream_t);
+template void op_plane_stats_partial<__half>(double*, const __half*, int, int, int, int, hipStream_t);
+// mean / std of 2 x planes plane records: the first `planes` of hw_a values each -> stats_a, the others of hw_b values -> stats_b
+__global__ void k_stats_final2(const double* __restrict__ acc, float* __restrict__ sa, float* __restrict__ sb, int planes, int hw_a, int hw_b) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= 2 * planes) return;
+  double S = 0, Q = 0;
+  for (int s = 0; s < STATS_SLOTS; ++s) { S += acc[((size_t)s * 2 * planes + p) * 2]; Q += acc[((size_t)s * 2 * planes + p) * 2 + 1]; }
+  const double n = (double)(p < planes ? hw_a : hw_b);
+  const double mean = S / n;
+  double var = (Q - S * S / n) / (n - 1.0);   // (k_stats_final's expressions)
+  if (var < 0) var = 0;
+  float* o = p < planes ? sa + 2 * p : sb + 2 * (p - planes);
+  o[0] = (float)mean;
+  o[1] = (float)sqrt(var);
+}
+void op_plane_stats_finish2(const double* acc, float* stats_a, float* stats_b, int planes, int hw_a, int hw_b, hipStream_t st) {
+  hipLaunchKernelGGL(k_stats_final2, dim3((2 * planes + 63) / 64), dim3(64), 0, st, acc, stats_a, stats_b, planes, hw_a, hw_b); SS4K_LAUNCH_OK();
 }
 template void op_plane_stats<float>(double*, const float*, float*, int, int, hipStream_t);
 template void op_plane_stats<__half>(double*, const __half*, float*, int, int, hipStream_t);

@@ -874,7 +874,7 @@ void Model::abort_forward(hipStream_t st) noexcept {
   if (section_open) { ctx->prof_pool.push_back(section); section_open = false; }
   tune_timed = nullptr; cur_lanes = 1;
   chain_rec = false;
-  out_stats_acc = nullptr; out_stats_done = false; out_half = false;
+  out_stats_acc = nullptr; out_stats_done = false; out_half = false; in_u8 = false;
 }
 
 void Model::forward(const float* in, float* out, int n, int h, int w, hipStream_t st) {
@@ -913,8 +913,9 @@ void Model::forward_impl(const float* in, float* out, int n, int h, int w, hipSt
     if (plan_only) { plan_bytes.assign(2, px * 12 * 4); return; }
     acts[0].ensure(px * 12 * 4); acts[1].ensure(px * 12 * 4);
     const bool half_out = out_half; out_half = false;
+    const bool u8_in = in_u8; in_u8 = false;
     fsrcnn_forward(ctx, fsw, desc.scale, in, out, n, h, w, acts[0].as<float>(), acts[1].as<float>(),
-                   fs_exact ? FS_MODE_EXACT : f16 ? FS_MODE_HALF : FS_MODE_SPLIT, st, half_out);
+                   fs_exact ? FS_MODE_EXACT : f16 ? FS_MODE_HALF : FS_MODE_SPLIT, st, half_out, u8_in);
     return;
   }
   lanes_begin(n, h, w, st);
