@@ -61,9 +61,9 @@ struct Model {
   // one-shot request of the caller: `in` of the next forward is the service's uint8 NHWC frame tensor (n = 3 x frames colour planes), not fp32
   // planes.  Only where can_u8_in() says so (an FSRCNN on the matrix-core head: it converts while it loads)
   bool in_u8 = false;
-  // (fp16 mode only: the fp32-grade head sits at 256 registers, the byte loader pushes it into scratch and the stage loses more than the
-  //  conversion pass costs - measured, profiles/NOTES_r06.md)
-  bool can_u8_in() const { return desc.kind == SS4K_FSRCNN && !fs_exact && desc.dtype == SS4K_F16; }
+  // (both matrix-core modes: the fp32-grade head sits at 256 registers and the byte loader costs it four spilled registers, + 4 % on that
+  //  stage - the job still gains 2 % from the passes it no longer makes: profiles/NOTES_r06.md)
+  bool can_u8_in() const { return desc.kind == SS4K_FSRCNN && !fs_exact; }
   bool can_half_out() const {
     return (desc.kind == SS4K_SRVGG || (desc.kind == SS4K_FSRCNN && !fs_exact)) && desc.dtype == SS4K_F16 && !plan_only && !hr_f32;
   }
