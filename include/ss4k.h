@@ -244,7 +244,7 @@ int ss4k_prof_read_kind(ss4k_ctx* ctx, int kind, int64_t* launches, double* tota
 int ss4k_prof_read_family(ss4k_ctx* ctx, int index, char* name, size_t name_capacity, int64_t* launches, double* total_ms, double* flops);
 /* ---- streams
  * HIP serves a process's streams from a few hardware queues.  Two streams on one queue run in order whatever the program says, and
- * some pairs of queues launch slowly while both are busy (measured: 14 us per launch instead of 2.5, profiles/r05_lane_queue.txt);
+ * some pairs of queues launch slowly while both are busy (measured: 14 us per launch instead of 2.5, profiles/earlier/r05/r05_lane_queue.txt);
  * which queue a stream gets depends on how many the process created before it.  This call MEASURES a pair (a 0.2 ms idle kernel on
  * each, then 200 x 1 us kernels interleaved; ~ 3 ms, synchronises both streams) and sets *side_by_side to 1 or 0.  A host that runs
  * several contexts on its own streams calls it once per pair and replaces a stream that fails (keep the failed one alive until the

@@ -16,8 +16,8 @@ import sys as _sys
 #:  * a process that calls the library IN-PROCESS (``_capi`` directly) sets them itself before its first GPU call, or accepts the defaults;
 #:    ``runtime_env_state()`` says which of the two it has.
 #: HIP_FORCE_DEV_KERNARG=1: kernel-argument blocks in device memory (a forward is 213-351 launches; + 0.9 % on the headline job,
-#: profiles/r05_kernarg_ab.txt).  GPU_MAX_HW_QUEUES=8: room for a worker's five side-by-side streams (profiles/r05_hwq_ab.txt); streams
-#: that share a hardware queue run in order and some queue PAIRS are slow (profiles/r05_lane_queue.txt), which the library and the service
+#: profiles/earlier/r05/r05_kernarg_ab.txt).  GPU_MAX_HW_QUEUES=8: room for a worker's five side-by-side streams (profiles/earlier/r05/r05_hwq_ab.txt); streams
+#: that share a hardware queue run in order and some queue PAIRS are slow (profiles/earlier/r05/r05_lane_queue.txt), which the library and the service
 #: test for whatever this is set to (ss4k_stream_pair_check).
 RUNTIME_ENV = {"HIP_FORCE_DEV_KERNARG": "1", "GPU_MAX_HW_QUEUES": "8"}
 

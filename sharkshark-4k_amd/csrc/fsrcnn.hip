@@ -1300,7 +1300,7 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
     if (half) {
       // strips of 64 NU columns (56 / 120 interior).  NU = 2 (round 5, VERDICT r4 item 8: two independent units of work per wave between
       // barriers, half the barriers and halo columns per pixel - at two workgroups per CU instead of four, 66.5 KB of rings each) is
-      // bit-identical and 8.7 % SLOWER on the stage (0.375 against 0.345 ms per 12 planes of 720p, profiles/r05_fs_nu_ab.txt): four
+      // bit-identical and 8.7 % SLOWER on the stage (0.375 against 0.345 ms per 12 planes of 720p, profiles/earlier/r05/r05_fs_nu_ab.txt): four
       // resident workgroups per CU interleave better than one wave does with itself.  Kept as a dev-library switch (SS4K_MH_NU=2).
       int mh_nu = 1;
 #ifdef SS4K_DEV

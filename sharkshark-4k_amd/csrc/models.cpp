@@ -710,7 +710,7 @@ int Model::tune_step(std::map<std::tuple<int, int, int>, LaneTune>& tab, int n, 
 //   INTERLEAVE  200 kernels of 1 us on each stream, enqueued alternately.  Normally the host's enqueue rate bounds this (1.0 ms, twice
 //               the 0.5 ms of 200 kernels on the caller's stream alone).  On the one bad pairing seen (the process's 5th hardware
 //               queue against the NULL stream's, GPU_MAX_HW_QUEUES=8) it takes 5.6 ms - 14 us per launch while both queues are busy,
-//               which is what cost a 351-launch forward its 6 % (profiles/r05_lane_queue.txt).
+//               which is what cost a 351-launch forward its 6 % (profiles/earlier/r05/r05_lane_queue.txt).
 namespace ss4k {
 bool stream_pair_ok(hipStream_t caller, hipStream_t ls) {
   static const bool log = std::getenv("SS4K_LANE_CHECK_LOG") != nullptr;

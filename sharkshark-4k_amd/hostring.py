@@ -3,7 +3,7 @@
 The reference's data flow starts and ends in host memory: the recorder process holds numpy frames and moves each job to the device
 itself (``src/sharkshark/pipeline.py:84-93``: ``torch.tensor(...).to(device)`` + CUDA IPC), the streamer process copies every result back
 (``src/stream/streamer.py:92-98``: ``.to('cpu').numpy()``).  On one GPU that is merely slow - a pageable 44 MB read-back costs as much as
-the job that produced it (``profiles/r05_pcie_inclusive.txt``: 63.9 against 127.0 frames/s).  On a node of G GPUs it is also wrong-shaped:
+the job that produced it (``profiles/earlier/r05/r05_pcie_inclusive.txt``: 63.9 against 127.0 frames/s).  On a node of G GPUs it is also wrong-shaped:
 the caller would have to open a context on every GPU to put job ``s`` into the HBM of GPU ``s % G``.  So the node takes HOST frames and each
 worker moves its own:
 

@@ -30,7 +30,7 @@ launch boundaries and partly filled tile rounds of job i - what frame lanes do i
 single-set path (same kernels, same weights).  The worker keeps at most ``overlap_sets - 1`` results of ALTERNATING jobs back while it
 enqueues their successors, and hands each over as soon as its end event has fired (``BaseService``: held results; a multi-frame job flushes
 them and leaves at once, as in the reference's loop); ``upscale()`` called directly stays synchronous with the current stream unless ``wait=False``.
-Measured on one box (RRDBNet x2, 720p, ``profiles/r05_n1_probe_sets.txt``): one set 108.8 frames/s, two 122.8, three 125.6, four 124.9 -
+Measured on one box (RRDBNet x2, 720p, ``profiles/earlier/r05/r05_n1_probe_sets.txt``): one set 108.8 frames/s, two 122.8, three 125.6, four 124.9 -
 against 127.5 for four-frame jobs; two- and four-frame jobs gain nothing from alternating (125.5 / 125.7 against 125.0 / 127.5), so they
 stay on set 0.  Cost per extra set: a copy of the SR weights and activation workspace (RRDBNet x2 at 720p: 67 MB + 1.25 GB), built on the
 first one-frame job.  HIP serves a process's streams from a few hardware queues: the sets' streams are checked once to really run side by
@@ -408,7 +408,7 @@ class HipUpscalerService(BaseUpscalerService):
         """A new stream that passes the library's pair test (``ss4k_stream_pair_check``, ~ 3 ms a pair) against every stream of `others`: HIP
         serves a process's streams from a few hardware queues, two streams of one queue run in order, and some PAIRS of queues are slow while
         both are busy - or while one is merely WAITING for the other, as the current stream does for a job set's (measured: a one-frame job
-        17.5 instead of 9.5 ms on a set-0 stream that was the process's 4th, `profiles/r05_lane_queue.txt`).  Which queue a stream gets depends
+        17.5 instead of 9.5 ms on a set-0 stream that was the process's 4th, `profiles/earlier/r05/r05_lane_queue.txt`).  Which queue a stream gets depends
         on how many the process created before."""
         if under_profiler():
             return torch.cuda.Stream(self.torch_device)
@@ -444,7 +444,7 @@ class HipUpscalerService(BaseUpscalerService):
     def _check_streams(self, frames: torch.Tensor, tries: int = 4) -> None:
         """One-off, at the first small job: do the job sets' streams really run side by side?  HIP serves a process's streams from a few
         hardware queues; two streams that share one are executed in order, whatever the program says - seen on a process that had created
-        many streams before (profiles/r05_n1_probe_streams.txt: 107 instead of 122 frames/s, silently).  So, for every pair of sets: six
+        many streams before (profiles/earlier/r05/r05_n1_probe_streams.txt: 107 instead of 122 frames/s, silently).  So, for every pair of sets: six
         one-frame jobs alternating over the two, first with both sets on ONE stream, then each on its own; side by side they take 0.88-0.92 of
         the time in order (what is gained is the overlap of a job's tail with the next one's head, so a single pair of jobs shows only half of
         it), on a shared queue 0.97-1.2.  A set that does not pass takes another stream and is checked again.  Blocks the host for a few dozen

@@ -115,7 +115,7 @@ def test_config2_rrdbnet_x2_720p_fp16_service_vs_oracle(ctx):
     print(f"configs[2] fp16 vs oracle: PSNR {p:.2f} dB, max |delta| {int(d.max())} LSB, {float((d > 0).float().mean()):.4%} bytes differ")
     record_measured("config2_rrdbnet_x2_720p_fp16_service", psnr_db=p, max_lsb=int(d.max()), bytes_differ=float((d > 0).float().mean()),
                     bytes_2lsb=int((d >= 2).sum()), asserted="PSNR >= 55.5 dB, max <= 2 LSB, at most 16 bytes at 2 LSB")
-    # measured 57.50 dB / 2 LSB - the 2 in ONE byte of 11 059 200 (profiles/r05_parity_measured.json: bytes_2lsb = 1); with either of the
+    # measured 57.50 dB / 2 LSB - the 2 in ONE byte of 11 059 200 (profiles/earlier/r05/r05_parity_measured.json: bytes_2lsb = 1); with either of the
     # two not-bit-identical route choices pinned off (NO_W16, NO_UPS_PRESUM) the worst byte is 1 LSB, with both off it is 2 again: a byte
     # on a rounding edge that any change of summation order moves, not the cost of one route.  Asserted at measured - 2 dB, the measured
     # worst byte, and a count: a handful of rounding-edge bytes may reach 2 LSB, thousands of them (or one byte at 3) is a regression.
@@ -173,7 +173,7 @@ def test_config3_bsvd_rrdbnet_fp32_vs_oracle_small(ctx, rate, out_shape, in_hw):
             assert_close(up.read_tap(which), w, what=f"configs[3] fp32 job {job} tap {key}")
 
 
-# measured (profiles/r05_parity_measured.json) + 1 LSB / - 2 dB
+# measured (profiles/earlier/r05/r05_parity_measured.json) + 1 LSB / - 2 dB
 C3_PSNR_DB, C3_MAX_LSB = 55.9, 2   # measured 57.93 dB, 1 LSB (both jobs)
 
 
@@ -272,7 +272,7 @@ def test_job_whose_plane_exceeds_4gb_is_routed_as_a_whole(ctx):
     torch.cuda.empty_cache()
 
 
-C4_PSNR_DB, C4_MAX_LSB = 55.5, 2   # measured 57.55 dB, 1 LSB (profiles/r05_parity_measured.json)
+C4_PSNR_DB, C4_MAX_LSB = 55.5, 2   # measured 57.55 dB, 1 LSB (profiles/earlier/r05/r05_parity_measured.json)
 
 
 # ------------------------------------------------------------------------------ (f) fp16 storage at realistic activation ranges
@@ -300,7 +300,7 @@ def test_rrdbnet_fp16_full_gain_weights(ctx, nb):
     peak = float(want.abs().max())
     p = psnr(y16, want, peak=peak)
     print(f"fp16 vs oracle with gain-1.0 RDB weights, {nb} blocks: output peak {peak:.3g}, PSNR {p:.1f} dB")
-    bar = {6: 72.0, 23: 67.0}[nb]   # measured 74.4 dB / 69.1 dB (profiles/r05_parity_measured.json), asserted at - 2 dB
+    bar = {6: 72.0, 23: 67.0}[nb]   # measured 74.4 dB / 69.1 dB (profiles/earlier/r05/r05_parity_measured.json), asserted at - 2 dB
     record_measured(f"rrdbnet_fp16_full_gain_{nb}blocks", psnr_db=p, out_peak=peak, asserted=f"PSNR > {bar} dB (peak = output peak)")
     assert p > bar, f"PSNR {p:.1f} dB at output peak {peak:.3g}"
 

@@ -184,7 +184,7 @@ def test_worker_loop_delivers_in_order_with_the_overlap(want):
 def test_service_soak_mixed_job_sizes_through_one_worker():
     """`tools/service_soak.py`: 400 jobs of 1 / 2 / 4 frames, every input a fresh tensor that the producer drops right after the push, through one
     spawned worker with the job sets; every result byte for byte against an in-process single-set upscaler.  (Without the service's hold on a
-    job's input until its end event has fired, ~ 2 jobs in 1000 come back wrong: `profiles/r05_service_soak.txt`.)"""
+    job's input until its end event has fired, ~ 2 jobs in 1000 come back wrong: `profiles/earlier/r05/r05_service_soak.txt`.)"""
     import os
     import subprocess
     import sys

@@ -137,7 +137,7 @@ def test_srvgg_fp16_psnr(ctx):
     m = _capi.Model(ctx, desc, W.flatten(table, W.srvgg_keys(4)))
     p = psnr(m(dev(g["x"])), g["y"])
     record_measured("srvgg_f64_c4_x4_fp16_vs_reference_golden", psnr_db=p, asserted="PSNR > 85.5 dB (peak 1.0)")
-    assert p > 85.5, p   # measured 87.5 dB (profiles/r05_parity_measured.json), asserted at - 2 dB; the 32-conv default: tests/test_gpu_srvgg_default.py
+    assert p > 85.5, p   # measured 87.5 dB (profiles/earlier/r05/r05_parity_measured.json), asserted at - 2 dB; the 32-conv default: tests/test_gpu_srvgg_default.py
 
 
 # ------------------------------------------------------------------------------ BSVD
@@ -646,7 +646,7 @@ def test_fsrcnn_f16_mode_vs_oracle(ctx, factor, tag, shape):
     err = float((got - want).abs().max())
     record_measured(f"fsrcnn_f16_x{factor}_{tag}_{shape[2]}x{shape[3]}", psnr_db=p, max_abs_err=err, peak=peak)
     print(f"fsrcnn f16 x{factor} {tag} {shape}: PSNR {p:.1f} dB, max |d| {err:.3g} of peak {peak:.3g}")
-    # measured 69.1-85.8 dB over the six cases (profiles/r05_parity_measured.json): asserted at the worst case - 2 dB
+    # measured 69.1-85.8 dB over the six cases (profiles/earlier/r05/r05_parity_measured.json): asserted at the worst case - 2 dB
     assert p > 67.0 and err < 1e-2 * max(1.0, peak)
 
 

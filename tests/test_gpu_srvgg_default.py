@@ -60,7 +60,7 @@ def test_srvgg32_wild_slopes_reach_both_epilogue_forms():
     assert min(float(np.asarray(t[f"body.{2 * i + 1}.weight"]).min()) for i in range(33)) < -0.4
 
 
-# asserted at measured - 2 dB / + 1 LSB; measured values: profiles/r05_parity_measured.json
+# asserted at measured - 2 dB / + 1 LSB; measured values: profiles/earlier/r05/r05_parity_measured.json
 S32_PSNR_DB, S32_MAX_LSB = 61.8, 2     # measured 63.89 dB, 1 LSB (2.7 % of the bytes differ)
 S32W_PSNR_DB, S32W_MAX_LSB = 61.5, 2   # measured 63.56 dB, 1 LSB (2.9 %)
 

@@ -1,7 +1,7 @@
 """GPU: the stream-pair test (``ss4k_stream_pair_check``) and the context's self-check of its lane stream.
 
 HIP maps a process's streams onto a few hardware queues; two streams of one queue run in order, and the 5th queue of a process is slow
-against the NULL stream's while both are busy (``profiles/r05_lane_queue.txt``: a 4-frame RRDBNet job with two launch chains 110 instead of
+against the NULL stream's while both are busy (``profiles/earlier/r05/r05_lane_queue.txt``: a 4-frame RRDBNet job with two launch chains 110 instead of
 117 frames/s when three streams had been created before the context's lane stream).  ``ss4k_ctx::lane_check`` (csrc/models.cpp) measures the
 pair before the first fork and replaces a lane stream that fails.
 """
