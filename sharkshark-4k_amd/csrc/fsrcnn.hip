@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
   // (fp16 mode: the 12-channel tensor is fp16, 8 bytes per pixel and group; .x/.y of a0 and a1 carry the packed pairs.)  Every load is
   // UNCONDITIONAL - address clamped into the image, the value replaced where it is used - and several rows are in flight: with one row
   // ahead and the load under a branch (rounds 2-5) the fp16 mode, whose row is 14 MFMAs, spent 63 % of its wave cycles in s_waitcnt
-  // (profiles/r06_fsrcnn_f16_sq_counters.json: SQ_WAIT_ANY) - a row is shorter than a trip to HBM.
+  // (SQ_WAIT_ANY in the round's first counter pass, profiles/NOTES_r06.md 6) - a row is shorter than a trip to HBM.
   // fp16 mode: FIVE rows per trip of the unrolled loop - the five output rows under construction then rotate by INDEX (row j of sub-step u
   // is register set (j + JSTEP u) % 5: a compile-time constant) instead of by ten register moves per row
   constexpr int PF = SPLIT ? (S == 2 ? 3 : 2) : 5;   // (fp32-grade: three | two rows in flight fit the 170 registers of three workgroups per CU)
