@@ -248,7 +248,11 @@ int ss4k_prof_read_family(ss4k_ctx* ctx, int index, char* name, size_t name_capa
  * which queue a stream gets depends on how many the process created before it.  This call MEASURES a pair (a 0.2 ms idle kernel on
  * each, then 200 x 1 us kernels interleaved; ~ 3 ms, synchronises both streams) and sets *side_by_side to 1 or 0.  A host that runs
  * several contexts on its own streams calls it once per pair and replaces a stream that fails (keep the failed one alive until the
- * replacement exists, or the new stream lands on the same queue).  The library does this itself for each ctx's internal lane stream. */
+ * replacement exists, or the new stream lands on the same queue).  The library does this itself for each ctx's internal lane stream
+ * (once per ctx and caller stream, before the first two-chain forward); that built-in test is switched off by the environment variable
+ * SS4K_NO_LANE_CHECK=1, is skipped while the caller's stream is being captured into a graph or a profiler has preloaded itself
+ * (ROCP_TOOL_LIBRARIES / LD_PRELOAD of rocprofiler: counter collection serialises kernels), and leaves the NULL stream alone while any
+ * other stream of the process is under a global-mode capture. */
 int ss4k_stream_pair_check(ss4k_ctx* ctx, void* hip_stream_a, void* hip_stream_b, int* side_by_side);
 
 /* Conv sections: wall time, on the caller's stream, from the first conv launch of every network forward to the end
