@@ -17,6 +17,15 @@
 namespace ss4k {
 
 __device__ __forceinline__ float prelu(float v, float a) { return v >= 0.f ? v : a * v; }
+// PReLU of the matrix-core modes as max(v, a v): one instruction less than compare + select.  It is PReLU for a <= 1 only; a model of those
+// modes carries every channel with a > 1 negated through its activation (weights folded when it is built, models.cpp: exact, rounding
+// to nearest is sign-symmetric), where max(-v, -a v) = -PReLU(v).  The exact-fp32 kernels (unfolded weights) keep prelu().
+__device__ __forceinline__ float prelu_mx(float v, float a) {
+  const float t = a * v;
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(t));   // (= fmaxf for non-NaN inputs, one instruction)
+  return r;
+}
 
 __global__ __launch_bounds__(256) void k_fs_head(const float* __restrict__ in, float* __restrict__ out,
                                                  const float* __restrict__ wf, const float* __restrict__ bf,
@@ -501,7 +510,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const float v = SPLIT ? fmaf(E2[4 * k + t], LO, E1[4 * k + t]) : E1[4 * k + t];
-            ev[4 * k + t] = prelu(v, sv[t]);
+            ev[4 * k + t] = prelu_mx(v, sv[t]);
           }
         }
 #pragma unroll
@@ -798,7 +807,7 @@ __global__ __launch_bounds__(256, 2) void k_fs_head_m(const float* __restrict__ 
               const float sl[4] = {sv.x, sv.y, sv.z, sv.w};
               float ev[4];
 #pragma unroll
-              for (int t = 0; t < 4; ++t) ev[t] = prelu(fmaf(acc2[4 * q + t], LO, acc[4 * q + t]), sl[t]);
+              for (int t = 0; t < 4; ++t) ev[t] = prelu_mx(fmaf(acc2[4 * q + t], LO, acc[4 * q + t]), sl[t]);
               split2(ev[0], ev[1], E[0][2 * q], E[1][2 * q]);
               split2(ev[2], ev[3], E[0][2 * q + 1], E[1][2 * q + 1]);
             }
@@ -824,7 +833,7 @@ __global__ __launch_bounds__(256, 2) void k_fs_head_m(const float* __restrict__ 
           const float sl[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
           float of[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) of[i] = prelu(fmaf(d2l[i], LO, d2[i]), sl[i]);
+          for (int i = 0; i < 8; ++i) of[i] = prelu_mx(fmaf(d2l[i], LO, d2[i]), sl[i]);
           // lane half 0 holds channel groups 0 (registers 0-3) and 2 (registers 4-7), lane half 1 group 1, of pixel P + 2n + g
           const int xg = P + 2 * n + g;
           if (xg < w) {
@@ -1008,7 +1017,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
             d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, d2, 0, 0, 0);
           }
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = prelu(fmaf(d2[i], LO, d1[i]), slo[i]);
+          for (int i = 0; i < 4; ++i) v[i] = prelu_mx(fmaf(d2[i], LO, d1[i]), slo[i]);
           const int xu = x0 - FM_HALO + 16 * u;   // wave-uniform: only units that straddle the image edge mask
           if (xu < 0 || xu + 15 >= w) {
             const bool ok = x >= 0 && x < w;       // a column outside the image is zero padding for the next layer
@@ -1246,6 +1255,7 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
                     int w, float* ws12a, float* ws12b, int mode, hipStream_t st, bool out_half, bool in_u8) {
   const bool exact = mode == FS_MODE_EXACT, half = mode == FS_MODE_HALF;
   SS4K_REQUIRE(!out_half || half, "FSRCNN: an fp16 output tensor is offered in fp16 mode only");
+  SS4K_REQUIRE(exact || W.prelu_le1, "FSRCNN matrix-core modes: the weight blob is not sign-folded for the max-form PReLU (models.cpp)");
   SS4K_REQUIRE(!in_u8 || (!exact && planes % 3 == 0), "FSRCNN: uint8 NHWC input is read by the matrix-core head only, three colour planes per frame");
   const size_t total = (size_t)planes * h * w;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);

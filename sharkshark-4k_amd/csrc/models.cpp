@@ -294,12 +294,12 @@ void Model::build(const float* w, size_t n) {
     for (int c = 0; c < 56; ++c) for (int t = 0; t < 81; ++t) wd[(size_t)t * 56 + c] = p[(size_t)c * 81 + t];
     off[k++] = push(wd);
     fsw.b_deconv = *pc.take(1);
-    // fp16 mode: PReLU as max(v, v s) - two packed instructions instead of three (fsrcnn.hip prelu_h2) - is PReLU only for s <= 1; for a
+    // Matrix-core modes: PReLU as max(v, v s) - an instruction less than the select form (fsrcnn.hip prelu_h2 / prelu_mx) - is PReLU only for s <= 1; for a
     // channel with s > 1 it is min(v, v s) = -max(-v, -v s).  The real checkpoints have such channels (T91 x2: one at 1.04; x4: up to 9.1).
     // So every channel with s > 1 is carried NEGATED through its activation: its producing weights and bias are negated here, and so are
     // the weights with which the next layer consumes it.  Rounding to nearest is sign-symmetric in every step (products, fp32 sums, fp16
     // conversions), so the network's values are bit for bit what they were; the kernels then take the max form for every channel.
-    if (desc.dtype == SS4K_F16 && !fs_exact) {
+    if (!fs_exact) {   // (both matrix-core modes: fp16 and fp32-grade)
       // (offsets into `blob`: 0 w_feat [25][56], 1 b_feat, 2 a_feat, 3 w_shrink [56][12], 4 b, 5 a, 6 + 3l w_map[l] [9][12][12] (tap, cin, cout),
       //  7 + 3l b, 8 + 3l a, 18 w_expand [12][56], 19 b, 20 a, 21 w_deconv [81][56] (tap, cin))
       auto flip = [&](float* p, size_t count, size_t stride) { for (size_t i = 0; i < count; ++i) p[i * stride] = -p[i * stride]; };

@@ -626,6 +626,21 @@ def _wild_slopes(table, seed):
     return t
 
 
+@pytest.mark.parametrize("factor,shape", [(2, (3, 1, 70, 141)), (4, (2, 1, 45, 66))])
+def test_fsrcnn_f32_grade_wild_slopes_vs_oracle(ctx, factor, shape):
+    """fp32-grade mode with every PReLU slope redrawn from [-0.6, 1.8]: the matrix-core kernels take max(v, v s) and carry the channels with a
+    slope above 1 negated (weights folded at model build) - at the literal fp32 tolerance against the oracle, and against the exact-fp32
+    kernels, which run on the unfolded weights with the select form."""
+    table = _wild_slopes(W.fsrcnn_table(seed=factor), 10 + factor)
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[3]))
+    with torch.no_grad():
+        want = onets.fsrcnn(x, table, factor)
+    got = factory.build_model_fsrcnn(ctx, factor=factor, weights=table)(x.cuda()).cpu()
+    assert_close(got, want, what=f"fsrcnn x{factor} wild slopes, fp32-grade")
+    exact = _capi.Model(ctx, _capi.make_desc(_capi.FSRCNN, _capi.F32, scale=factor, flags=_capi.MODEL_FS_EXACT), W.flatten(table, W.fsrcnn_keys()))(x.cuda()).cpu()
+    assert_close(exact, want, what=f"fsrcnn x{factor} wild slopes, exact kernels")
+
+
 @pytest.mark.parametrize("factor,tag,shape", [(2, "t91", (3, 1, 150, 333)), (4, "t91", (3, 1, 97, 130)), (2, "syn", (12, 1, 64, 260)),
                                               (2, "syn", (1, 1, 5, 7)), (4, "syn", (2, 1, 33, 129)), (2, "t91", (1, 1, 256, 256)),
                                               (2, "wild", (3, 1, 70, 141)), (4, "wild", (2, 1, 45, 66))])
