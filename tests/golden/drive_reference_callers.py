@@ -191,6 +191,8 @@ def drive_image_server():
     while IP.upscaler is None and time.time() < deadline:   # ITS handler thread runs ITS start_pipeline()
         time.sleep(0.01)
     svc = IP.upscaler
+    while not svc.proc.is_alive() and time.time() < deadline:   # (the module sets its global BEFORE it calls start(): wait for the worker itself)
+        time.sleep(0.01)
     assert type(svc) is CpuDoubleOfHipService and svc.exit_on_error is True and svc.on_queue is IP.pipeline_onqueue
     assert svc.ctor_seen["jit_mode"] is False and svc.ctor_seen["lr_hr_resize"] is False and svc.ctor_seen["batch_size"] == 1
     assert svc.proc.is_alive()

@@ -212,3 +212,50 @@ def test_reference_callers_drive_the_service_with_one_import_swapped():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "drive_reference_callers.py")], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DRIVE OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+class HeldResults(NearestDouble):
+    """A double whose results are 'on the device' for a while: ready 30 ms after the job was taken, up to two of them may be held."""
+
+    def proc_init(self):
+        self.ready_at = {}
+        self.polls = 0
+
+    def proc_job_recieved(self, job):
+        entry = super().proc_job_recieved(job)
+        self.ready_at[entry.step] = time.time() + 0.03
+        return entry
+
+    def proc_deliver_lag(self):
+        return 2
+
+    def proc_result_ready(self, entry):
+        self.polls += 1
+        return time.time() >= self.ready_at[entry.step]
+
+    def proc_before_deliver(self, entry):
+        entry.profiler.set("delivered_after_ready_s", time.time() - self.ready_at[entry.step])
+        entry.profiler.set("polls", self.polls)
+
+
+def test_held_results_leave_when_ready_not_when_a_successor_arrives():
+    """The worker loop's held results (BaseService): an ISOLATED job's result leaves as soon as it is ready - no successor, no idle flush
+    needed - in job order, and more than `lag` results are never held (the oldest then leaves at once, ready or not)."""
+    svc = HeldResults()
+    svc.start()
+    try:
+        t0 = time.time()
+        svc.push_job(UpscalerQueueEntry(frames=torch.zeros(1, 2, 2, 3, dtype=torch.uint8), step=0, profiler=Profiler()))
+        lone = svc.get_result(timeout=60)
+        took = time.time() - t0
+        assert lone.step == 0 and lone.profiler.data["polls"] >= 2            # it WAS held and polled ...
+        assert 0 <= lone.profiler.data["delivered_after_ready_s"] < 0.02      # ... and left within a poll interval of becoming ready
+        assert took < 5.0
+        for step in range(1, 7):                                              # a burst: at most two are held, order is kept
+            svc.push_job(UpscalerQueueEntry(frames=torch.zeros(1, 2, 2, 3, dtype=torch.uint8), step=step, profiler=Profiler()))
+        got = [svc.get_result(timeout=60) for _ in range(6)]
+        assert [g.step for g in got] == [1, 2, 3, 4, 5, 6]
+        forced = [g for g in got if g.profiler.data["delivered_after_ready_s"] < 0]   # pushed out by the lag bound before they were ready
+        assert len(forced) >= 1 and got[-1].profiler.data["delivered_after_ready_s"] >= 0
+    finally:
+        svc.stop()
