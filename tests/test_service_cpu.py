@@ -223,7 +223,7 @@ class HeldResults(NearestDouble):
 
     def proc_job_recieved(self, job):
         entry = super().proc_job_recieved(job)
-        self.ready_at[entry.step] = time.time() + 0.03
+        self.ready_at[entry.step] = time.time() + (0.03 if entry.step == 0 else 1.0)
         return entry
 
     def proc_deliver_lag(self):
@@ -249,13 +249,14 @@ def test_held_results_leave_when_ready_not_when_a_successor_arrives():
         lone = svc.get_result(timeout=60)
         took = time.time() - t0
         assert lone.step == 0 and lone.profiler.data["polls"] >= 2            # it WAS held and polled ...
-        assert 0 <= lone.profiler.data["delivered_after_ready_s"] < 0.02      # ... and left within a poll interval of becoming ready
+        assert 0 <= lone.profiler.data["delivered_after_ready_s"] < 0.5       # ... and left when it became ready (a poll interval is 0.2 ms; a loaded box gets slack)
         assert took < 5.0
         for step in range(1, 7):                                              # a burst: at most two are held, order is kept
             svc.push_job(UpscalerQueueEntry(frames=torch.zeros(1, 2, 2, 3, dtype=torch.uint8), step=step, profiler=Profiler()))
         got = [svc.get_result(timeout=60) for _ in range(6)]
         assert [g.step for g in got] == [1, 2, 3, 4, 5, 6]
-        forced = [g for g in got if g.profiler.data["delivered_after_ready_s"] < 0]   # pushed out by the lag bound before they were ready
-        assert len(forced) >= 1 and got[-1].profiler.data["delivered_after_ready_s"] >= 0
+        # (results of the burst are ready a second after their job: the six jobs are in long before that)
+        forced = [g.step for g in got if g.profiler.data["delivered_after_ready_s"] < 0]   # pushed out by the lag bound before they were ready
+        assert forced == [1, 2, 3, 4] and all(g.profiler.data["delivered_after_ready_s"] >= 0 for g in got[-2:])
     finally:
         svc.stop()
