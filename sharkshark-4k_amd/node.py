@@ -117,6 +117,7 @@ class UpscalerNode:
             svc.start()
             fresh.append(svc)
         self._wait_ready(fresh, timeout)
+        self.dispatcher.rescue_orphans()   # (host steps still inside the dead workers' rings: re-queued before those rings go)
         for k, svc in zip(slots, fresh):
             old = self.services[k]
             self.services[k] = svc

@@ -20,6 +20,9 @@ Restates what the reference's ``TwitchUpscalerPostStreamer`` does around the ups
   ``frame_skips=False`` - is waited for while finished results are copied out of the rings to make room.  Device tensors pass through
   untouched (a tensor on another GPU than the worker's is copied over once by the worker: ``report()['peer_copies']``); host frames for a
   worker without rings, or bigger than a slot, travel as pickled tensors the old way (``report()['host_fallback']``);
+* a HOST job that was inside a worker when it died is not lost: its frames are still in that worker's input ring (shared memory the
+  parent holds), so the step is copied into a living worker's ring and queued again (``report()['rescued']``; results still leave in step
+  order).  Device-tensor jobs have no such copy and are counted lost, as before;
 * a result that never arrives (a worker died, or ``BaseService`` dropped it on a full result queue)
   must not stall a 24/7 stream: a step that keeps later results waiting for more than
   ``lost_after_s`` seconds, or behind more than ``max_reorder`` pending results, is declared lost,
@@ -70,6 +73,8 @@ class StreamDispatcher:
         self._lent_steps = set()
         self.host_jobs_total = 0
         self.host_fallback_total = 0
+        self.rescued_total = 0
+        self._jobs: Dict[int, tuple] = {}         # queued host step -> (shape, audio, profiler, rescues so far): what a re-submission needs
         self._peer_copies: Dict[int, int] = {}    # service index -> the worker's running count, from its latest result
         self.push_timeout = 10.0
 
@@ -177,6 +182,7 @@ class StreamDispatcher:
                 self._owner[step] = svc
                 if slots is not None:
                     self._slots[step] = (svc, slots[0], slots[1])
+                    self._jobs[step] = (shape, audio, profiler, 0)
             except queue.Full:
                 if slots is not None:
                     self._pool(svc).give_in(slots[0])
@@ -185,6 +191,41 @@ class StreamDispatcher:
                 self.dropped_total += 1
                 print("StreamDispatcher: upscaler queue full, job skipped", file=sys.stderr)
         return queued
+
+    def rescue_orphans(self) -> int:
+        """Host steps whose worker has died (and whose results, if any, have been collected): their frames still sit in the dead worker's
+        input ring - copy them into a living worker's ring and queue them again.  Returns how many were re-submitted."""
+        n = 0
+        for step, owner in list(self._owner.items()):
+            held, job = self._slots.get(step), self._jobs.get(step)
+            if held is None or job is None or self._alive(owner) or not owner.result_queue.empty() or owner.host_rings is None:
+                continue
+            shape, audio, profiler, tries = job
+            if tries >= 3:
+                continue
+            try:
+                svc = self._pick(step)
+            except RuntimeError:
+                return n          # nobody left alive
+            pool = self._pool(svc)
+            if pool is None or not svc.host_rings[0].fits(shape):
+                continue
+            slots = pool.take()
+            if slots is None:
+                continue          # (next poll)
+            try:
+                svc.host_rings[0].write(slots[0], owner.host_rings[0].view(held[1], shape))
+                svc.push_job_nowait(UpscalerQueueEntry(frames=HostFrames(slot=slots[0], out_slot=slots[1], shape=shape), audio_segment=audio,
+                                                       step=step, profiler=profiler))
+            except (queue.Full, ValueError, TypeError):   # (a closed ring, a full queue: leave the step to the lost-step logic)
+                pool.give_in(slots[0]); pool.give_out(slots[1])
+                continue
+            self._owner[step] = svc
+            self._slots[step] = (svc, slots[0], slots[1])
+            self._jobs[step] = (shape, audio, profiler, tries + 1)
+            self.rescued_total += 1
+            n += 1
+        return n
 
     def _emit_ready(self, force: bool = False):
         out = []
@@ -204,11 +245,15 @@ class StreamDispatcher:
                 # queue first) cannot come back: no point in waiting lost_after_s for it
                 owner = self._owner.get(self.next_emit)
                 orphan = owner is not None and not self._alive(owner) and owner.result_queue.empty()
+                job = self._jobs.get(self.next_emit)
+                if orphan and job is not None and job[3] < 3 and getattr(owner, "host_rings", None) is not None:
+                    orphan = False   # (a host step: rescue_orphans() will queue it again as soon as a living worker has a free slot)
                 if force or orphan or now - self._stalled_since > self.lost_after_s:
                     nxt = min(self._pending)  # lost downstream: do not stall the stream (poll() keeps every pending step >= next_emit)
                     gone = [s for s in range(self.next_emit, nxt) if s not in self._dropped]
                     self.lost_total += len(gone)
                     for g in gone:
+                        self._jobs.pop(g, None)
                         self._owner.pop(g, None)   # (ring slots of a lost step stay taken: its worker may still write the result; they
                                                     #  come back with a late result, or go with the worker)
                     self._dropped.difference_update(range(self.next_emit, nxt))
@@ -239,6 +284,7 @@ class StreamDispatcher:
                     break
                 got_any = True
                 held = self._slots.pop(e.step, None)
+                self._jobs.pop(e.step, None)
                 if isinstance(e.frames, HostFrames):
                     e.frames = svc.host_rings[1].view(e.frames.out_slot, e.frames.shape)
                     if held is not None:
@@ -267,6 +313,7 @@ class StreamDispatcher:
         deadline = time.monotonic() + timeout
         while True:
             got_any = self._collect()
+            self.rescue_orphans()
             ready = self._emit_ready(force=len(self._pending) > self.max_reorder)
             if ready or time.monotonic() >= deadline:
                 for e in ready:
@@ -292,5 +339,5 @@ class StreamDispatcher:
     def report(self) -> dict:
         return {"frame_step": self.frame_step, "dropped": self.dropped_total, "lost": self.lost_total, "late": self.late_total,
                 "pending": len(self._pending), "rerouted": self.rerouted_total, "host_jobs": self.host_jobs_total,
-                "host_fallback": self.host_fallback_total, "peer_copies": [self._peer_copies.get(k, 0) for k in range(len(self.services))],
+                "host_fallback": self.host_fallback_total, "rescued": self.rescued_total, "peer_copies": [self._peer_copies.get(k, 0) for k in range(len(self.services))],
                 "upscaler.inputq": [s.job_queue.qsize() for s in self.services]}

@@ -153,3 +153,30 @@ def test_ring_view_travels_as_a_handle_and_unpickles_as_a_tensor():
     ring.close()
     with pytest.raises(RuntimeError, match="has not mapped"):
         pickle.loads(blob)
+
+
+def test_host_steps_inside_a_killed_worker_are_rescued_not_lost(tmp_path):
+    """A worker dies with host jobs queued inside it: their frames are still in ITS input ring, which the parent holds - the dispatcher
+    copies them into the living worker's ring and queues them again; every step arrives, in order, none is lost."""
+    import signal
+    node = _node(tmp_path, 2, frame_skips=False, host_slots=6, lost_after_s=30.0)
+    node.start(timeout=300)
+    try:
+        frames = torch.arange(48, dtype=torch.uint8).view(48, 1, 1, 1).expand(48, 4, 6, 3).contiguous()
+        # stop worker 1 so that its jobs pile up inside it, then kill it
+        os.kill(node.services[1].proc.pid, signal.SIGSTOP)
+        steps = node.submit_batch(frames)                 # 12 jobs: six for each worker
+        assert steps == list(range(12))
+        time.sleep(0.3)
+        os.kill(node.services[1].proc.pid, signal.SIGKILL)
+        node.services[1].proc.join(30)
+        out = node.drain(steps, timeout=120)
+        assert [e.step for e in out] == steps
+        for e in out:
+            assert e.frames[:, 1, 1, 0].tolist() == list(range(4 * e.step, 4 * e.step + 4))
+            assert int(e.frames[0, 0, 0, 0]) == 0          # every job was computed by worker 0 in the end ... (rank stamp)
+        rep = node.report()
+        assert rep["lost"] == 0 and rep["rescued"] == 6 and rep["alive"] == [True, False], rep
+    finally:
+        node.stop()
+        node.close()

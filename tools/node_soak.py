@@ -3,8 +3,9 @@
 
 For `seconds`: host frames through ``UpscalerNode(devices=[0, 0])`` (the product path: pinned rings, in-worker copy streams, ordered fan-in),
 every result compared byte for byte with an in-process upscaler; every `kill_every` seconds one worker (alternating) is killed with
-SIGKILL in mid-stream, the stream goes on over the survivor, ``replace_dead()`` starts a fresh child in the slot.  Checked: zero wrong
-frames; every step either arrives in order or is counted lost, and only steps that were inside the killed worker are lost; the
+SIGKILL in mid-stream, the stream goes on over the survivor (the host steps that were inside the victim are re-queued from its input
+ring: ``report()['rescued']``), ``replace_dead()`` starts a fresh child in the slot.  Checked: zero wrong frames; every step either arrives
+in order or is counted lost, and only steps that were inside the killed worker can be lost; the
 SURVIVOR's device memory does not grow (``hipMemGetInfo`` before / after, this process holds the reference model only).
 
 usage: python tools/node_soak.py [seconds=300] [kill_every=30]
@@ -96,7 +97,7 @@ if __name__ == "__main__":
         node.stop()
         node.close()
     growth = free_marks[0] - min(free_marks[1:]) if len(free_marks) > 1 else 0.0
-    print(f"{seconds:.0f} s, {kills} kill/replace cycles: {good} jobs right, {bad} wrong, {rep['lost']} lost (<= {inside_killed} inside killed workers), "
+    print(f"{seconds:.0f} s, {kills} kill/replace cycles: {good} jobs right, {bad} wrong, {rep['lost']} lost, {rep['rescued']} rescued ({inside_killed} were inside killed workers), "
           f"{rep['rerouted']} rerouted, free device memory with both workers up: {free_marks[0]:.0f} MB at the start, min {min(free_marks):.0f} MB later "
           f"(growth {growth:.0f} MB)")
     ok = bad == 0 and rep["lost"] <= inside_killed and growth < 256 and good > 0
