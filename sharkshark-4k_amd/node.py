@@ -27,7 +27,9 @@ What it does, in order:
 * a ``StreamDispatcher`` fans jobs out ``step % G`` over the LIVING workers and re-orders results by ``step``;
 * a worker that dies later is routed around at once (the node runs on G - 1; the jobs that were inside it are counted in
   ``report()['lost']``); ``replace_dead()`` starts a new child in its slot - a world-of-one worker that loads the weights itself, as
-  the group of the start-up is gone by then.
+  the group of the start-up is gone by then.  ``auto_replace=True`` does that by itself, without blocking the stream: ``poll()`` starts
+  the replacement when it sees a dead worker and swaps it in once it reports ready (the reference's image server restarts its pipeline on a
+  dead worker, ``image_pipeline.py:66-73,295-301``; its deployment script loops ``while true``).
 """
 from __future__ import annotations
 
@@ -49,7 +51,7 @@ def _free_port() -> int:
 class UpscalerNode:
     def __init__(self, devices: Union[int, Sequence[int], None] = None, service_cls=HipUpscalerService, backend: Optional[str] = None,
                  fps: int = 24, frame_skips: bool = True, on_result=None, lost_after_s: float = 5.0, force_group: bool = False,
-                 output_shape="unset", host_frames=True, host_slots: int = 6, **service_kwargs):
+                 output_shape="unset", host_frames=True, host_slots: int = 6, auto_replace: bool = False, **service_kwargs):
         if devices is None:
             import torch
             devices = torch.cuda.device_count()   # (counting devices does not initialise the GPU in this process)
@@ -67,6 +69,9 @@ class UpscalerNode:
         self.services = [self._make_service(k, len(self.devices)) for k in range(len(self.devices))]
         self.dispatcher = StreamDispatcher(self.services, fps=fps, frame_skips=frame_skips, on_result=on_result, lost_after_s=lost_after_s)
         self.started = False
+        self.auto_replace = bool(auto_replace)
+        self._replacing = {}      # slot -> replacement service that has been started and is not ready yet
+        self.replaced_total = 0
 
     def _make_service(self, k: int, world: int):
         import torch.multiprocessing as mp
@@ -135,7 +140,31 @@ class UpscalerNode:
         return self.dispatcher.submit_batch(frames, audio_segment, profiler)
 
     def poll(self, timeout: float = 0.0):
+        if self.auto_replace and self.started:
+            self._auto_replace_step()
         return self.dispatcher.poll(timeout)
+
+    def _auto_replace_step(self) -> None:
+        """Non-blocking: start a replacement for every dead worker that has none yet; swap in the ones that have reported ready; start
+        another one for a replacement that died while loading."""
+        for k, svc in enumerate(self.services):
+            if k in self._replacing:
+                new = self._replacing[k]
+                if new.ready_event.is_set():
+                    self.dispatcher.rescue_orphans()     # (host steps still in the dead worker's ring, before it goes)
+                    old = self.services[k]
+                    self.services[k] = new
+                    self.dispatcher.services[k] = new
+                    self._close_rings(old)
+                    del self._replacing[k]
+                    self.replaced_total += 1
+                elif not new.proc.is_alive():
+                    self._close_rings(new)
+                    del self._replacing[k]                # (it died during start-up: the next poll starts another)
+            elif not svc.proc.is_alive():
+                new = self._make_service(k, 1)
+                new.start()
+                self._replacing[k] = new
 
     def drain(self, expected_steps, timeout: float = 60.0):
         return self.dispatcher.drain(expected_steps, timeout)
@@ -143,10 +172,18 @@ class UpscalerNode:
     def report(self) -> dict:
         r = self.dispatcher.report()
         r["alive"] = self.alive()
+        r["replaced"] = self.replaced_total
+        r["replacing"] = sorted(self._replacing)
         return r
 
     def stop(self) -> List[Optional[int]]:
         codes = []
+        for new in list(self._replacing.values()):   # (replacements that were still loading)
+            if new.proc.is_alive():
+                new.proc.kill()
+                new.proc.join(timeout=15)
+            self._close_rings(new)
+        self._replacing.clear()
         for svc in self.services:
             if svc.proc.is_alive():
                 try:

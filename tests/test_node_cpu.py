@@ -140,3 +140,31 @@ def test_single_worker_node_needs_no_group(tmp_path):
     with node:
         out = node.drain(node.submit_batch(torch.zeros(4, 2, 2, 3, dtype=torch.uint8)), timeout=120)
         assert [e.step for e in out] == [0] and int(out[0].frames[0, 0, 0, 1]) == _want_checksum()
+
+
+def test_auto_replace_swaps_a_fresh_worker_in_without_blocking_the_stream(tmp_path):
+    """``auto_replace=True``: poll() notices the dead worker, starts a replacement in the background and swaps it in when it is ready;
+    meanwhile the stream runs over the survivor."""
+    import signal
+    node = _node(tmp_path, 2, frame_skips=False, auto_replace=True)
+    node.start(timeout=300)
+    try:
+        os.kill(node.services[1].proc.pid, signal.SIGKILL)
+        node.services[1].proc.join(30)
+        frames = torch.arange(8).view(8, 1, 1, 1).expand(8, 4, 6, 3).to(torch.uint8).contiguous()
+        seen, deadline = [], time.monotonic() + 240
+        while node.report()["replaced"] < 1 and time.monotonic() < deadline:
+            steps = node.submit_batch(frames)             # two jobs per round: the stream does not wait for the replacement
+            t_end = time.monotonic() + 30
+            while len(seen) < steps[-1] + 1 and time.monotonic() < t_end:
+                seen += [e.step for e in node.poll(0.05)]
+        rep = node.report()
+        assert rep["replaced"] == 1 and rep["alive"] == [True, True] and rep["replacing"] == [] and rep["lost"] == 0, rep
+        assert seen == list(range(len(seen))) and len(seen) >= 2
+        steps = node.submit_batch(frames)                 # both workers serve again
+        out = node.drain(steps, timeout=120)
+        assert [e.step for e in out] == steps
+        assert {int(e.frames[0, 0, 0, 2]) for e in out} == {0, 1}      # (the double stamps its device: the replacement in slot 1 takes jobs again)
+    finally:
+        node.stop()
+        node.close()
