@@ -191,3 +191,27 @@ def test_service_soak_mixed_job_sizes_through_one_worker():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "service_soak.py"), "400"], cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "SERVICE SOAK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_node_kill_rescue_and_auto_replace_with_host_frames(want):
+    """Two real workers on cuda:0, host frames, ``auto_replace=True``: a worker is SIGKILLed with jobs inside it - those jobs are re-queued
+    from its input ring (none lost), the stream goes on over the survivor, and poll() swaps a fresh worker in without blocking."""
+    import os
+    import signal
+    frames, ref = want
+    node = UpscalerNode(devices=[0, 0], fps=24, frame_skips=False, auto_replace=True, **KW)
+    with node:
+        host = frames.numpy()
+        got = {}
+        steps = node.submit_batch(host) + node.submit_batch(host)          # six jobs, three per worker
+        os.kill(node.services[1].proc.pid, signal.SIGKILL)                 # exactly the child this node started
+        deadline = time.monotonic() + 300
+        while (not set(steps) <= set(got) or node.report()["replaced"] < 1) and time.monotonic() < deadline:
+            for e in node.poll(0.02):
+                got[e.step] = e.frames.clone()
+        rep = node.report()
+        assert sorted(got) == steps and rep["lost"] == 0 and rep["replaced"] == 1 and rep["alive"] == [True, True], rep
+        assert torch.equal(torch.cat([got[s] for s in steps]), torch.cat([ref, ref]))
+        out = node.drain(node.submit_batch(host), timeout=300)              # the replacement serves
+        assert torch.equal(torch.cat([e.frames for e in out]), ref)
+    node.close()
