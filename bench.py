@@ -323,7 +323,7 @@ def fsrcnn_stage_rooflines(svc, frames, psteps=3, half=False):
     return stages
 
 
-def host_frames_leg(local, in_shape, batch, resident_fps, flops_per_frame, n_jobs=40, in_flight=3):
+def host_frames_leg(local, in_shape, batch, resident_fps, flops_per_frame, n_jobs=40, in_flight=3, resident_svc=None):
     from sharkshark4k_amd.node import UpscalerNode
     kw, _, _ = SERVICE_OF["rrdbnet"]
     node = UpscalerNode(devices=[local], fps=24 if batch >= 4 else batch, frame_skips=False, weights="synthetic", seed=0, dtype="f16", lr_shape=in_shape, **kw)
@@ -344,13 +344,23 @@ def host_frames_leg(local, in_shape, batch, resident_fps, flops_per_frame, n_job
                     checksum += int(e.frames[0, 0, 0, 0])               # (the consumer touches the host result)
                     got += 1
         pump(10)
+        same = None
+        if resident_svc is not None:   # one job's host result against the resident path's frames for the same input (byte for byte)
+            got = None
+            node.submit_batch(host)
+            while got is None:
+                for e in node.poll(0.01):
+                    got = e.frames.clone()
+            want = resident_svc.upscale(torch.from_numpy(host).to(resident_svc.torch_device)).cpu()
+            same = bool(torch.equal(got, want))
         t1 = time.perf_counter(); pump(n_jobs); dt = time.perf_counter() - t1
         rep = node.report()
         fps = n_jobs * job / dt
         return {"workload": WORKLOADS["rrdbnet"] + f", HOST frames in and out through node.UpscalerNode (one spawned worker; pinned shared-memory rings, H2D / D2H on the "
                             f"worker's copy streams, {in_flight} jobs in flight): PCIe-inclusive, never the headline value",
                 "frames_per_step": job, "fps": fps, "of_resident_value": fps / resident_fps, "net_tflops": flops_per_frame * fps / 1e12,
-                "host_bytes_per_frame": in_shape[0] * in_shape[1] * 3 + 4 * in_shape[0] * in_shape[1] * 3, "report": {k: rep[k] for k in ("host_jobs", "host_fallback", "lost", "dropped")}}
+                "host_bytes_per_frame": in_shape[0] * in_shape[1] * 3 + 4 * in_shape[0] * in_shape[1] * 3, "identical_to_resident_path": same,
+                "report": {k: rep[k] for k in ("host_jobs", "host_fallback", "lost", "dropped", "rescued")}}
     finally:
         node.stop()
         node.close()
@@ -611,7 +621,7 @@ def main():
         # this GPU, numpy frames in host memory -> the worker's pinned input ring -> H2D on the worker's copy stream -> the job -> D2H into
         # the pinned output ring -> a host view at the sink; 4-frame jobs, three in flight.  PCIe-inclusive: never the headline `value`.
         try:
-            also["host_frames"] = host_frames_leg(local, in_shape, args.batch, fps, flops_per_frame)
+            also["host_frames"] = host_frames_leg(local, in_shape, args.batch, fps, flops_per_frame, resident_svc=svc)
         except Exception as e:  # never lose the headline line to a secondary measurement
             also["host_frames"] = {"error": f"{type(e).__name__}: {e}"}
         result["also"] = also
