@@ -550,7 +550,7 @@ def main():
                                           ("rrdbnet_n1_one_set", "rrdbnet", 1, (720, 1280), 60),   # (0.55 s: a 0.18 s burst after the service build measured 108-116 by how long the chip had idled)
                                           ("rrdbnet_x4", "rrdbnet_x4", 1, (1080, 1920), 5)):
             # rrdbnet_n1: back-to-back one-frame jobs from ONE service (the image server's caller): consecutive jobs alternate over the
-            # service's two job sets (hip_upscaler.py); rrdbnet_n1_one_set: the same with overlap_jobs=False (every job on one set / stream)
+            # service's three job sets (hip_upscaler.py); rrdbnet_n1_one_set: the same with overlap_jobs=False (every job on one set / stream)
             if name == "rrdbnet_n1":
                 svc2, fpf = svc, flops_per_frame
             else:
@@ -559,7 +559,7 @@ def main():
             # FSRCNN: a service build idles the chip for ~ 1 s and a 0.1 s burst right after it runs at the clock of the ramp, not the one the
             # job holds (in-bench 5 590 against 5 690 frames/s stand-alone with 20 warm-up steps): 100 untimed steps first
             dt = timed(svc2, fr2, reps, settle=100 if wl.startswith("fsrcnn") else 7)
-            also[name] = {"workload": WORKLOADS[wl] + (", back-to-back one-frame jobs from one service, alternating over its two job sets" if name == "rrdbnet_n1" else
+            also[name] = {"workload": WORKLOADS[wl] + (", back-to-back one-frame jobs from one service, alternating over its three job sets" if name == "rrdbnet_n1" else
                                                        ", one-frame jobs on one job set (overlap_jobs=False)" if name == "rrdbnet_n1_one_set" else ""),
                           "frames_per_step": nb, "fps": reps * nb / dt, "net_tflops": fpf * reps * nb / dt / 1e12}
             if name == "rrdbnet_n1":
@@ -594,7 +594,7 @@ def main():
                 del svc2
             torch.cuda.empty_cache()
         # ... and the same one-frame jobs through a REAL worker process of the service (spawned child, job / result queues, CUDA-IPC
-        # tensors, deliver_lag = 1): what an integrator's image server gets from one GPU
+        # tensors, results held until ready / at most two while jobs alternate): what an integrator's image server gets from one GPU
         try:
             from sharkshark4k_amd.upscale.upscaler_base import UpscalerQueueEntry
             kw, _, _ = SERVICE_OF["rrdbnet"]
