@@ -350,7 +350,7 @@ template <int S, bool SPLIT, bool OUT_HALF = false>
 __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ in12, float* __restrict__ out,
                                                    const float* __restrict__ we, const float* __restrict__ be,
                                                    const float* __restrict__ ae, const float* __restrict__ wd, float bias,
-                                                   int planes, int h, int w, int bands) {
+                                                   int planes, int h, int w, int bands, int tall_rpb) {
   constexpr int HALO = FsTailGeo<S>::HALO, CI = FsTailGeo<S>::CI, JSTEP = S / 2;
   extern __shared__ __attribute__((aligned(16))) float fs_lds[];
   // A operands, fragment order: [tap block 3][k-step 4][lane 64] x 8 fp16, hi then lo tables; expand [2][64] x 8
@@ -361,9 +361,25 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
   float* bea = reinterpret_cast<float*>(we_lo + 128);  // [64] bias, [64] PReLU slope of the (padded) expand channels
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, hh = lane >> 5;
   const int wstrips = (w + CI - 1) / CI, strips = (wstrips + 3) / 4;
-  const int strip = blockIdx.x % strips, band = (blockIdx.x / strips) % bands, plane = blockIdx.x / (strips * bands);
-  const int rpb = (h + bands - 1) / bands, ylo = band * rpb, yhi = min(h, ylo + rpb);
-  if (plane >= planes || ylo >= yhi) return;
+  // Bands.  Classic (tall_rpb == 0): a workgroup is four neighbouring wave strips of one of `bands` equal bands of one plane.  Tall (round 6):
+  // the unit is the WAVE (waves share nothing but the weight tables) and the planes are stacked into one image of planes * h rows cut into
+  // bands of tall_rpb rows, so that the wave count can be what fills the chip's slots: 720p x2, 12 planes, are 46 wave strips - classic
+  // 12 workgroup strips (two idle waves each) x 5 bands x 12 planes = 720 workgroups of 768 slots and 148 row steps each, tall 66 bands of
+  // 131 rows.  A band that straddles a plane boundary is marched as two segments (4 more halo rows).
+  int ws, plane, ylo, yhi, tall0 = 0, tall1 = 0;
+  if (tall_rpb > 0) {
+    const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);
+    ws = wid % wstrips;
+    tall0 = (wid / wstrips) * tall_rpb; tall1 = min(planes * h, tall0 + tall_rpb);
+    plane = tall0 / h; ylo = tall0 - plane * h; yhi = min(h, ylo + (tall1 - tall0));
+  } else {
+    const int strip = blockIdx.x % strips, band = (blockIdx.x / strips) % bands;
+    plane = blockIdx.x / (strips * bands);
+    const int rpb = (h + bands - 1) / bands;
+    ylo = band * rpb; yhi = min(h, ylo + rpb);
+    if (plane >= planes || ylo >= yhi) return;
+    ws = strip * 4 + wave;
+  }
 
   // Tap slot r of block tb sits in half hs = (r>>2)&1 of the accumulator; half 0 carries the 45 taps with even ky,
   // half 1 the 36 with odd ky, each in (ky, kx) order (as k_fs_tail).  k = 8*kq + j of k-step s is channel
@@ -404,8 +420,8 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
   }
   if (tid < 64) { bea[tid] = tid < 56 ? be[tid] : 0.f; bea[64 + tid] = tid < 56 ? ae[tid] : 1.f; }
   __syncthreads();
-  const int ws = strip * 4 + wave;   // this wave's strip of CI interior columns; nothing below synchronises
-  if (ws >= wstrips) return;
+  // ws: this wave's strip of CI interior columns; nothing below synchronises
+  if (ws >= wstrips || (tall_rpb > 0 && tall0 >= tall1)) return;
 
   // fp16 mode: PReLU slopes of the expand channels this lane's accumulators hold, packed in pairs (registers instead of LDS reads)
   uint32_t slp[2][8];
@@ -420,7 +436,6 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
   }
   const size_t plane_px = (size_t)h * w, total = (size_t)planes * plane_px;
   const int OW = S * w, OH = S * h;
-  float* oplane = out + (size_t)plane * OH * OW;
   const int px = ws * CI - HALO + p;
   const bool col_ok = px >= 0 && px < w;
   const bool interior = p >= HALO && p < 32 - HALO && px < w;
@@ -447,14 +462,16 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
     }
   };
   typedef float fvS __attribute__((ext_vector_type(S)));
+  constexpr float LO = 1.f / 2048.f;
+  const f32x16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+ for (;;) {   // one segment = rows [ylo, yhi) of `plane` (classic bands: exactly one)
+  float* oplane = out + (size_t)plane * OH * OW;
   fvS V[5];   // output rows S*y - 4 + 2j + hh under construction, this lane's S columns of each
 #pragma unroll
   for (int j = 0; j < 5; ++j) V[j] = fvS(0.f);
   float4 n0[PF], n1[PF];
 #pragma unroll
   for (int u = 0; u < PF; ++u) load_x(ylo - 2 + u, n0[u], n1[u]);
-  constexpr float LO = 1.f / 2048.f;
-  const f32x16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int yb = ylo - 2; yb < yhi + 2; yb += PF) {
 #pragma unroll
    for (int u = 0; u < PF; ++u) {
@@ -596,6 +613,11 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
     }
    }
   }
+  if (tall_rpb <= 0) break;
+  tall0 += yhi - ylo;
+  if (tall0 >= tall1) break;
+  plane = tall0 / h; ylo = 0; yhi = min(h, tall1 - tall0);   // the rest of the band: the first rows of the next plane
+ }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1071,7 +1093,7 @@ __device__ __forceinline__ int mh_chunk(int q) {
 
 template <bool STAMP, int NU>
 __global__ __launch_bounds__(256, 4 / NU) void k_fs_maps4_h(const uint2* __restrict__ in, uint2* __restrict__ out, const FsMapW W,
-                                                            int planes, int h, int w, int bands, unsigned long long* dbg) {
+                                                            int planes, int h, int w, int bands, unsigned long long* dbg, int tall_rpb = 0) {
   constexpr int MH_COLS = MhGeo<NU>::COLS, MH_CI = MhGeo<NU>::CI, MH_ROWB = MhGeo<NU>::ROWB, MH_STAGEB = MhGeo<NU>::STAGEB, MH_LDS = MhGeo<NU>::LDS;
   extern __shared__ __attribute__((aligned(16))) char mh_ring[];
   // dev build, STAMP: cycles of this wave per phase (s_memtime): [0] loader, [1] operand reads + MFMAs, [2] epilogue + stores, [3] barrier
@@ -1090,11 +1112,25 @@ __global__ __launch_bounds__(256, 4 / NU) void k_fs_maps4_h(const uint2* __restr
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
   const int st = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's layer
   const int strips = (w + MH_CI - 1) / MH_CI;
-  const int strip = blockIdx.x % strips, band = (blockIdx.x / strips) % bands, plane = blockIdx.x / (strips * bands);
-  const int rpb = (h + bands - 1) / bands, ylo = band * rpb, yhi = min(h, ylo + rpb);
-  if (plane >= planes || ylo >= yhi) return;
+  const int strip = blockIdx.x % strips;
+  // Bands.  Classic (tall_rpb == 0): `bands` equal bands per plane.  Tall (round 6): the planes stacked into one image of planes * h rows
+  // cut into bands of tall_rpb rows - so that the workgroup count can be what fills the chip's slots (12 planes x 23 strips x 3 bands are
+  // 828 workgroups for 1024 slots; 44 tall bands x 23 are 1012) - and a band that straddles a plane boundary is marched as two segments
+  // (the four-layer pipeline drains and refills at the boundary: 14 more steps for that workgroup).
+  int tall0 = 0, tall1 = 0, plane, ylo, yhi;
+  if (tall_rpb > 0) {
+    const int band = blockIdx.x / strips;
+    tall0 = band * tall_rpb; tall1 = min(planes * h, tall0 + tall_rpb);
+    if (tall0 >= tall1) return;
+    plane = tall0 / h; ylo = tall0 - plane * h; yhi = min(h, ylo + (tall1 - tall0));
+  } else {
+    const int band = (blockIdx.x / strips) % bands;
+    plane = blockIdx.x / (strips * bands);
+    const int rpb = (h + bands - 1) / bands;
+    ylo = band * rpb; yhi = min(h, ylo + rpb);
+    if (plane >= planes || ylo >= yhi) return;
+  }
   const int x0 = strip * MH_CI;
-  for (int e = tid; e < MH_LDS / 16; e += 256) reinterpret_cast<uint4*>(mh_ring)[e] = make_uint4(0u, 0u, 0u, 0u);
 
   // weights of this wave's layer: row m = (co & 3) + 8 * (co >> 2) + 4 * g (the accumulator register order, so lane half g holds
   // pixel g's slots 0..15 in registers 0..15); K-step (dy, c): window column c, slot 8 * hh + j
@@ -1135,6 +1171,11 @@ __global__ __launch_bounds__(256, 4 / NU) void k_fs_maps4_h(const uint2* __restr
   const size_t plane_px = (size_t)h * w, total = (size_t)planes * plane_px;
   const uint2* src = in + (size_t)plane * plane_px;
   uint2* dst = out + (size_t)plane * plane_px;
+  unsigned long long pre = 0;
+  int steps_done = 0;
+ for (int seg = 0;; ++seg) {   // one segment = rows [ylo, yhi) of `plane` (classic bands: exactly one)
+  if (seg) { src = in + (size_t)plane * plane_px; dst = out + (size_t)plane * plane_px; __syncthreads(); }   // (every wave is done with the rings)
+  for (int e = tid; e < MH_LDS / 16; e += 256) reinterpret_cast<uint4*>(mh_ring)[e] = make_uint4(0u, 0u, 0u, 0u);
   // input loader: thread tid < 192 moves channel group lg = tid / 64 (8 bytes) of ring column lc = tid % 64; threads 192..255 write
   // the constant-1 slots of the row
   const int lg = tid >> 6, lc = tid & 63, lx = x0 - MH_HALO + lc;
@@ -1166,8 +1207,8 @@ __global__ __launch_bounds__(256, 4 / NU) void k_fs_maps4_h(const uint2* __restr
   const f32x16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int nsteps = (yhi - ylo) + 4 + 6;   // layer 3 reaches relative row (yhi - ylo) + 3 at step that + 6
   const int rlast = (yhi - ylo) + 3 + (3 - st);
-  unsigned long long pre = 0;
-  if constexpr (STAMP) pre = __builtin_amdgcn_s_memtime() - ct0;
+  if constexpr (STAMP) { if (!seg) pre = __builtin_amdgcn_s_memtime() - ct0; }
+  steps_done += nsteps;
   for (int t0 = 0; t0 < nsteps; t0 += 4) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1241,11 +1282,16 @@ __global__ __launch_bounds__(256, 4 / NU) void k_fs_maps4_h(const uint2* __restr
       stamp(3);
     }
   }
+  if (tall_rpb <= 0) break;
+  tall0 += yhi - ylo;
+  if (tall0 >= tall1) break;
+  plane = tall0 / h; ylo = 0; yhi = min(h, tall1 - tall0);   // the rest of the band: the first rows of the next plane
+ }
   if constexpr (STAMP) {
     if (lane == 0 && dbg && blockIdx.x < 1024) {
       unsigned long long* o = dbg + ((size_t)blockIdx.x * 4 + st) * 8;
       for (int k = 0; k < 4; ++k) o[k] = ph[k];
-      o[5] = (unsigned long long)nsteps; o[4] = pre; o[6] = __builtin_amdgcn_s_memtime() - ct0;
+      o[5] = (unsigned long long)steps_done; o[4] = pre; o[6] = __builtin_amdgcn_s_memtime() - ct0;
       o[7] = ((__builtin_amdgcn_s_memtime() - ct0) << 20) / (__builtin_amdgcn_s_memrealtime() - rt0 + 1);
     }
   }
@@ -1333,7 +1379,7 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
         const void* fs = reinterpret_cast<const void*>(kst);
         if (ctx->lds_attr_set.insert(fs).second) SS4K_HIP(hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, MH_LDS));
         hipLaunchKernelGGL(kst, dim3((unsigned)(planes * hb * hs)), block, MH_LDS, st, reinterpret_cast<const uint2*>(cur),
-                           reinterpret_cast<uint2*>(nxt), mw, planes, h, w, hb, dbuf);
+                           reinterpret_cast<uint2*>(nxt), mw, planes, h, w, hb, dbuf, 0);
         SS4K_HIP(hipStreamSynchronize(st));
         std::vector<unsigned long long> hbuf(1024 * 4 * 8);
         SS4K_HIP(hipMemcpy(hbuf.data(), dbuf, hbuf.size() * 8, hipMemcpyDeviceToHost));
@@ -1354,8 +1400,19 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
         auto kfn = NUr == 2 ? &k_fs_maps4_h<false, 2> : &k_fs_maps4_h<false, 1>;
         const void* fn = reinterpret_cast<const void*>(kfn);
         if (ctx->lds_attr_set.insert(fn).second) SS4K_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MH_LDS));
-        hipLaunchKernelGGL(kfn, dim3((unsigned)(planes * hb * hs)), block, MH_LDS, st, reinterpret_cast<const uint2*>(cur),
-                           reinterpret_cast<uint2*>(nxt), mw, planes, h, w, hb, nullptr);
+        // tall bands: as many bands over the stacked planes as fill the chip's workgroup slots once (bands of at least 32 rows)
+        int tall_rpb = 0;
+        unsigned nwg = (unsigned)(planes * hb * hs);
+        static const bool tall_off = std::getenv("SS4K_MH_NO_TALL") != nullptr;
+        if (NUr == 1 && !tall_off) {
+          const long rows = (long)planes * h;
+          const int slots = (4 / NUr) * ctx->num_cu;
+          const int nb = (int)std::max(1L, std::min(rows / 32, (long)(slots / std::max(1, hs))));
+          tall_rpb = (int)((rows + nb - 1) / nb);
+          nwg = (unsigned)(((rows + tall_rpb - 1) / tall_rpb) * hs);
+        }
+        hipLaunchKernelGGL(kfn, dim3(nwg), block, MH_LDS, st, reinterpret_cast<const uint2*>(cur),
+                           reinterpret_cast<uint2*>(nxt), mw, planes, h, w, hb, nullptr, tall_rpb);
       }
     } else {
       const void* fn = reinterpret_cast<const void*>(&k_fs_maps4);
@@ -1372,17 +1429,33 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
   // one round of workgroups at three per CU; every band re-does 4 halo rows (fp16 mode: 4, 5 or 6 per CU measured, no gain)
   const int bands = std::max(1, std::min((h + 15) / 16, 3 * ctx->num_cu / std::max(1, planes * strips)));
   const dim3 tgrid((unsigned)(planes * bands * strips));
-  auto launch_tail = [&](auto kern, int S) {
-    const size_t lds = exact ? (size_t)(6144 + 768 + 128 + 16 * (S * 128 + 8)) * 4 : (size_t)(2 * 768 + 2 * 128) * 16 + 128 * 4;
+  auto launch_tail = [&](auto kern, int S) {   // the exact-fp32 tail
+    const size_t lds = (size_t)(6144 + 768 + 128 + 16 * (S * 128 + 8)) * 4;
     hipLaunchKernelGGL(kern, tgrid, block, lds, st, cur, out, W.w_expand, W.b_expand, W.a_expand, W.w_deconv, W.b_deconv,
                        planes, h, w, bands);
   };
+  auto launch_tail_r = [&](auto kern, int S) {   // the matrix-core tails: tall bands of independent waves (see the kernel)
+    const size_t lds = (size_t)(2 * 768 + 2 * 128) * 16 + 128 * 4;
+    static const bool tall_off = std::getenv("SS4K_TAIL_NO_TALL") != nullptr;
+    int tall_rpb = 0;
+    dim3 grid = tgrid;
+    if (!tall_off) {
+      const int wstrips = (w + ci / 4 - 1) / (ci / 4);
+      const long rows = (long)planes * h;
+      const int nb = (int)std::max(1L, std::min(rows / 16, (long)(4 * 3 * ctx->num_cu / wstrips)));
+      tall_rpb = (int)((rows + nb - 1) / nb);
+      const long waves = ((rows + tall_rpb - 1) / tall_rpb) * wstrips;
+      grid = dim3((unsigned)((waves + 3) / 4));
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, st, cur, out, W.w_expand, W.b_expand, W.a_expand, W.w_deconv, W.b_deconv,
+                       planes, h, w, bands, tall_rpb);
+  };
   if (factor == 2) {
-    if (exact) launch_tail(k_fs_tail<2>, 2); else if (half && out_half) launch_tail(k_fs_tail_r<2, false, true>, 2);
-    else if (half) launch_tail(k_fs_tail_r<2, false>, 2); else launch_tail(k_fs_tail_r<2, true>, 2);
+    if (exact) launch_tail(k_fs_tail<2>, 2); else if (half && out_half) launch_tail_r(k_fs_tail_r<2, false, true>, 2);
+    else if (half) launch_tail_r(k_fs_tail_r<2, false>, 2); else launch_tail_r(k_fs_tail_r<2, true>, 2);
   } else {
-    if (exact) launch_tail(k_fs_tail<4>, 4); else if (half && out_half) launch_tail(k_fs_tail_r<4, false, true>, 4);
-    else if (half) launch_tail(k_fs_tail_r<4, false>, 4); else launch_tail(k_fs_tail_r<4, true>, 4);
+    if (exact) launch_tail(k_fs_tail<4>, 4); else if (half && out_half) launch_tail_r(k_fs_tail_r<4, false, true>, 4);
+    else if (half) launch_tail_r(k_fs_tail_r<4, false>, 4); else launch_tail_r(k_fs_tail_r<4, true>, 4);
   }
   prof_tail.done(10416.0 * (double)total);
   SS4K_HIP(hipGetLastError());
