@@ -665,6 +665,23 @@ def test_fsrcnn_f16_mode_vs_oracle(ctx, factor, tag, shape):
     assert p > 67.0 and err < 1e-2 * max(1.0, peak)
 
 
+def test_fsrcnn_tall_bands_same_bytes_as_whole_bands_per_plane():
+    """Round 6's grids (fp16 mapping stage, both matrix-core tails: the planes stacked into one tall image, cut into as many bands as fill
+    the chip's workgroup slots, a band straddling plane boundaries marched in segments) against the classic ones (SS4K_MH_NO_TALL,
+    SS4K_TAIL_NO_TALL: whole bands per plane), each in a child process: SHA-256 of every output tensor, shapes with one band over seven
+    planes up to configs[1]'s 12 x 720 x 1280, both modes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for switches in ({}, {"SS4K_MH_NO_TALL": "1", "SS4K_TAIL_NO_TALL": "1"}):
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "drive_fs_bands.py")], cwd=root, capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, **switches))
+        assert r.returncode == 0 and "FS BANDS DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("x")])
+    assert len(outs[0]) == 16 and outs[0] == outs[1], [(a, b) for a, b in zip(*outs) if a != b]
+
+
 # ------------------------------------------------------------------------------ fp16 HR tensor on the batched service path
 @pytest.mark.parametrize("out_shape,lr_shape,n", [((144, 256), (72, 128), 2), (None, (72, 128), 1), ((180, 250), (90, 125), 3)])
 def test_srvgg_f16_half_hr_tensor_vs_fp32_hr_tensor(ctx, out_shape, lr_shape, n):
