@@ -45,7 +45,8 @@ static std::vector<float> sharpen_taps(double strength) {  // sharpen_ker, fsrcn
 struct Upscaler {
   ss4k_ctx* ctx; ss4k_upscale_cfg cfg; Model* sr; Model* dn;
   DevBuf k_gauss17, k_sharp, k_sharp_hr;
-  DevBuf img, lr, lr4, den, hr, hr2, lb, hb, lbb, hbb, st_hr, st_lr, st_acc;
+  DevBuf img, lr, lr4, den, hr, hr2, lb, hb, lbb, hbb, st_hr, st_lr, st_acc, st_acc2;
+  bool acc2_clean = false;   // st_acc2 holds zeros (its last user re-zeroed what it had summed: k_stats_final2)
   bool first_frame = true;
   bool taps_on = false;
   // host time spent enqueueing the last job's denoise / SR model stages: what the reference's
@@ -188,12 +189,21 @@ struct Upscaler {
       hr.ensure((size_t)P * H * W * 4 * 2);
       st_hr.ensure(P * 8); st_lr.ensure(P * 8);
       SS4K_REQUIRE(P <= STATS_MAX_PLANES, "too many frames in one job");
-      // one set of accumulators for both tensors' statistics - the frames' [0, P) and the network output's [P, 2 P) - zeroed by ONE memset
-      // and finished by ONE launch (two memsets and two finishing launches less than two op_plane_stats calls: ~ 10 us of a 0.7 ms job)
+      // one set of accumulators for both tensors' statistics - the frames' [0, P) and the network output's [P, 2 P) - finished by ONE launch
+      // that also zeroes what it has read: the accumulators (their own buffer, sized once for the largest job) are memset only when they
+      // are new or when a job died between its first partial sum and its finishing launch (three launches of ~ 5 us less than two
+      // op_plane_stats calls, in a 0.65 ms job)
       SS4K_REQUIRE(2 * P <= STATS_MAX_PLANES, "too many frames in one job");
-      st_acc.ensure(sizeof(double) * 2 * 2 * P * STATS_SLOTS);
-      SS4K_HIP(hipMemsetAsync(st_acc.as<double>(), 0, sizeof(double) * 2 * 2 * P * STATS_SLOTS, st));
-      op_plane_stats_u8nhwc_partial(st_acc.as<double>(), in, n, lh * lw, 2 * P, 0, st);
+      const size_t acc2_bytes = sizeof(double) * 2 * STATS_MAX_PLANES * STATS_SLOTS;
+      if (st_acc2.bytes < acc2_bytes) { st_acc2.ensure(acc2_bytes); acc2_clean = false; }
+      // (a job that is being CAPTURED into a graph by the caller runs later, any number of times, in whatever state an eager job in
+      // between has left: it always carries the memset, and nothing it records changes what the buffer holds now)
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing(st, &cap);
+      const bool capturing = cap != hipStreamCaptureStatusNone, was_clean = acc2_clean;
+      if (!acc2_clean || capturing) SS4K_HIP(hipMemsetAsync(st_acc2.as<double>(), 0, acc2_bytes, st));
+      acc2_clean = false;
+      op_plane_stats_u8nhwc_partial(st_acc2.as<double>(), in, n, lh * lw, 2 * P, 0, st);
       enq_denoise_ms = 0;
       const double tm0 = now_ms();
       sr->out_half = hr16; sr->in_u8 = true;
@@ -201,8 +211,9 @@ struct Upscaler {
       enq_model_ms = now_ms() - tm0;
       const bool rs_ = cfg.out_h > 0 && !(cfg.out_h == H && cfg.out_w == W);
       auto finish = [&](auto* hrt) {
-        op_plane_stats_partial(st_acc.as<double>(), hrt, P, H * W, 2 * P, P, st);
-        op_plane_stats_finish2(st_acc.as<double>(), st_lr.as<float>(), st_hr.as<float>(), P, lh * lw, H * W, st);
+        op_plane_stats_partial(st_acc2.as<double>(), hrt, P, H * W, 2 * P, P, st);
+        op_plane_stats_finish2(st_acc2.as<double>(), st_lr.as<float>(), st_hr.as<float>(), P, lh * lw, H * W, true, st);
+        acc2_clean = capturing ? was_clean : true;
         if (!rs_) op_tail_fused(hrt, out, static_cast<const float*>(nullptr), n, 3, H, W, 1, 1, st_hr.as<float>(), st_lr.as<float>(), st);
         else {
           op_tail_fused(hrt, static_cast<uint8_t*>(nullptr), static_cast<const float*>(nullptr), n, 3, H, W, 1, 1, st_hr.as<float>(), st_lr.as<float>(), st);
@@ -410,7 +421,7 @@ void ss4k_upscaler_destroy(ss4k_upscaler* up) {
   if (!up) return;
   Upscaler& u = up->u;
   for (DevBuf* b : {&u.k_gauss17, &u.k_sharp, &u.k_sharp_hr, &u.img, &u.lr, &u.lr4, &u.den, &u.hr, &u.hr2, &u.lb, &u.hb,
-                    &u.lbb, &u.hbb, &u.st_hr, &u.st_lr, &u.st_acc})
+                    &u.lbb, &u.hbb, &u.st_hr, &u.st_lr, &u.st_acc, &u.st_acc2})
     b->release();
   for (auto& t : u.tap) t.release();
   delete up;

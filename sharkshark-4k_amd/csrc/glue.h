@@ -23,7 +23,7 @@ void op_plane_stats_u8nhwc(double* acc, const uint8_t* in, float* stats, int n, 
 void op_plane_stats_u8nhwc_partial(double* acc, const uint8_t* in, int n, int hw, int acc_planes, int plane0, hipStream_t st);
 template <typename HT>
 void op_plane_stats_partial(double* acc, const HT* in, int planes, int hw, int acc_planes, int plane0, hipStream_t st);
-void op_plane_stats_finish2(const double* acc, float* stats_a, float* stats_b, int planes, int hw_a, int hw_b, hipStream_t st);
+void op_plane_stats_finish2(double* acc, float* stats_a, float* stats_b, int planes, int hw_a, int hw_b, bool rezero, hipStream_t st);
 // HT: element type of the network's HR output tensor (float, or __half where the network's tail can write it)
 template <typename HT>
 void op_area_normalized(const HT* in, float* out, int planes, int h, int w, int oh, int ow, const float* st_hr, const float* st_lr,

@@ -145,9 +145,23 @@ __global__ void k_stats_partial(const HT* __restrict__ in, double* __restrict__ 
   const HT* src = in + (size_t)pl * hw;
   double s = 0.0, q = 0.0;
   if ((hw & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-    // 16-byte loads, four independent fp64 chains (the sums are order-free: the partials meet in atomics anyway)
+    // four values per load, four independent fp64 chains (the sums are order-free: the partials meet in atomics anyway), FOUR loads in
+    // flight per thread: with one (rounds 1-5) the pass ran at 4 TB/s - 84 % of its wave cycles waiting (profiles/r06_fsrcnn_f16_sq_counters.json)
     double s4[4] = {0, 0, 0, 0}, q4[4] = {0, 0, 0, 0};
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)hw / 4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n4 = (size_t)hw / 4, stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = hr_ld4<HT>(src + 4 * (i + u * stride));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double d[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s4[k] += d[k]; q4[k] += d[k] * d[k]; }
+      }
+    }
+    for (; i < n4; i += stride) {
       const float4 v = hr_ld4<HT>(src + 4 * i);
       const double d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -262,11 +276,17 @@ void op_plane_stats_partial(double* acc, const HT* in, int planes, int hw, int a
 template void op_plane_stats_partial<float>(double*, const float*, int, int, int, int, hipStream_t);
 template void op_plane_stats_partial<__half>(double*, const __half*, int, int, int, int, hipStream_t);
 // mean / std of 2 x planes plane records: the first `planes` of hw_a values each -> stats_a, the others of hw_b values -> stats_b
-__global__ void k_stats_final2(const double* __restrict__ acc, float* __restrict__ sa, float* __restrict__ sb, int planes, int hw_a, int hw_b) {
+// `rezero`: the partial sums are zeroed as they are read, so that the NEXT job finds clean accumulators without a memset launch
+__global__ void k_stats_final2(double* __restrict__ acc, float* __restrict__ sa, float* __restrict__ sb, int planes, int hw_a, int hw_b, int rezero) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= 2 * planes) return;
   double S = 0, Q = 0;
-  for (int s = 0; s < STATS_SLOTS; ++s) { S += acc[((size_t)s * 2 * planes + p) * 2]; Q += acc[((size_t)s * 2 * planes + p) * 2 + 1]; }
+  for (int s = 0; s < STATS_SLOTS; ++s) {
+    double2* a = reinterpret_cast<double2*>(acc + ((size_t)s * 2 * planes + p) * 2);
+    const double2 v = *a;
+    S += v.x; Q += v.y;
+    if (rezero) *a = make_double2(0.0, 0.0);
+  }
   const double n = (double)(p < planes ? hw_a : hw_b);
   const double mean = S / n;
   double var = (Q - S * S / n) / (n - 1.0);   // (k_stats_final's expressions)
@@ -275,8 +295,8 @@ __global__ void k_stats_final2(const double* __restrict__ acc, float* __restrict
   o[0] = (float)mean;
   o[1] = (float)sqrt(var);
 }
-void op_plane_stats_finish2(const double* acc, float* stats_a, float* stats_b, int planes, int hw_a, int hw_b, hipStream_t st) {
-  hipLaunchKernelGGL(k_stats_final2, dim3((2 * planes + 63) / 64), dim3(64), 0, st, acc, stats_a, stats_b, planes, hw_a, hw_b); SS4K_LAUNCH_OK();
+void op_plane_stats_finish2(double* acc, float* stats_a, float* stats_b, int planes, int hw_a, int hw_b, bool rezero, hipStream_t st) {
+  hipLaunchKernelGGL(k_stats_final2, dim3((2 * planes + 63) / 64), dim3(64), 0, st, acc, stats_a, stats_b, planes, hw_a, hw_b, rezero ? 1 : 0); SS4K_LAUNCH_OK();
 }
 template void op_plane_stats<float>(double*, const float*, float*, int, int, hipStream_t);
 template void op_plane_stats<__half>(double*, const __half*, float*, int, int, hipStream_t);

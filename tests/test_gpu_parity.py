@@ -665,6 +665,48 @@ def test_fsrcnn_f16_mode_vs_oracle(ctx, factor, tag, shape):
     assert p > 67.0 and err < 1e-2 * max(1.0, peak)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_fsrcnn_service_accumulators_clean_themselves_across_jobs(ctx, dtype):
+    """The uint8-direct FSRCNN job (no area resize, no denoiser) keeps ONE set of fp64 accumulators for both statistics, and its finishing
+    launch zeroes what it has read instead of the next job paying a memset (api.cpp: st_acc2).  Jobs of 4, 1, 3, 2, 4 frames through one
+    upscaler - different plane counts, hence different accumulator layouts over the same buffer - against a NEW upscaler per job: every
+    byte.  Then the same job CAPTURED into a graph on a side stream (a captured job always carries the memset: it runs later, in whatever
+    state eager jobs in between leave) and replayed around eager jobs."""
+    sr = factory.build_model_fsrcnn(ctx, factor=2, weights=W.fsrcnn_table(seed=5), dtype=dtype)
+    lr_shape = (46, 84)
+    frames = torch.from_numpy(smooth_u8(91, (4, lr_shape[0], lr_shape[1], 3))).cuda()
+    one = _capi.Upscaler(ctx, sr, lr_shape, None, True, True, None, 1.0)
+
+    def fresh_result(x):
+        fresh = _capi.Upscaler(ctx, sr, lr_shape, None, True, True, None, 1.0)
+        want = fresh(x).cpu()
+        fresh.close()
+        return want
+
+    for i, n in enumerate([4, 1, 3, 2, 4, 1]):
+        x = frames[:n].roll(i, dims=1).contiguous()
+        got = one(x).cpu()
+        want = fresh_result(x)
+        assert torch.equal(got, want), f"job {i} of {n} frames differs from a new upscaler's: {int((got != want).sum())} bytes"
+    # captured: static input / output tensors, replayed with new contents, eager jobs of other sizes in between
+    x_static = frames[:2].clone()
+    out_static = torch.empty_like(one(x_static))
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        one(x_static, out_static)
+    for i in range(3):
+        x = frames[i:i + 2].roll(3 * i + 1, dims=2).contiguous()
+        x_static.copy_(x)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out_static.cpu(), fresh_result(x)), f"replay {i} differs"
+        y = frames[:3 - i].contiguous()
+        assert torch.equal(one(y).cpu(), fresh_result(y)), f"eager job after replay {i} differs"
+    del g
+    one.close()
+
+
 def test_fsrcnn_tall_bands_same_bytes_as_whole_bands_per_plane():
     """Round 6's grids (fp16 mapping stage, both matrix-core tails: the planes stacked into one tall image, cut into as many bands as fill
     the chip's workgroup slots, a band straddling plane boundaries marched in segments) against the classic ones (SS4K_MH_NO_TALL,
