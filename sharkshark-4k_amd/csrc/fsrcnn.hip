@@ -1065,31 +1065,25 @@ __global__ __launch_bounds__(256, 3) void k_fs_maps4(const float* __restrict__ i
 
 // ---------------------------------------------------------------------------------------------
 // fp16-mode mapping stage: the same four-layer row march (wave s is layer s, four-row rings in LDS, one barrier per row),
-// re-shaped so that a row costs a wave ~12 MFMAs and ~60 other instructions instead of 15 + 270:
-//   * records are 16 fp16 slots = 32 bytes per pixel (12 channels, slot 12 = the constant 1 that carries the bias, 3 spare);
+// re-shaped so that a row costs a wave 9 MFMAs and ~60 other instructions instead of 15 + 270:
+//   * records are the pixel's 12 fp16 channels = 24 bytes, packed (round 6; rounds 3-5: 16 slots = 32 bytes with a constant-1 slot that
+//     carried the bias and 3 spare - a quarter of every K-step was padding);
 //   * v_mfma_f32_32x32x16_f16 with the 32 rows = (pixel parity g, 16 cout slots) and the 32 columns = pixel PAIRS: K = a window of
-//     four columns (x - 1 .. x + 2 of the even pixel x) x 16 slots per kernel row, 12 K-steps per row of 64 pixels; the weight
-//     operand holds tap dx = c - g at window column c (a two-pixel Toeplitz block), so lane (n, hh) ends up with all 16 slots
-//     of pixel 2n + hh: its record for the next layer, written with two 16-byte stores;
+//     four columns (x - 1 .. x + 2 of the even pixel x) x 12 channels = 48 = THREE K-steps per kernel row, 9 per row of 64 pixels
+//     (12 with the padded records); K-step s of lane half hh is the 16 bytes at 32 s + 16 hh of the window's 96 contiguous bytes - a
+//     window starts at record 2n = byte 48 n of the ring row, so every read is a 16-byte-aligned ds_read_b128, and at a lane stride of
+//     48 bytes the 16 lanes of a b128 group cover all 64 banks (no swizzle).  The weight operand holds tap dx = c - g at window
+//     column c (a two-pixel Toeplitz block), the bias is the first MFMA's C operand, and lane (n, hh) ends up with the 12 channels of
+//     pixel 2n + hh: its record for the next layer, written with three 8-byte stores;
 //   * layer s keeps input row R in ring slot (R + 2s) & 3, so at step t EVERY layer reads slots (t-1, t, t+1) & 3 and writes
 //     slot (t+2) & 3 of the next ring: with the step loop unrolled by four all LDS offsets are immediates;
 //   * PReLU on packed fp16.
-// 16-byte chunk q of a ring row sits at a chunk with its low two bits XOR-ed by higher bits of q (mh_chunk): a wave's 16-byte reads at a
-// 64-byte lane stride spread over all banks.
 // NU units of 64 columns per workgroup strip (a wave computes NU x 32 pixel pairs per row: NU independent accumulators, reads and
 // epilogues between two barriers; 8 halo columns per 64 NU instead of per 64)
-constexpr int MH_HALO = 4;
+constexpr int MH_HALO = 4, MH_RECB = 24, MH_UNITB = 64 * MH_RECB;
 template <int NU> struct MhGeo {
-  static constexpr int COLS = 64 * NU, CI = COLS - 2 * MH_HALO, REC = COLS + 2, ROWB = REC * 32, STAGEB = 4 * ROWB, LDS = 4 * STAGEB;
+  static constexpr int COLS = 64 * NU, CI = COLS - 2 * MH_HALO, REC = COLS + 2, ROWB = REC * MH_RECB, STAGEB = 4 * ROWB, LDS = 4 * STAGEB;
 };
-__device__ __forceinline__ int mh_chunk(int q) {
-#ifdef SS4K_MH_SWZ_OLD
-  return (q ^ ((q >> 4) & 3)) * 16;
-#else
-  // reads stay conflict-free (the four 16-lane groups of ds_read_b128), the 16-byte record writes drop from 2-way to 1.5-way
-  return (q ^ (((q >> 4) & 1) | ((((q >> 3) ^ (q >> 5)) & 1) << 1))) * 16;
-#endif
-}
 
 template <bool STAMP, int NU>
 __global__ __launch_bounds__(256, 4 / NU) void k_fs_maps4_h(const uint2* __restrict__ in, uint2* __restrict__ out, const FsMapW W,
@@ -1133,39 +1127,36 @@ __global__ __launch_bounds__(256, 4 / NU) void k_fs_maps4_h(const uint2* __restr
   const int x0 = strip * MH_CI;
 
   // weights of this wave's layer: row m = (co & 3) + 8 * (co >> 2) + 4 * g (the accumulator register order, so lane half g holds
-  // pixel g's slots 0..15 in registers 0..15); K-step (dy, c): window column c, slot 8 * hh + j
-  uint4 A[3][4];
+  // pixel g's couts 0..15 in registers 0..15); K-step (dy, s): element 16 s + 8 hh + j of the window = column c, channel ch
+  uint4 A[3][3];
+  f32x16v bias16;   // the first MFMA's C operand: register i of either lane half is cout i
   {
     const float* wm = W.w[st]; const float* bm = W.b[st];
     const int g = (n >> 2) & 1, co = (n & 3) + 4 * (n >> 3);
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int s = 0; s < 3; ++s) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const int slot = 8 * hh + j, dx = c - g;
-          v[j] = 0.f;
-          if (co < 12) {
-            if (slot < 12) { if (dx >= 0 && dx < 3) v[j] = wm[((dy * 3 + dx) * 12 + slot) * 12 + co]; }
-            else if (slot == 12 && dy == 1 && dx == 1) v[j] = bm[co];   // the pixel's own record, constant-1 slot
-          }
+          const int k = 16 * s + 8 * hh + j, c = k / 12, ch = k - 12 * c, dx = c - g;
+          v[j] = (co < 12 && dx >= 0 && dx < 3) ? wm[((dy * 3 + dx) * 12 + ch) * 12 + co] : 0.f;
         }
-        A[dy][c] = make_uint4(half2_rne(v[0], v[1]), half2_rne(v[2], v[3]), half2_rne(v[4], v[5]), half2_rne(v[6], v[7]));
+        A[dy][s] = make_uint4(half2_rne(v[0], v[1]), half2_rne(v[2], v[3]), half2_rne(v[4], v[5]), half2_rne(v[6], v[7]));
       }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bias16[i] = i < 12 ? bm[i] : 0.f;
   }
   uint32_t slp[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) slp[j] = half2_rne(W.a[st][2 * j], W.a[st][2 * j + 1]);
-  // pixel operand of K-step (dy, c): record 2n + c (record = ring column + 1: record 0 and 65 are the zero borders), chunk hh
-  int rd[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) rd[c] = st * MH_STAGEB + mh_chunk(2 * (2 * n + c) + hh);
-  // this lane's output pixel of unit un: ring column 2n + hh + 64 un, its record's two chunks in the next layer's ring (a unit is 128
-  // chunks = 2 KB further: mh_chunk permutes chunks inside blocks of 64 only)
+  // pixel operand of K-step (dy, s): bytes 32 s + 16 hh of the window that starts at record 2n (record = ring column + 1: records 0 and
+  // 65 are the zero borders)
+  const int rd = st * MH_STAGEB + 2 * n * MH_RECB + 16 * hh;
+  // this lane's output pixel of unit un: ring column 2n + hh + 64 un, its record in the next layer's ring
   const int oc = 2 * n + hh, X = x0 - MH_HALO + oc;
-  const int wr0 = (st + 1) * MH_STAGEB + mh_chunk(2 * (oc + 1)), wr1 = (st + 1) * MH_STAGEB + mh_chunk(2 * (oc + 1) + 1);
+  const int wr = (st + 1) * MH_STAGEB + (oc + 1) * MH_RECB;
   const bool edge = x0 - MH_HALO < 0 || x0 - MH_HALO + MH_COLS > w;   // wave-uniform: this strip has columns outside the image
 
   const size_t plane_px = (size_t)h * w, total = (size_t)planes * plane_px;
@@ -1176,10 +1167,9 @@ __global__ __launch_bounds__(256, 4 / NU) void k_fs_maps4_h(const uint2* __restr
  for (int seg = 0;; ++seg) {   // one segment = rows [ylo, yhi) of `plane` (classic bands: exactly one)
   if (seg) { src = in + (size_t)plane * plane_px; dst = out + (size_t)plane * plane_px; __syncthreads(); }   // (every wave is done with the rings)
   for (int e = tid; e < MH_LDS / 16; e += 256) reinterpret_cast<uint4*>(mh_ring)[e] = make_uint4(0u, 0u, 0u, 0u);
-  // input loader: thread tid < 192 moves channel group lg = tid / 64 (8 bytes) of ring column lc = tid % 64; threads 192..255 write
-  // the constant-1 slots of the row
+  // input loader: thread tid < 192 moves channel group lg = tid / 64 (8 bytes) of ring column lc = tid % 64 (layer 3's wave has none)
   const int lg = tid >> 6, lc = tid & 63, lx = x0 - MH_HALO + lc;
-  const int ld_off = mh_chunk(2 * (lc + 1) + (lg >> 1)) + 8 * (lg & 1);
+  const int ld_off = (lc + 1) * MH_RECB + 8 * lg;
   // Every load is UNCONDITIONAL (address clamped into the image, the value replaced when it is stored): a load under a branch makes
   // hipcc wait with vmcnt(0), which also waits for the rows requested after it and turns the four-row prefetch into none
   const size_t lplane = (size_t)min(lg, 2) * total;
@@ -1190,9 +1180,9 @@ __global__ __launch_bounds__(256, 4 / NU) void k_fs_maps4_h(const uint2* __restr
     const int y = ylo - 4 + r, xx = lx + 64 * un;
     const bool in_img = xx >= 0 && xx < w && y >= 0 && y < h;
     uint2 o;   // (component-wise selects: selecting between whole values makes hipcc select between their addresses in scratch)
-    o.x = in_img ? (lg == 3 ? 0x00003c00u : v.x) : 0u;
-    o.y = (in_img && lg != 3) ? v.y : 0u;
-    *reinterpret_cast<uint2*>(mh_ring + (r & 3) * MH_ROWB + ld_off + un * 2048) = o;
+    o.x = in_img ? v.x : 0u;
+    o.y = in_img ? v.y : 0u;
+    if (lg < 3) *reinterpret_cast<uint2*>(mh_ring + (r & 3) * MH_ROWB + ld_off + un * MH_UNITB) = o;   // (wave-uniform)
   };
   __syncthreads();   // rings are zero
 #pragma unroll
@@ -1226,30 +1216,29 @@ __global__ __launch_bounds__(256, 4 / NU) void k_fs_maps4_h(const uint2* __restr
       if (r >= 0 && r <= rlast) {
         const int y = ylo - 4 + r;
         const bool row_in = y >= 0 && y < h;
-        uint32_t E[NU][8];
+        uint32_t E[NU][6];
 #pragma unroll
         for (int un = 0; un < NU; ++un)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) E[un][j] = 0u;
+          for (int j = 0; j < 6; ++j) E[un][j] = 0u;
         if (row_in) {   // wave-uniform
           f32x16v acc[NU];
-#pragma unroll
-          for (int un = 0; un < NU; ++un) acc[un] = zero16;
-          // the four pixel operands of a kernel row (of every unit) are read together, then its MFMAs issue; the next row's reads overlap
-          // them (left to itself hipcc re-uses one register quad: read, wait, MFMA, twelve times over)
+          // the three pixel operands of a kernel row (of every unit) are read together, then its MFMAs issue; the next row's reads overlap
+          // them (left to itself hipcc re-uses one register quad: read, wait, MFMA, nine times over)
 #pragma unroll
           for (int dy = 0; dy < 3; ++dy) {
-            uint4 b[NU][4];
+            uint4 b[NU][3];
 #pragma unroll
             for (int un = 0; un < NU; ++un)
 #pragma unroll
-              for (int c = 0; c < 4; ++c) b[un][c] = *reinterpret_cast<const uint4*>(mh_ring + rd[c] + un * 2048 + ((u + 3 + dy) & 3) * MH_ROWB);
+              for (int s = 0; s < 3; ++s) b[un][s] = *reinterpret_cast<const uint4*>(mh_ring + rd + 32 * s + un * MH_UNITB + ((u + 3 + dy) & 3) * MH_ROWB);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int s = 0; s < 3; ++s)
 #pragma unroll
               for (int un = 0; un < NU; ++un)
-                acc[un] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A[dy][c]), __builtin_bit_cast(f16x8v, b[un][c]), acc[un], 0, 0, 0);
+                acc[un] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, A[dy][s]), __builtin_bit_cast(f16x8v, b[un][s]),
+                                                                 (dy == 0 && s == 0) ? bias16 : acc[un], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
           stamp(1);
@@ -1257,11 +1246,10 @@ __global__ __launch_bounds__(256, 4 / NU) void k_fs_maps4_h(const uint2* __restr
           for (int un = 0; un < NU; ++un) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) E[un][j] = prelu_h2(half2_rne(acc[un][2 * j], acc[un][2 * j + 1]), slp[j]);
-            E[un][6] = 0x00003c00u;
             const int Xu = X + 64 * un;
             if (edge && !(Xu >= 0 && Xu < w)) {   // a column outside the image is zero padding for the next layer
 #pragma unroll
-              for (int j = 0; j < 7; ++j) E[un][j] = 0u;
+              for (int j = 0; j < 6; ++j) E[un][j] = 0u;
             }
           }
         }
@@ -1269,8 +1257,9 @@ __global__ __launch_bounds__(256, 4 / NU) void k_fs_maps4_h(const uint2* __restr
         for (int un = 0; un < NU; ++un) {
           const int ocu = oc + 64 * un, Xu = X + 64 * un;
           if (st < 3) {
-            *reinterpret_cast<uint4*>(mh_ring + wr0 + un * 2048 + ((u + 2) & 3) * MH_ROWB) = make_uint4(E[un][0], E[un][1], E[un][2], E[un][3]);
-            *reinterpret_cast<uint4*>(mh_ring + wr1 + un * 2048 + ((u + 2) & 3) * MH_ROWB) = make_uint4(E[un][4], E[un][5], E[un][6], E[un][7]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+              *reinterpret_cast<uint2*>(mh_ring + wr + 8 * q + un * MH_UNITB + ((u + 2) & 3) * MH_ROWB) = make_uint2(E[un][2 * q], E[un][2 * q + 1]);
           } else if (row_in && y >= ylo && y < yhi && ocu >= MH_HALO && ocu < MH_HALO + MH_CI && Xu < w) {
             uint2* o = dst + (size_t)y * w + Xu;
             o[0] = make_uint2(E[un][0], E[un][1]); o[total] = make_uint2(E[un][2], E[un][3]); o[2 * total] = make_uint2(E[un][4], E[un][5]);
