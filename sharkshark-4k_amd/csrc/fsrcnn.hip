@@ -1119,7 +1119,7 @@ template <int NU> struct MhGeo {
 };
 
 template <bool STAMP, int NU>
-__global__ __launch_bounds__(256, 4 / NU) void k_fs_maps4_h(const uint2* __restrict__ in, uint2* __restrict__ out, const FsMapW W,
+__global__ __launch_bounds__(256, NU == 2 ? 3 : 4) void k_fs_maps4_h(const uint2* __restrict__ in, uint2* __restrict__ out, const FsMapW W,
                                                             int planes, int h, int w, int bands, unsigned long long* dbg, int tall_rpb = 0) {
   constexpr int MH_COLS = MhGeo<NU>::COLS, MH_CI = MhGeo<NU>::CI, MH_ROWB = MhGeo<NU>::ROWB, MH_STAGEB = MhGeo<NU>::STAGEB, MH_LDS = MhGeo<NU>::LDS;
   extern __shared__ __attribute__((aligned(16))) char mh_ring[];
@@ -1380,6 +1380,7 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
       // barriers, half the barriers and halo columns per pixel - at two workgroups per CU instead of four, 66.5 KB of rings each) is
       // bit-identical and 8.7 % SLOWER on the stage (0.375 against 0.345 ms per 12 planes of 720p, profiles/earlier/r05/r05_fs_nu_ab.txt): four
       // resident workgroups per CU interleave better than one wave does with itself.  Kept as a dev-library switch (SS4K_MH_NU=2).
+      // Round 6, packed records (rings of 50 KB, three workgroups per CU, tall bands): 0.235 against 0.238 ms - within a percent; still the switch.
       int mh_nu = 1;
 #ifdef SS4K_DEV
       if (const char* e = std::getenv("SS4K_MH_NU")) mh_nu = std::atoi(e);
@@ -1387,7 +1388,8 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
       const int NUr = (mh_nu != 2 || w <= MhGeo<1>::CI) ? 1 : 2;
       const int MH_CI = NUr == 2 ? MhGeo<2>::CI : MhGeo<1>::CI, MH_LDS = NUr == 2 ? MhGeo<2>::LDS : MhGeo<1>::LDS;
       const int hs = (w + MH_CI - 1) / MH_CI;
-      int hb = std::max(1, std::min((h + 31) / 32, (4 / NUr) * ctx->num_cu / std::max(1, planes * hs)));   // one round at four (two) per CU
+      const int per_cu = NUr == 2 ? 3 : 4;   // resident workgroups per CU (rings of 25 | 50 KB)
+      int hb = std::max(1, std::min((h + 31) / 32, per_cu * ctx->num_cu / std::max(1, planes * hs)));   // one round
 #ifdef SS4K_DEV
       if (const char* e = std::getenv("SS4K_MH_BANDS")) hb = std::max(1, std::atoi(e));
 #endif
@@ -1426,9 +1428,9 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
         int tall_rpb = 0;
         unsigned nwg = (unsigned)(planes * hb * hs);
         static const bool tall_off = std::getenv("SS4K_MH_NO_TALL") != nullptr;
-        if (NUr == 1 && !tall_off) {
+        if (!tall_off) {
           const long rows = (long)planes * h;
-          const int slots = (4 / NUr) * ctx->num_cu;
+          const int slots = per_cu * ctx->num_cu;
           const int nb = (int)std::max(1L, std::min(rows / 32, (long)(slots / std::max(1, hs))));
           tall_rpb = (int)((rows + nb - 1) / nb);
           nwg = (unsigned)(((rows + tall_rpb - 1) / tall_rpb) * hs);

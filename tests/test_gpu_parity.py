@@ -716,12 +716,16 @@ def test_fsrcnn_tall_bands_same_bytes_as_whole_bands_per_plane():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for switches in ({}, {"SS4K_MH_NO_TALL": "1", "SS4K_TAIL_NO_TALL": "1"}):
+    # (third run: the fp16 mapping stage with two 64-column units per workgroup strip - a kept A/B build of the DEV library, classic bands)
+    from sharkshark4k_amd import build as B
+    assert os.path.exists(B.LIB_DEV), "libss4k_hip_dev.so was not built (__graft_entry__.build())"
+    for switches in ({}, {"SS4K_MH_NO_TALL": "1", "SS4K_TAIL_NO_TALL": "1"}, {"SS4K_LIB": B.LIB_DEV, "SS4K_MH_NU": "2"}):
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "drive_fs_bands.py")], cwd=root, capture_output=True, text=True, timeout=900,
                            env=dict(os.environ, **switches))
         assert r.returncode == 0 and "FS BANDS DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("x")])
-    assert len(outs[0]) == 16 and outs[0] == outs[1], [(a, b) for a, b in zip(*outs) if a != b]
+    assert len(outs[0]) == 16 and outs[0] == outs[1], [(a, b) for a, b in zip(outs[0], outs[1]) if a != b]
+    assert outs[0] == outs[2], [(a, b) for a, b in zip(outs[0], outs[2]) if a != b]
 
 
 # ------------------------------------------------------------------------------ fp16 HR tensor on the batched service path

@@ -8,4 +8,5 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('%-8s %-11s %7.1f frames/s   stages ms: %s' % ('$1', '$3', d['value'], '  '.join('%s %.4f' % (k.split(' ')[0], v['ms_per_step']) for k, v in d['roofline']['stages'].items())))"
 }
-for r in $(seq $R); do for wl in fsrcnn_f16 fsrcnn; do one with "$SW" $wl; one without SS4K_AB=0 $wl; done; done
+BASE=${3:-SS4K_AB=0}   # third argument: environment of BOTH runs (e.g. SS4K_LIB=... for switches of the dev library)
+for r in $(seq $R); do for wl in fsrcnn_f16 fsrcnn; do one with "$BASE $SW" $wl; one without "$BASE" $wl; done; done
