@@ -52,7 +52,19 @@ __global__ __launch_bounds__(256) void k(const uint4* __restrict__ src, float* o
       f32x16 e1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[2], z, 0, 0, 0);
       v += e0[0] + e1[0];
     }
-    if constexpr (MODE == 0 || MODE == 2) {
+    if constexpr (MODE == 4 || MODE == 5) {   // the same matrix work as 28 x v_mfma_f32_16x16x32_f16 (16 cycles each), seven chains of four
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 7; ++c) {
+        f32x4 acc = z4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(s + (c >> 2)) & 3], b[(s + c) & 3], acc, 0, 0, 0);   // (no two chains alike)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T[c % 3][(4 * (c / 3) + e) & 15] = acc[e];
+      }
+    }
+    if constexpr (MODE == 0 || MODE == 2 || MODE == 4) {
       if constexpr (MODE == 2) {   // (the accumulators are opaque every iteration: nothing of the block below can be hoisted)
 #pragma unroll
         for (int tb = 0; tb < 3; ++tb)
@@ -140,5 +152,7 @@ int main() {
   run<2>("vector phase only", src, out, res, cus);
   run<0>("MFMA phase, then vector phase (the tail)", src, out, res, cus);
   run<3>("software-pipelined by hand", src, out, res, cus);
+  run<5>("28 x MFMA 16x16x32 only", src, out, res, cus);
+  run<4>("28 x MFMA 16x16x32, then vector phase", src, out, res, cus);
   return 0;
 }
