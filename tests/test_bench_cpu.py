@@ -135,3 +135,16 @@ def test_live_traffic_declines_cleanly_and_aggregates_what_a_profiler_wrote(tmp_
     assert t["launches_counted"] == 6 and t["steps"] == 2 and t["frames_per_launch"] == 2
     assert t["traffic_bytes_per_step"] == (2 * 1000.0 + 300.0) * 1024 * 6 / 2
     assert set(t["by_kernel"]) == {"conv3x3_w16_kernel", "conv3x3_dense2_kernel", "conv3x3_w16n_kernel"}
+
+
+def test_packed_record_bank_enumeration_matches_the_kernel_comment():
+    """tools/costing/fm_packed_banks.py: the LDS cycles fsrcnn.hip quotes for the fp32-grade mapping stage's packed-record reads (40 per unit
+    of 16 pixels with hi | lo interleaved records and pieces 8 ks + q + 4 e; the split-row layout is worse) are what the enumeration gives."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "costing"))
+    try:
+        import fm_packed_banks as fb
+    finally:
+        sys.path.pop(0)
+    natural = fb.assigns["8ks+q+4e"]
+    assert fb.cycles(fb.layout_interleaved(fb.FM_RW * 48), natural) == 40
+    assert fb.cycles(fb.layout_split(fb.FM_RW * 24), natural) > 40

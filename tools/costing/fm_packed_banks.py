@@ -39,10 +39,11 @@ assigns = {
     "8ks+2q+e": lambda ks, q, e: 8 * ks + 2 * q + e,
     "8ks+q+4e, quarters swapped 1<->2": lambda ks, q, e: 8 * ks + (0, 2, 1, 3)[q] + 4 * e,
 }
-for name, a in assigns.items():
-    print(f"{name:36s} interleaved hi|lo records (48 B): {cycles(layout_interleaved(FM_RW * 48), a):3d}   "
-          f"split hi / lo rows (24 B): {cycles(layout_split(FM_RW * 24), a):3d}   "
-          f"split, rows padded to 1216 B: {cycles(layout_split(1216), a):3d}")
+def table():
+    for name, a in assigns.items():
+        print(f"{name:36s} interleaved hi|lo records (48 B): {cycles(layout_interleaved(FM_RW * 48), a):3d}   "
+              f"split hi / lo rows (24 B): {cycles(layout_split(FM_RW * 24), a):3d}   "
+              f"split, rows padded to 1216 B: {cycles(layout_split(1216), a):3d}")
 
 
 def search(seed=0, iters=20000):
@@ -70,6 +71,7 @@ def search(seed=0, iters=20000):
 
 if __name__ == "__main__":
     import sys
+    table()
     if "--search" in sys.argv:
         c, perm = search()
         print("best", c, "slot (ks, e, q) -> piece:", perm)
