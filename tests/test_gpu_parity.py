@@ -707,6 +707,34 @@ def test_fsrcnn_service_accumulators_clean_themselves_across_jobs(ctx, dtype):
     one.close()
 
 
+@pytest.mark.parametrize("factor", [2, 4])
+def test_fsrcnn_strip_and_band_boundaries_vs_oracle(ctx, factor):
+    """Widths on either side of every strip width of the matrix-core stages (mapping: 56 interior columns per workgroup in fp16 mode, 40 in
+    fp32-grade mode; tail: 28 | 30 per wave; head: 128), heights from one row up to a band that straddles planes, 2-5 planes: both modes
+    against the fp32 CPU forward (fp32-grade at the network tolerance, fp16 mode by PSNR)."""
+    table = W.fsrcnn_table(seed=11 + factor)
+    m32 = factory.build_model_fsrcnn(ctx, factor=factor, weights=table)
+    m16 = factory.build_model_fsrcnn(ctx, factor=factor, weights=table, dtype="f16")
+    widths = [1, 2, 27, 28, 29, 30, 31, 39, 40, 41, 55, 56, 57, 111, 112, 113, 127, 128, 129]
+    heights = [1, 2, 3, 17, 33]
+    worst = 99.0
+    for i, wd in enumerate(widths):
+        ht = heights[i % len(heights)]
+        planes = 2 + i % 4
+        x = torch.rand(planes, 1, ht, wd, generator=torch.Generator().manual_seed(1000 * ht + wd))
+        with torch.no_grad():
+            want = onets.fsrcnn(x, table, factor)
+        got32 = m32(x.cuda()).cpu()
+        assert_close(got32, want, what=f"fsrcnn x{factor} fp32-grade {planes}x{ht}x{wd}")
+        got16 = m16(x.cuda()).float().cpu()
+        assert torch.isfinite(got16).all()
+        peak = float(want.abs().max())
+        p = psnr(got16 / peak, want / peak)
+        worst = min(worst, p)
+        assert p > 60.0, f"fsrcnn x{factor} fp16 mode {planes}x{ht}x{wd}: PSNR {p:.1f} dB"
+    record_measured(f"fsrcnn_boundaries_x{factor}", worst_psnr_db_f16=worst, cases=len(widths))
+
+
 def test_fsrcnn_tall_bands_same_bytes_as_whole_bands_per_plane():
     """Round 6's grids (fp16 mapping stage, both matrix-core tails: the planes stacked into one tall image, cut into as many bands as fill
     the chip's workgroup slots, a band straddling plane boundaries marched in segments) against the classic ones (SS4K_MH_NO_TALL,
