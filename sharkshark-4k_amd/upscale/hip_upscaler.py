@@ -74,6 +74,9 @@ def log(*args, **kwargs):
     print(f"HipUpscalerService: {' '.join(str(a) for a in args)}", **kwargs)
 
 
+#: the reference's own backend names (realesrgan/factory.py:175-230, fsrcnn/factory.py:17-69, bsvd/factory.py:21-75)
+REFERENCE_BACKENDS = ("trt", "t2trt", "jit", "ds", "trt_vol")
+
 class HipUpscalerService(BaseUpscalerService):
     profiler: Profiler
     #: (input ring, output ring) of pinned shared host memory for ``HostFrames`` jobs (hostring.py); None: every job carries a tensor
@@ -98,9 +101,14 @@ class HipUpscalerService(BaseUpscalerService):
                  group: Optional[sharding.GroupSpec] = None, overlap_jobs=True, overlap_sets=3, overlap_max_frames=1):
         # None (the stream pipeline's default: "the compiled backend", pipeline.py:23,41-44) and False (the image server: "eager",
         # image_pipeline.py:58-61) both mean "whatever this build runs the network with" to a caller that cannot know about 'hip';
-        # a backend asked for BY NAME that this build does not have ('trt', 'jit', 'ds', 't2trt': realesrgan/factory.py:175-230) is refused
-        if not (jit_mode is None or jit_mode is False or jit_mode == "hip"):
-            raise Exception(f"jit_mode={jit_mode!r}: this build has one backend, 'hip' (None and False select it too)")
+        # so does a backend of the REFERENCE asked for by name ('trt', 't2trt', 'jit', 'ds': realesrgan/factory.py:175-230, fsrcnn/factory.py:17-69 -
+        # a configuration written for the reference keeps working; said once on stderr).  Any other name is refused, as the reference's
+        # factories refuse a name they do not know.
+        if jit_mode in REFERENCE_BACKENDS:
+            print(f"HipUpscalerService: jit_mode={jit_mode!r} names a backend of the reference; this build runs every network on its one "
+                  f"backend, 'hip'", file=sys.stderr)
+        elif not (jit_mode is None or jit_mode is False or jit_mode == "hip"):
+            raise Exception(f"jit_mode={jit_mode!r}: this build has one backend, 'hip' (None, False and the reference's names select it too)")
         if upscaler_model not in ("fsrcnn", "realesrgan"):
             raise Exception(upscaler_model)
         self.lr_shape = tuple(lr_shape) if lr_shape is not None else LR_LEVELS[lr_level]

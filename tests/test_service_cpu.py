@@ -114,9 +114,10 @@ def test_hip_service_configuration_mirrors_reference():
     with pytest.raises(Exception):
         HipUpscalerService(upscaler_model="egvsr")
     with pytest.raises(Exception):
-        HipUpscalerService(jit_mode="trt")   # a backend asked for by name that this build does not have
-    # the callers' own literals: None (stream pipeline default) and False (the image server's "eager") select the one backend
-    for jm in (None, False, "hip"):
+        HipUpscalerService(jit_mode="tensorrt9")   # a name neither this build nor the reference's factories know
+    # the callers' own literals: None (stream pipeline default) and False (the image server's "eager") select the one backend, and so do
+    # the reference's backend names (a configuration written for it keeps working)
+    for jm in (None, False, "hip", "trt", "t2trt", "jit", "ds"):
         assert HipUpscalerService(denoising=False, jit_mode=jm).jit_mode == "hip"
     image_server = HipUpscalerService(lr_level=3, device=0, denoising=False, denoise_rate=0.2, on_queue=None, upscaler_model="realesrgan",
                                       batch_size=1, jit_mode=False, lr_hr_resize=False)   # the image server's constructor call, literally
