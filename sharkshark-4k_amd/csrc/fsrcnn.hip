@@ -17,15 +17,13 @@
 namespace ss4k {
 
 __device__ __forceinline__ float prelu(float v, float a) { return v >= 0.f ? v : a * v; }
-// PReLU of the matrix-core modes as max(v, a v): one instruction less than compare + select.  It is PReLU for a <= 1 only; a model of those
-// modes carries every channel with a > 1 negated through its activation (weights folded when it is built, models.cpp: exact, rounding
-// to nearest is sign-symmetric), where max(-v, -a v) = -PReLU(v).  The exact-fp32 kernels (unfolded weights) keep prelu().
-__device__ __forceinline__ float prelu_mx(float v, float a) {
-  const float t = a * v;
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(t));   // (= fmaxf for non-NaN inputs, one instruction)
-  return r;
-}
+// PReLU of the matrix-core modes in ONE full-rate instruction.  PReLU(x) = a x + b |x| with a = (1 + s) / 2, b = (1 - s) / 2; a model of those
+// modes has the weights and the bias that PRODUCE a channel scaled by its a when it is built (models.cpp; s > -1 + 1/8 for every channel, else
+// the exact kernels), so the accumulator holds y = a x, and PReLU(x) = y + c |y| with c = b / a = (1 - s) / (1 + s) - which is what the model's
+// "slope" arrays hold in these modes.  |y| is a source modifier: v_fma_f32 at 2.1 cycles against multiply + v_max_f32 (2.1 + 3.8: v_max is a
+// half-rate instruction, tools/micro/valu_rates.hip) or, on packed fp16, v_pk_mul_f16 + v_pk_max_f16 (3.6 + 3.9).  Padded channels: c = 0.
+// The exact-fp32 kernels (unscaled weights, true slopes) keep prelu().
+__device__ __forceinline__ float prelu_mx(float y, float c) { return __builtin_fmaf(__builtin_fabsf(y), c, y); }
 
 __global__ __launch_bounds__(256) void k_fs_head(const float* __restrict__ in, float* __restrict__ out,
                                                  const float* __restrict__ wf, const float* __restrict__ bf,
@@ -322,17 +320,9 @@ __device__ __forceinline__ uint32_t half2_rne(float x0, float x1) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h16x2v));
 }
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-// PReLU on a packed fp16 pair as max(v, v s): a packed multiply and a packed max (rounds 3-5: max(v, 0) + s min(v, 0), three
-// instructions - the fp16 kernels issue 10-11 vector instructions per MFMA, profiles/r06_fsrcnn_f16_inst_counters.json, and a third to
-// three quarters of them are this function).  max(v, v s) is PReLU only for s <= 1; an fp16-mode model therefore carries every channel
-// with s > 1 NEGATED through its activation (its producing weights and bias and its consuming weights are negated when the model is
-// built, models.cpp): max(-v, -v s) = -min(v, v s) = -PReLU(v) for s > 1.  Same bits as the three-instruction form either way
-// (v < 0: s v >= v, and fl(s v) is what the fma form rounds to; v >= 0: s v <= v; rounding to nearest is sign-symmetric).
-__device__ __forceinline__ uint32_t prelu_h2(uint32_t x, uint32_t a) {
-  const h16x2 v = __builtin_bit_cast(h16x2, x), sl = __builtin_bit_cast(h16x2, a);
-  const h16x2 r = __builtin_elementwise_max(v, v * sl);
-  return __builtin_bit_cast(uint32_t, r);
-}
+// fp16 mode: PReLU in fp32 on the accumulators (prelu_mx: one fma each), then ONE rounding to fp16 - rounds 3-6 converted first and took
+// max(v, v s) on the packed pair (v_cvt_pk + v_pk_mul_f16 + v_pk_max_f16 = 13 cycles a pair; now 2 x 2.1 + the conversion's 5.6)
+__device__ __forceinline__ uint32_t prelu_h2(float y0, float y1, float c0, float c1) { return half2_rne(prelu_mx(y0, c0), prelu_mx(y1, c1)); }
 template <bool SPLIT>
 __device__ __forceinline__ void pack2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
   if constexpr (SPLIT) split2(x0, x1, hi, lo); else { hi = half2_rne(x0, x1); lo = 0u; }
@@ -418,21 +408,18 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
     }
     we_hi[tid] = make_uint4(vh[0], vh[1], vh[2], vh[3]); we_lo[tid] = make_uint4(vl[0], vl[1], vl[2], vl[3]);
   }
-  if (tid < 64) { bea[tid] = tid < 56 ? be[tid] : 0.f; bea[64 + tid] = tid < 56 ? ae[tid] : 1.f; }
+  if (tid < 64) { bea[tid] = tid < 56 ? be[tid] : 0.f; bea[64 + tid] = tid < 56 ? ae[tid] : 0.f; }   // (PReLU constants c, prelu_mx: 0 = identity)
   __syncthreads();
   // ws: this wave's strip of CI interior columns; nothing below synchronises
   if (ws >= wstrips || (tall_rpb > 0 && tall0 >= tall1)) return;
 
-  // fp16 mode: PReLU slopes of the expand channels this lane's accumulators hold, packed in pairs (registers instead of LDS reads)
-  uint32_t slp[2][8];
+  // fp16 mode: PReLU constants of the expand channels this lane's accumulators hold (registers instead of LDS reads)
+  float slp[2][SPLIT ? 1 : 16];
   if constexpr (!SPLIT) {
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int i = 0; i < 16; i += 2) {
-        const int c0 = 32 * b + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        slp[b][i >> 1] = half2_rne(bea[64 + c0], bea[64 + c0 + 1]);
-      }
+      for (int i = 0; i < 16; ++i) slp[b][i] = bea[64 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * hh];
   }
   const size_t plane_px = (size_t)h * w, total = (size_t)planes * plane_px;
   const int OW = S * w, OH = S * h;
@@ -503,7 +490,7 @@ __global__ __launch_bounds__(256, 3) void k_fs_tail_r(const float* __restrict__ 
           const f32x16v E1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bxh, zero16, 0, 0, 0);
           uint32_t e[8];
 #pragma unroll
-          for (int i = 0; i < 16; i += 2) e[i >> 1] = prelu_h2(half2_rne(E1[i], E1[i + 1]), slp[b][i >> 1]);
+          for (int i = 0; i < 16; i += 2) e[i >> 1] = prelu_h2(E1[i], E1[i + 1], slp[b][i], slp[b][i + 1]);
           ebh[2 * b] = make_uint4(e[0], e[1], e[2], e[3]); ebh[2 * b + 1] = make_uint4(e[4], e[5], e[6], e[7]);
           ebl[2 * b] = ebl[2 * b + 1] = make_uint4(0u, 0u, 0u, 0u);
         }
@@ -661,8 +648,8 @@ __global__ __launch_bounds__(256, 2) void k_fs_head_m(const float* __restrict__ 
   if constexpr (U8IN) { u8_lut[tid & 255] = (float)(tid & 255) / 255.0f; if constexpr (!SPLIT) __syncthreads(); }
   if constexpr (SPLIT) {
     // [kq][block b][i]: slope of channel 32b + (i&3) + 8(i>>2) + 4kq; then [kq][i] for the shrink's rows (i&3) + 8(i>>2) + 4kq
-    if (tid < 64) { const int q = tid >> 5, bb = (tid >> 4) & 1, i = tid & 15, c = 32 * bb + (i & 3) + 8 * (i >> 2) + 4 * q; slope_lds[tid] = c < 56 ? af[c] : 1.f; }
-    else if (tid < 80) { const int q = (tid - 64) >> 3, i = tid & 7, c = (i & 3) + 8 * (i >> 2) + 4 * q; slope_lds[tid] = c < 12 ? as[c] : 1.f; }
+    if (tid < 64) { const int q = tid >> 5, bb = (tid >> 4) & 1, i = tid & 15, c = 32 * bb + (i & 3) + 8 * (i >> 2) + 4 * q; slope_lds[tid] = c < 56 ? af[c] : 0.f; }
+    else if (tid < 80) { const int q = (tid - 64) >> 3, i = tid & 7, c = (i & 3) + 8 * (i >> 2) + 4 * q; slope_lds[tid] = c < 12 ? as[c] : 0.f; }
     __syncthreads();
   }
   if (plane >= planes || ylo >= yhi) return;   // whole waves leave: nothing below synchronises across waves
@@ -711,20 +698,20 @@ __global__ __launch_bounds__(256, 2) void k_fs_head_m(const float* __restrict__ 
     A2[0][s4] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
     if constexpr (SPLIT) A2[1][s4] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
   }
-  // fp16 mode: PReLU slopes of the channels this lane's accumulators hold, packed in pairs (SPLIT: fp32, in LDS)
-  uint32_t sl1[2][8], sl2[4];
+  // fp16 mode: PReLU constants (prelu_mx) of the channels this lane's accumulators hold (SPLIT: in LDS); 0 for a padded channel
+  float sl1[2][SPLIT ? 1 : 16], sl2[SPLIT ? 1 : 8];
   if constexpr (!SPLIT) {
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int i = 0; i < 16; i += 2) {
+      for (int i = 0; i < 16; ++i) {
         const int c0 = 32 * b + (i & 3) + 8 * (i >> 2) + 4 * kq;
-        sl1[b][i >> 1] = half2_rne(c0 < 56 ? af[c0] : 1.f, c0 + 1 < 56 ? af[c0 + 1] : 1.f);
+        sl1[b][i] = c0 < 56 ? af[c0] : 0.f;
       }
 #pragma unroll
-    for (int i = 0; i < 8; i += 2) {
+    for (int i = 0; i < 8; ++i) {
       const int c0 = (i & 3) + 8 * (i >> 2) + 4 * kq;
-      sl2[i >> 1] = half2_rne(c0 < 12 ? as[c0] : 1.f, c0 + 1 < 12 ? as[c0 + 1] : 1.f);
+      sl2[i] = c0 < 12 ? as[c0] : 0.f;
     }
   }
 
@@ -835,7 +822,7 @@ __global__ __launch_bounds__(256, 2) void k_fs_head_m(const float* __restrict__ 
             }
           } else {
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) E[0][i >> 1] = prelu_h2(half2_rne(acc[i], acc[i + 1]), sl1[b][i >> 1]);
+            for (int i = 0; i < 16; i += 2) E[0][i >> 1] = prelu_h2(acc[i], acc[i + 1], sl1[b][i], sl1[b][i + 1]);
           }
 #pragma unroll
           for (int hs = 0; hs < 2; ++hs) {
@@ -865,7 +852,7 @@ __global__ __launch_bounds__(256, 2) void k_fs_head_m(const float* __restrict__ 
           }
         } else {
 #pragma unroll
-          for (int i = 0; i < 8; i += 2) o[g][i >> 1] = prelu_h2(half2_rne(d2[i], d2[i + 1]), sl2[i >> 1]);
+          for (int i = 0; i < 8; i += 2) o[g][i >> 1] = prelu_h2(d2[i], d2[i + 1], sl2[i], sl2[i + 1]);
         }
       }
       // lane half 0 holds channel groups 0 (registers 0-3) and 2 (registers 4-7), lane half 1 group 1, of pixels P + 2n, P + 2n + 1
@@ -966,7 +953,7 @@ __global__ __launch_bounds__(256, 4) void k_fs_maps4(const float* __restrict__ i
   // (their weights are zero): the last real one is read instead
   f32x4v bia, slo;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { const int c = 4 * q + i; bia[i] = c < 12 ? W.b[st][c] : 0.f; slo[i] = c < 12 ? W.a[st][c] : 1.f; }
+  for (int i = 0; i < 4; ++i) { const int c = 4 * q + i; bia[i] = c < 12 ? W.b[st][c] : 0.f; slo[i] = c < 12 ? W.a[st][c] : 0.f; }
   // (the kernel row p / 9 of slot (ks, e) is the same for all four quarters except in two slots: (1, 0) - pieces 8 | 9, 10, 11 - and
   // (2, 0) - pieces 16, 17 | 18, 19: the ring row's offset is a scalar everywhere else)
   int pc_off[4][2];
@@ -1181,9 +1168,9 @@ __global__ __launch_bounds__(256, NU == 2 ? 3 : 4) void k_fs_maps4_h(const uint2
 #pragma unroll
     for (int i = 0; i < 16; ++i) bias16[i] = i < 12 ? bm[i] : 0.f;
   }
-  uint32_t slp[6];
+  float slp[12];   // PReLU constants (prelu_mx) of this wave's layer: wave-uniform
 #pragma unroll
-  for (int j = 0; j < 6; ++j) slp[j] = half2_rne(W.a[st][2 * j], W.a[st][2 * j + 1]);
+  for (int j = 0; j < 12; ++j) slp[j] = W.a[st][j];
   // pixel operand of K-step (dy, s): bytes 32 s + 16 hh of the window that starts at record 2n (record = ring column + 1: records 0 and
   // 65 are the zero borders)
   const int rd = st * MH_STAGEB + 2 * n * MH_RECB + 16 * hh;
@@ -1278,7 +1265,7 @@ __global__ __launch_bounds__(256, NU == 2 ? 3 : 4) void k_fs_maps4_h(const uint2
 #pragma unroll
           for (int un = 0; un < NU; ++un) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) E[un][j] = prelu_h2(half2_rne(acc[un][2 * j], acc[un][2 * j + 1]), slp[j]);
+            for (int j = 0; j < 6; ++j) E[un][j] = prelu_h2(acc[un][2 * j], acc[un][2 * j + 1], slp[2 * j], slp[2 * j + 1]);
             const int Xu = X + 64 * un;
             if (edge && !(Xu >= 0 && Xu < w)) {   // a column outside the image is zero padding for the next layer
 #pragma unroll
@@ -1323,7 +1310,7 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
                     int w, float* ws12a, float* ws12b, int mode, hipStream_t st, bool out_half, bool in_u8) {
   const bool exact = mode == FS_MODE_EXACT, half = mode == FS_MODE_HALF;
   SS4K_REQUIRE(!out_half || half, "FSRCNN: an fp16 output tensor is offered in fp16 mode only");
-  SS4K_REQUIRE(exact || W.prelu_le1, "FSRCNN matrix-core modes: the weight blob is not sign-folded for the max-form PReLU (models.cpp)");
+  SS4K_REQUIRE(exact || W.prelu_abs, "FSRCNN matrix-core modes: the weight blob is not scaled for the one-fma PReLU (models.cpp)");
   SS4K_REQUIRE(!in_u8 || (!exact && planes % 3 == 0), "FSRCNN: uint8 NHWC input is read by the matrix-core head only, three colour planes per frame");
   const size_t total = (size_t)planes * h * w;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
@@ -1345,7 +1332,7 @@ void fsrcnn_forward(ss4k_ctx* ctx, const FsrcnnWeights& W, int factor, const flo
     const int hbands = (h + (h + hb0 - 1) / hb0 - 1) / ((h + hb0 - 1) / hb0);
     const unsigned hwaves = (unsigned)(planes * hbands * hstrips);
     if (half) {
-      SS4K_REQUIRE(W.prelu_le1, "FSRCNN fp16 mode: the weight blob is not sign-folded for the max-form PReLU (models.cpp)");
+      SS4K_REQUIRE(W.prelu_abs, "FSRCNN fp16 mode: the weight blob is not scaled for the one-fma PReLU (models.cpp)");
       auto hk = in_u8 ? &k_fs_head_m<false, true> : &k_fs_head_m<false, false>;
       hipLaunchKernelGGL(hk, dim3((hwaves + 3) / 4), block, 0, st, in, static_cast<void*>(ws12a), W.w_feat, W.b_feat,
                          W.a_feat, W.w_shrink, W.b_shrink, W.a_shrink, planes, h, w, hbands);

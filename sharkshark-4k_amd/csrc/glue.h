@@ -73,7 +73,7 @@ struct FsrcnnWeights {
   const float* b_expand; const float* a_expand;  // [56]
   const float* w_deconv; // [81][56]  (ky*9+kx), cin
   float b_deconv;
-  bool prelu_le1 = false;   // fp16-mode models: channels with a PReLU slope > 1 are carried negated (models.cpp), so max(v, v s) is PReLU for every channel
+  bool prelu_abs = false;   // matrix-core modes: producing weights / biases scaled by (1 + s) / 2 and the slope arrays hold (1 - s) / (1 + s) (models.cpp): PReLU is y + c |y|
 };
 // mode: fp32 accuracy on the fp16 matrix rate (hi/lo-split operands, the default of an SS4K_F32 model), the exact-fp32 kernels, or
 // plain fp16 operands with fp32 accumulation (an SS4K_F16 model: the precision the reference's TensorRT engine runs FSRCNN in)

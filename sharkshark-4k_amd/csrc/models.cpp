@@ -294,33 +294,29 @@ void Model::build(const float* w, size_t n) {
     for (int c = 0; c < 56; ++c) for (int t = 0; t < 81; ++t) wd[(size_t)t * 56 + c] = p[(size_t)c * 81 + t];
     off[k++] = push(wd);
     fsw.b_deconv = *pc.take(1);
-    // Matrix-core modes: PReLU as max(v, v s) - an instruction less than the select form (fsrcnn.hip prelu_h2 / prelu_mx) - is PReLU only for s <= 1; for a
-    // channel with s > 1 it is min(v, v s) = -max(-v, -v s).  The real checkpoints have such channels (T91 x2: one at 1.04; x4: up to 9.1).
-    // So every channel with s > 1 is carried NEGATED through its activation: its producing weights and bias are negated here, and so are
-    // the weights with which the next layer consumes it.  Rounding to nearest is sign-symmetric in every step (products, fp32 sums, fp16
-    // conversions), so the network's values are bit for bit what they were; the kernels then take the max form for every channel.
+    // Matrix-core modes: PReLU(x) = a x + b |x| with a = (1 + s) / 2, b = (1 - s) / 2.  The weights and the bias that PRODUCE a channel are
+    // scaled by its a here, so the kernels' accumulators hold y = a x, and PReLU(x) = y + c |y| with c = b / a = (1 - s) / (1 + s) - one fma
+    // with a free |.| modifier per value (fsrcnn.hip prelu_mx; rounds 3-6: multiply + max on values carried negated where s > 1).  The
+    // slope arrays of the blob hold c.  Needs a > 0, i.e. s > -1, for every channel (real checkpoints: T91 x2 0.0 .. 1.04, x4 up to 9.1);
+    // a slope at or below -1 + 1/8 - where c would exceed 15 and the scaled weights lose their bits - sends the model to the exact kernels.
+    // (offsets into `blob`: 0 w_feat [25][56], 1 b_feat, 2 a_feat, 3 w_shrink [56][12], 4 b, 5 a, 6 + 3l w_map[l] [9][12][12] (tap, cin, cout),
+    //  7 + 3l b, 8 + 3l a, 18 w_expand [12][56], 19 b, 20 a, 21 w_deconv [81][56] (tap, cin))
+    struct Act { int w, b, a, channels, count, stride; };   // producing weights: `count` values per channel, `stride` apart, first at w + channel
+    const Act acts[7] = {{0, 1, 2, 56, 25, 56}, {3, 4, 5, 12, 56, 12}, {6, 7, 8, 12, 108, 12}, {9, 10, 11, 12, 108, 12}, {12, 13, 14, 12, 108, 12},
+                         {15, 16, 17, 12, 108, 12}, {18, 19, 20, 56, 12, 56}};
+    if (!fs_exact)
+      for (const Act& A : acts)
+        for (int c = 0; c < A.channels; ++c) if (!(blob[off[A.a] + c] > -0.875f)) fs_exact = true;
     if (!fs_exact) {   // (both matrix-core modes: fp16 and fp32-grade)
-      // (offsets into `blob`: 0 w_feat [25][56], 1 b_feat, 2 a_feat, 3 w_shrink [56][12], 4 b, 5 a, 6 + 3l w_map[l] [9][12][12] (tap, cin, cout),
-      //  7 + 3l b, 8 + 3l a, 18 w_expand [12][56], 19 b, 20 a, 21 w_deconv [81][56] (tap, cin))
-      auto flip = [&](float* p, size_t count, size_t stride) { for (size_t i = 0; i < count; ++i) p[i * stride] = -p[i * stride]; };
       float* B = blob.data();
-      for (int c = 0; c < 56; ++c) if (B[off[2] + c] > 1.f) {          // feature extraction -> shrink
-        flip(B + off[0] + c, 25, 56); flip(B + off[1] + c, 1, 1); flip(B + off[3] + (size_t)c * 12, 12, 1);
-      }
-      for (int c = 0; c < 12; ++c) if (B[off[5] + c] > 1.f) {          // shrink -> map 0
-        flip(B + off[3] + c, 56, 12); flip(B + off[4] + c, 1, 1);
-        for (int t = 0; t < 9; ++t) flip(B + off[6] + ((size_t)t * 12 + c) * 12, 12, 1);
-      }
-      for (int l = 0; l < 4; ++l)
-        for (int c = 0; c < 12; ++c) if (B[off[8 + 3 * l] + c] > 1.f) {   // map l -> map l + 1 | expand
-          flip(B + off[6 + 3 * l] + c, 9 * 12, 12); flip(B + off[7 + 3 * l] + c, 1, 1);
-          if (l < 3) { for (int t = 0; t < 9; ++t) flip(B + off[6 + 3 * (l + 1)] + ((size_t)t * 12 + c) * 12, 12, 1); }
-          else flip(B + off[18] + (size_t)c * 56, 56, 1);
+      for (const Act& A : acts)
+        for (int c = 0; c < A.channels; ++c) {
+          const float sl = B[off[A.a] + c], sa = 0.5f * (1.f + sl);
+          for (int i = 0; i < A.count; ++i) B[off[A.w] + c + (size_t)i * A.stride] *= sa;
+          B[off[A.b] + c] *= sa;
+          B[off[A.a] + c] = (1.f - sl) / (1.f + sl);
         }
-      for (int c = 0; c < 56; ++c) if (B[off[20] + c] > 1.f) {         // expand -> transposed conv
-        flip(B + off[18] + c, 12, 56); flip(B + off[19] + c, 1, 1); flip(B + off[21] + c, 81, 56);
-      }
-      fsw.prelu_le1 = true;   // (in the sense the kernels need: the max form is PReLU for every channel as it is carried)
+      fsw.prelu_abs = true;
     }
     upload(fs_blob, blob.data(), blob.size() * 4);
     weight_bytes = blob.size() * 4;

@@ -616,8 +616,8 @@ def test_fused_tails_full_size_identical(ctx):
 
 # ------------------------------------------------------------------------------ FSRCNN in fp16 (the reference engine's precision)
 def _wild_slopes(table, seed):
-    """Every PReLU slope redrawn from [-0.6, 1.8]: about a third of the channels of every layer get a slope above 1 - the channels an
-    fp16-mode model carries negated (max-form PReLU, models.cpp) - next to negative ones and ordinary ones."""
+    """Every PReLU slope redrawn from [-0.6, 1.8]: slopes above 1 (the real checkpoints have them), negative ones and ordinary ones.  The
+    matrix-core modes compute PReLU as y + c |y| on accumulators of weights scaled by (1 + s) / 2 (models.cpp): c runs from - 0.29 to 4."""
     t = dict(table)
     rng = np.random.default_rng(seed)
     for k in list(t):
@@ -628,9 +628,9 @@ def _wild_slopes(table, seed):
 
 @pytest.mark.parametrize("factor,shape", [(2, (3, 1, 70, 141)), (4, (2, 1, 45, 66))])
 def test_fsrcnn_f32_grade_wild_slopes_vs_oracle(ctx, factor, shape):
-    """fp32-grade mode with every PReLU slope redrawn from [-0.6, 1.8]: the matrix-core kernels take max(v, v s) and carry the channels with a
-    slope above 1 negated (weights folded at model build) - at the literal fp32 tolerance against the oracle, and against the exact-fp32
-    kernels, which run on the unfolded weights with the select form."""
+    """fp32-grade mode with every PReLU slope redrawn from [-0.6, 1.8]: the matrix-core kernels take the one-fma form on scaled weights
+    (models.cpp) - at the literal fp32 tolerance against the oracle, and against the exact-fp32 kernels, which run on the unscaled weights
+    with the select form."""
     table = _wild_slopes(W.fsrcnn_table(seed=factor), 10 + factor)
     x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[3]))
     with torch.no_grad():
@@ -639,6 +639,25 @@ def test_fsrcnn_f32_grade_wild_slopes_vs_oracle(ctx, factor, shape):
     assert_close(got, want, what=f"fsrcnn x{factor} wild slopes, fp32-grade")
     exact = _capi.Model(ctx, _capi.make_desc(_capi.FSRCNN, _capi.F32, scale=factor, flags=_capi.MODEL_FS_EXACT), W.flatten(table, W.fsrcnn_keys()))(x.cuda()).cpu()
     assert_close(exact, want, what=f"fsrcnn x{factor} wild slopes, exact kernels")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_fsrcnn_slope_near_minus_one_takes_the_exact_kernels(ctx, dtype):
+    """The one-fma PReLU needs (1 + s) / 2 > 0 with room to spare: a checkpoint with a slope at or below -0.875 (here -0.95 and -1.3 on some
+    channels; no real checkpoint has one) is run by the exact-fp32 kernels on unscaled weights, whatever dtype was asked for - fp32 tolerance."""
+    table = dict(W.fsrcnn_table(seed=7))
+    n = 0
+    for k in list(table):
+        v = np.asarray(table[k])
+        if v.ndim == 1 and k.endswith(".weight"):
+            v = v.copy(); v[0] = -0.95; v[-1] = -1.3
+            table[k] = v; n += 1
+    assert n == 7
+    x = torch.rand(3, 1, 40, 77, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        want = onets.fsrcnn(x, table, 2)
+    got = factory.build_model_fsrcnn(ctx, factor=2, weights=table, dtype=dtype)(x.cuda()).float().cpu()
+    assert_close(got, want, what=f"fsrcnn x2, slopes near -1, dtype {dtype} (exact kernels)")
 
 
 @pytest.mark.parametrize("factor,tag,shape", [(2, "t91", (3, 1, 150, 333)), (4, "t91", (3, 1, 97, 130)), (2, "syn", (12, 1, 64, 260)),
